@@ -1,0 +1,211 @@
+/*
+ * pdeip.h -- C-ABI of libpdeip.so: the MI355X (gfx950) implementation of the MEX-side
+ * stencil hot path of JediZ/PDE-based-image-processing.
+ *
+ * Boundary.  The reference's FFI for this path is MATLAB's MEX gateway,
+ *     void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]),
+ * one shared object per gateway source in mex/source/ (mex/buildAll.m:5-25).  Each
+ * `pdeip_<name>` host entry point below is what the body of one gateway forwards to
+ * after unpacking its mxArrays; it reproduces the gateway's semantics (copy-in,
+ * iter<=0 handling, residuals from the INPUT iterate, zero-initialised outputs) so the
+ * MEX stub is pure unpacking.  INTEGRATION.md shows the stubs.
+ *
+ * Data.  Every array is MATLAB column-major float32: element (row i, col j, frame k) at
+ * k*nrows*ncols + j*nrows + i.  Scalars that MATLAB passes as 1x1 singles (iter, omega,
+ * solver, eps) are plain int/float here; the stub does the cast the gateway did
+ * (e.g. Oflow_sor_elin4_2d.c:263-283).
+ *
+ * Two families of entry points:
+ *   pdeip_<name>(...)      host pointers, synchronous, stateless: H2D, solve, D2H.
+ *   pdeip_<name>_dev(...)  device pointers (resident in HBM), asynchronous on `stream`
+ *                          (a hipStream_t passed as void*; NULL = default stream), in
+ *                          place where the reference solves in place.
+ *
+ * All functions return PDEIP_OK or an error code; pdeip_last_error() gives the message
+ * (the text a stub hands to mexErrMsgTxt).  No exceptions cross the boundary.  The
+ * library keeps one lazily created context per process (device workspace cache); it is
+ * thread-compatible: one call at a time.
+ *
+ * Sweep ordering (pdeip_set_mode):
+ *   PDEIP_MODE_EXACT_ORDER  the reference's lexicographic Gauss-Seidel order, evaluated
+ *                           as a pipelined tile wavefront; results are bit-identical to
+ *                           the CPU restatement of the reference (default).
+ *   PDEIP_MODE_RED_BLACK    red-black (5-point) / four-colour (9-point) ordering with the
+ *                           same per-pixel arithmetic: the throughput and multi-GPU mode.
+ *                           Converges to the same fixed point; differs at finite `iter`.
+ */
+#ifndef PDEIP_H
+#define PDEIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDEIP_OK 0
+#define PDEIP_ERR_ARG 1         /* null pointer, nrows/ncols < 3, nframes < 1 */
+#define PDEIP_ERR_SOLVER 2      /* "no such solver" (gateway default: branch) */
+#define PDEIP_ERR_UNSUPPORTED 3 /* solver 2 (alternating line relaxation) has no device path yet */
+#define PDEIP_ERR_DEVICE 4      /* HIP runtime error / no gfx950 device */
+#define PDEIP_ERR_NOMEM 5
+
+#define PDEIP_MODE_EXACT_ORDER 0
+#define PDEIP_MODE_RED_BLACK 1
+
+#define PDEIP_SOLVER_SOR 1 /* point-wise Gauss-Seidel SOR */
+#define PDEIP_SOLVER_ALR 2 /* alternating line relaxation */
+
+/* ---- library state ------------------------------------------------------------------ */
+const char *pdeip_version(void);
+const char *pdeip_last_error(void);
+int pdeip_set_mode(int mode);
+int pdeip_get_mode(void);
+/* Select the HIP device used by the host-pointer entry points (default 0). */
+int pdeip_set_device(int device_id);
+/* Release the cached device workspace (optional; the process exit also releases it). */
+int pdeip_release(void);
+/* Number of kernel launches the last *_dev solver call enqueued (diagnostic). */
+int pdeip_last_launch_count(void);
+
+/* ---- host-pointer drop-in entry points -------------------------------------------------
+ * Output pointers marked "optional" may be NULL (the corresponding MATLAB output was not
+ * requested, nlhs too small). */
+
+/* [U,V(,RU,RV)] = Oflow_sor_elin4_2d(U,V,M,Cu,Cv,Du,Dv,wW,wN,wE,wS,iter,omega,solver)
+ * replaces mexFunction of mex/source/Oflow_sor_elin4_2d.c:64-352 -> GS_SOR_elin4_2d
+ * (library/opticalflowSolvers.c:41) + Residuals_elin4_2d (:269).
+ * M,Cu,Cv,Du,Dv are [nrows x ncols x nframes_coef]; the solver reads frame 0, the
+ * residuals every frame; RU,RV (optional, both or neither) are [.. x nframes_coef].
+ * iter<=0: U_out,V_out are all zero (Oflow_sor_elin4_2d.c:341-346). */
+int pdeip_oflow_sor_elin4(const float *U, const float *V, const float *M, const float *Cu,
+                          const float *Cv, const float *Du, const float *Dv, const float *wW,
+                          const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                          int nframes_coef, int iter, float omega, int solver, float *U_out,
+                          float *V_out, float *RU, float *RV);
+
+/* [dU,dV(,RU,RV)] = Oflow_sor_llin4_2d(U,V,dU,dV,M,Cu,Cv,Du,Dv,wW,wN,wE,wS,iter,omega,solver)
+ * replaces mex/source/Oflow_sor_llin4_2d.c:66-386 -> GS_SOR_llin4_2d
+ * (opticalflowSolvers.c:504) + Residuals_llin4_2d (:766). */
+int pdeip_oflow_sor_llin4(const float *U, const float *V, const float *dU, const float *dV,
+                          const float *M, const float *Cu, const float *Cv, const float *Du,
+                          const float *Dv, const float *wW, const float *wN, const float *wE,
+                          const float *wS, int nrows, int ncols, int nframes_coef, int iter,
+                          float omega, int solver, float *dU_out, float *dV_out, float *RU,
+                          float *RV);
+
+/* [dU,dV(,RU,RV)] = Oflow_sor_llin8_2d(U,V,dU,dV,M,Cu,Cv,Du,Dv,wW,wNW,wN,wNE,wE,wSE,wS,wSW,
+ *                                      iter,omega,solver)
+ * replaces mex/source/Oflow_sor_llin8_2d.c:71-489 -> GS_SOR_llin8_2d (opticalflowSolvers.c:1487),
+ * whose point solver never reads the diagonal weights (:1550-1591); they are accepted and
+ * ignored here too.  The gateway allocates RU,RV but never fills them (:466-488): zeros. */
+int pdeip_oflow_sor_llin8(const float *U, const float *V, const float *dU, const float *dV,
+                          const float *M, const float *Cu, const float *Cv, const float *Du,
+                          const float *Dv, const float *wW, const float *wNW, const float *wN,
+                          const float *wNE, const float *wE, const float *wSE, const float *wS,
+                          const float *wSW, int nrows, int ncols, int nframes_coef, int iter,
+                          float omega, int solver, float *dU_out, float *dV_out, float *RU,
+                          float *RV);
+
+/* [AU,AV] = Oflow_lhs_elin4_2d(U,V,M,Du,Dv,wW,wN,wE,wS)
+ * replaces mex/source/Oflow_lhs_elin4_2d.c:56-231 -> LHS_elin4_2d (opticalflowSolvers.c:387). */
+int pdeip_oflow_lhs_elin4(const float *U, const float *V, const float *M, const float *Du,
+                          const float *Dv, const float *wW, const float *wN, const float *wE,
+                          const float *wS, int nrows, int ncols, int nframes_coef, float *AU,
+                          float *AV);
+
+/* [AU,AV] = Oflow_lhs_llin4_2d(U,V,dU,dV,M,Du,Dv,wW,wN,wE,wS)
+ * replaces mex/source/Oflow_lhs_llin4_2d.c:59-260 -> LHS_llin4_2d (opticalflowSolvers.c:923),
+ * including its top-border quirk (:1056). */
+int pdeip_oflow_lhs_llin4(const float *U, const float *V, const float *dU, const float *dV,
+                          const float *M, const float *Du, const float *Dv, const float *wW,
+                          const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                          int nframes_coef, float *AU, float *AV);
+
+/* [dU(,RU)] = Disp_sor_llin4_2d(U,dU,Cu,Du,wW,wN,wE,wS,iter,omega,solver)
+ * replaces mex/source/Disp_sor_llin4_2d.c:59-282 -> GS_SOR_llin4_2d (disparitySolvers.c:41).
+ * The gateway allocates RU but never computes it (:251-281): zeros. */
+int pdeip_disp_sor_llin4(const float *U, const float *dU, const float *Cu, const float *Du,
+                         const float *wW, const float *wN, const float *wE, const float *wS,
+                         int nrows, int ncols, int iter, float omega, int solver, float *dU_out,
+                         float *RU);
+
+/* X = PDEsolver4(X,TRACE,B,wW,wN,wE,wS,iter,omega,solver)
+ * replaces mex/source/PDEsolver4.c:54-249 -> GS_SOR_4_2d (pdeSolvers.c:44).  Every plane is
+ * [nrows x ncols x nframes].  iter<=0 returns a copy (PDEsolver4.c:239).  solver 3 (unbound
+ * function pointer in the reference, PDEsolver4.c:228) is rejected with PDEIP_ERR_SOLVER. */
+int pdeip_pde_sor4(const float *X, const float *TRACE, const float *B, const float *wW,
+                   const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                   int nframes, int iter, float omega, int solver, float *X_out);
+
+/* X = PDEsolver8(X,TRACE,B,wW,wNW,wN,wNE,wE,wSE,wS,wSW,iter,omega,solver)
+ * replaces mex/source/PDEsolver8.c:54-309 -> GS_SOR_8_2d (pdeSolvers.c:153). */
+int pdeip_pde_sor8(const float *X, const float *TRACE, const float *B, const float *wW,
+                   const float *wNW, const float *wN, const float *wNE, const float *wE,
+                   const float *wSE, const float *wS, const float *wSW, int nrows, int ncols,
+                   int nframes, int iter, float omega, int solver, float *X_out);
+
+/* [wW,wN,wE,wS] = DdiffWeights(D,eps)
+ * replaces mex/source/DdiffWeights.c:50-140 -> diffWeights6_2D_c (imageDiffusionWeights.c:341).
+ * D and the four outputs are [nrows x ncols x nframes]; frame 0 of each output holds the
+ * weights (max over frames), frames >= 1 stay zero as in the gateway. */
+int pdeip_diffweights6(const float *D, int nrows, int ncols, int nframes, float eps, float *wW,
+                       float *wN, float *wE, float *wS);
+
+/* Iout = BilinInterp_2d(Iin,X,Y)
+ * replaces mex/source/BilinInterp_2d.c:41-124 -> bilinInterp2 (imageInterpolation.c:44).
+ * Iin,Iout are [nrows x ncols x nframes]; X,Y are [nrows x ncols] 1-based coordinates
+ * (X = column, Y = row).  Out-of-range samples are NaN. */
+int pdeip_warp_bilinear(const float *Iin, const float *X, const float *Y, int nrows, int ncols,
+                        int nframes, float *Iout);
+
+/* ---- device-pointer entry points ---------------------------------------------------------
+ * Same arithmetic on buffers already resident in HBM; asynchronous on `stream`.  Solvers work
+ * in place on the iterate and take the ordering `mode` explicitly.  iter<=0 is a no-op here
+ * (the gateway's zero/copy semantics belong to the host entry points).  `col0` is the
+ * global column index of local column 0 when the buffers are one slab of a column-slab
+ * decomposition (only its parity matters, for the colour of a pixel); 0 for a whole image. */
+int pdeip_oflow_sor_elin4_dev(void *stream, float *U, float *V, const float *M, const float *Cu,
+                              const float *Cv, const float *Du, const float *Dv, const float *wW,
+                              const float *wN, const float *wE, const float *wS, int nrows,
+                              int ncols, int iter, float omega, int mode, int col0);
+int pdeip_oflow_sor_llin4_dev(void *stream, const float *U, const float *V, float *dU, float *dV,
+                              const float *M, const float *Cu, const float *Cv, const float *Du,
+                              const float *Dv, const float *wW, const float *wN, const float *wE,
+                              const float *wS, int nrows, int ncols, int iter, float omega,
+                              int mode, int col0);
+int pdeip_disp_sor_llin4_dev(void *stream, const float *U, float *dU, const float *Cu,
+                             const float *Du, const float *wW, const float *wN, const float *wE,
+                             const float *wS, int nrows, int ncols, int iter, float omega,
+                             int mode, int col0);
+int pdeip_pde_sor4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
+                       const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                       int nframes, int iter, float omega, int mode, int col0);
+int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
+                       const float *wNW, const float *wN, const float *wNE, const float *wE,
+                       const float *wSE, const float *wS, const float *wSW, int nrows, int ncols,
+                       int nframes, int iter, float omega, int mode, int col0);
+int pdeip_oflow_res_elin4_dev(void *stream, float *RU, float *RV, const float *U, const float *V,
+                              const float *M, const float *Cu, const float *Cv, const float *Du,
+                              const float *Dv, const float *wW, const float *wN, const float *wE,
+                              const float *wS, int nrows, int ncols, int nframes_coef);
+int pdeip_oflow_lhs_elin4_dev(void *stream, float *AU, float *AV, const float *U, const float *V,
+                              const float *M, const float *Du, const float *Dv, const float *wW,
+                              const float *wN, const float *wE, const float *wS, int nrows,
+                              int ncols, int nframes_coef);
+int pdeip_oflow_res_llin4_dev(void *stream, float *RU, float *RV, const float *U, const float *V,
+                              const float *dU, const float *dV, const float *M, const float *Cu,
+                              const float *Cv, const float *Du, const float *Dv, const float *wW,
+                              const float *wN, const float *wE, const float *wS, int nrows,
+                              int ncols, int nframes_coef);
+int pdeip_oflow_lhs_llin4_dev(void *stream, float *AU, float *AV, const float *U, const float *V,
+                              const float *dU, const float *dV, const float *M, const float *Du,
+                              const float *Dv, const float *wW, const float *wN, const float *wE,
+                              const float *wS, int nrows, int ncols, int nframes_coef);
+int pdeip_diffweights6_dev(void *stream, const float *D, int nrows, int ncols, int nframes,
+                           float eps, float *wW, float *wN, float *wE, float *wS);
+int pdeip_warp_bilinear_dev(void *stream, const float *Iin, const float *X, const float *Y,
+                            int nrows, int ncols, int nframes, float *Iout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDEIP_H */

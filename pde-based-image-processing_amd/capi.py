@@ -1,0 +1,123 @@
+"""ctypes binding of libpdeip.so (include/pdeip.h).  Plumbing only: no arithmetic lives here.
+
+The library is the product.  If it is missing or does not load, every entry point raises
+PdeipError -- there is no CPU fallback of any kind.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpdeip.so")
+
+PDEIP_OK = 0
+PDEIP_ERR_ARG = 1
+PDEIP_ERR_SOLVER = 2
+PDEIP_ERR_UNSUPPORTED = 3
+PDEIP_ERR_DEVICE = 4
+PDEIP_ERR_NOMEM = 5
+MODE_EXACT_ORDER = 0
+MODE_RED_BLACK = 1
+
+_P = ctypes.c_void_p  # float* (host or device), passed as an address
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+
+class PdeipError(RuntimeError):
+    """An error reported by libpdeip.so (the text a MEX stub would hand to mexErrMsgTxt)."""
+
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+def _sig(n_ptr_before, tail):
+    return [_P] * n_ptr_before + tail
+
+
+# name -> argtypes, in the order of include/pdeip.h
+SIGNATURES = {
+    # host-pointer drop-in entry points
+    "pdeip_oflow_sor_elin4": _sig(11, [_I, _I, _I, _I, _F, _I, _P, _P, _P, _P]),
+    "pdeip_oflow_sor_llin4": _sig(13, [_I, _I, _I, _I, _F, _I, _P, _P, _P, _P]),
+    "pdeip_oflow_sor_llin8": _sig(17, [_I, _I, _I, _I, _F, _I, _P, _P, _P, _P]),
+    "pdeip_oflow_lhs_elin4": _sig(9, [_I, _I, _I, _P, _P]),
+    "pdeip_oflow_lhs_llin4": _sig(11, [_I, _I, _I, _P, _P]),
+    "pdeip_disp_sor_llin4": _sig(8, [_I, _I, _I, _F, _I, _P, _P]),
+    "pdeip_pde_sor4": _sig(7, [_I, _I, _I, _I, _F, _I, _P]),
+    "pdeip_pde_sor8": _sig(11, [_I, _I, _I, _I, _F, _I, _P]),
+    "pdeip_diffweights6": [_P, _I, _I, _I, _F, _P, _P, _P, _P],
+    "pdeip_warp_bilinear": [_P, _P, _P, _I, _I, _I, _P],
+    # device-pointer entry points (first argument: hipStream_t)
+    "pdeip_oflow_sor_elin4_dev": _sig(1 + 11, [_I, _I, _I, _F, _I, _I]),
+    "pdeip_oflow_sor_llin4_dev": _sig(1 + 13, [_I, _I, _I, _F, _I, _I]),
+    "pdeip_disp_sor_llin4_dev": _sig(1 + 8, [_I, _I, _I, _F, _I, _I]),
+    "pdeip_pde_sor4_dev": _sig(1 + 7, [_I, _I, _I, _I, _F, _I, _I]),
+    "pdeip_pde_sor8_dev": _sig(1 + 11, [_I, _I, _I, _I, _F, _I, _I]),
+    "pdeip_oflow_res_elin4_dev": _sig(1 + 13, [_I, _I, _I]),
+    "pdeip_oflow_lhs_elin4_dev": _sig(1 + 11, [_I, _I, _I]),
+    "pdeip_oflow_res_llin4_dev": _sig(1 + 15, [_I, _I, _I]),
+    "pdeip_oflow_lhs_llin4_dev": _sig(1 + 13, [_I, _I, _I]),
+    "pdeip_diffweights6_dev": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
+    "pdeip_warp_bilinear_dev": [_P, _P, _P, _P, _I, _I, _I, _P],
+    # library state
+    "pdeip_set_mode": [_I],
+    "pdeip_get_mode": [],
+    "pdeip_set_device": [_I],
+    "pdeip_release": [],
+    "pdeip_last_launch_count": [],
+}
+STRING_FUNCS = ("pdeip_version", "pdeip_last_error")
+
+_lib = None
+
+
+def load():
+    """Load libpdeip.so once and declare every prototype.  Raises PdeipError if it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PdeipError(PDEIP_ERR_DEVICE,
+                         "libpdeip.so is not built (%s). Run `python __graft_entry__.py build`; "
+                         "there is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # e.g. libamdhip64 missing
+        raise PdeipError(PDEIP_ERR_DEVICE, "cannot load %s: %s" % (LIB_PATH, exc)) from exc
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    for name in STRING_FUNCS:
+        fn = getattr(lib, name)
+        fn.argtypes = []
+        fn.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().pdeip_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != PDEIP_OK:
+        raise PdeipError(rc, last_error())
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise PdeipError on a non-zero status."""
+    check(getattr(load(), name)(*args))
+
+
+def set_mode(mode):
+    call("pdeip_set_mode", int(mode))
+
+
+def get_mode():
+    return load().pdeip_get_mode()
+
+
+def version():
+    return load().pdeip_version().decode()

@@ -1,0 +1,742 @@
+// pdeip_capi.hip -- libpdeip.so: context, launch logic and the extern "C" boundary (include/pdeip.h).
+//
+// Build (see build.py): hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared.
+// -ffp-contract=off is part of the parity contract: the reference is plain C built without FMA.
+#include "../../include/pdeip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "pdeip_models.hpp"
+#include "pdeip_pointwise.hpp"
+#include "pdeip_sor_exact.hpp"
+#include "pdeip_sor_pde8.hpp"
+#include "pdeip_sor_rb.hpp"
+
+using namespace pdeip;
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_NSLOT };
+
+struct Context {
+    int device = 0;
+    int mode = PDEIP_MODE_EXACT_ORDER;
+    int last_launches = 0;
+    char err[512] = "";
+    void *ws[WS_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[WS_NSLOT] = {0, 0, 0, 0};
+    int rb_tj = 0; // columns per red-black unit (0 = default)
+};
+Context g;
+
+int set_err(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g.err, sizeof g.err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return set_err(PDEIP_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+// Grow-only device workspace.  Growing synchronises the device (old buffer may be in use).
+int ws_get(int slot, size_t bytes, float **out)
+{
+    if (g.ws_bytes[slot] < bytes) {
+        HIPCHK(hipDeviceSynchronize());
+        if (g.ws[slot]) HIPCHK(hipFree(g.ws[slot]));
+        g.ws[slot] = nullptr;
+        g.ws_bytes[slot] = 0;
+        hipError_t e = hipMalloc(&g.ws[slot], bytes);
+        if (e != hipSuccess) return set_err(PDEIP_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        g.ws_bytes[slot] = bytes;
+    }
+    *out = static_cast<float *>(g.ws[slot]);
+    return PDEIP_OK;
+}
+
+int check_dims(const char *who, int nrows, int ncols, int nframes)
+{
+    if (nrows < 3 || ncols < 3)
+        return set_err(PDEIP_ERR_ARG, "%s: image must be at least 3x3 (got %dx%d)", who, nrows, ncols);
+    if (nframes < 1) return set_err(PDEIP_ERR_ARG, "%s: number of frames must be >= 1 (got %d)", who, nframes);
+    if ((long long)nrows * ncols * nframes > 0x7fffffffLL)
+        return set_err(PDEIP_ERR_ARG, "%s: more than 2^31-1 elements", who);
+    return PDEIP_OK;
+}
+
+int check_mode(const char *who, int mode)
+{
+    if (mode != PDEIP_MODE_EXACT_ORDER && mode != PDEIP_MODE_RED_BLACK)
+        return set_err(PDEIP_ERR_ARG, "%s: unknown sweep ordering %d", who, mode);
+    return PDEIP_OK;
+}
+
+// The gateways' solver switch (e.g. Oflow_sor_elin4_2d.c:328-338).
+int check_solver(const char *who, int solver)
+{
+    if (solver == PDEIP_SOLVER_SOR) return PDEIP_OK;
+    if (solver == PDEIP_SOLVER_ALR)
+        return set_err(PDEIP_ERR_UNSUPPORTED,
+                       "%s: solver 2 (alternating line relaxation) has no device implementation; use solver 1", who);
+    return set_err(PDEIP_ERR_SOLVER, "%s: no such solver", who);
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sweep drivers (5-point models)
+// ------------------------------------------------------------------------------------------------
+
+// Runs `iter` sweeps of model Mdl on the iterate buffers P.it_out (in place from the caller's
+// point of view).  P.cf / P.ro must be set; P.it_in is ignored.
+template <class Mdl>
+int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nframes, int iter,
+               float omega, int mode, int col0)
+{
+    constexpr int NIT = Mdl::NIT;
+    const size_t n = (size_t)nrows * ncols;
+    g.last_launches = 0;
+    if (iter <= 0) return PDEIP_OK;
+
+    if (mode == PDEIP_MODE_EXACT_ORDER) {
+        const int A = (nrows - 2 + 63 + EX_R - 1) / EX_R;
+        const int B = (ncols - 2 + 63) / 64;
+        const int last_m = (A - 1) + 2 * (B - 1) + 3 * (iter - 1);
+        for (int f = 0; f < NIT; f++) P.it_in[f] = P.it_out[f];
+        const dim3 grid((unsigned)(B * iter), (unsigned)nframes);
+        for (int m = 0; m <= last_m; m++) {
+            hipLaunchKernelGGL(k_sor_exact<Mdl>, grid, dim3(64), 0, s, P, nrows, ncols, A, B, iter, m, omega, n);
+            g.last_launches++;
+        }
+        const int nb = 2 * ncols + 2 * (nrows - 2);
+        hipLaunchKernelGGL(k_fill_borders, dim3((nb + 255) / 256, nframes, NIT), dim3(256), 0, s,
+                           P.it_out[0], P.it_out[NIT - 1], NIT, nrows, ncols, n);
+        g.last_launches++;
+        HIPCHK(hipGetLastError());
+        return PDEIP_OK;
+    }
+
+    // red-black: ping-pong between the caller's buffers and a scratch copy
+    float *scratch = nullptr;
+    int rc = ws_get(WS_PING, (size_t)NIT * n * nframes * sizeof(float), &scratch);
+    if (rc) return rc;
+    float *bufA[NIT], *bufB[NIT];
+    bool vec = (nrows % 4 == 0);
+    for (int f = 0; f < NIT; f++) {
+        bufA[f] = P.it_out[f];
+        bufB[f] = scratch + (size_t)f * n * nframes;
+        vec = vec && aligned16(bufA[f]) && aligned16(bufB[f]);
+    }
+    for (int f = 0; f < Mdl::NCF; f++) vec = vec && aligned16(P.cf[f]);
+    for (int f = 0; f < Mdl::NRO; f++) vec = vec && aligned16(P.ro[f]);
+
+    int TJ = g.rb_tj > 0 ? g.rb_tj : env_int("PDEIP_RB_TJ", 32);
+    if (TJ < 2) TJ = 2;
+    const int ntiles_r = (nrows + RB_OWN_ROWS - 1) / RB_OWN_ROWS;
+    const int nstrips = (ncols + TJ - 1) / TJ;
+    const int nunits = ntiles_r * nstrips;
+    const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);
+    const dim3 block(64 * RB_WAVES_PER_BLOCK);
+    for (int it = 0; it < iter; it++) {
+        for (int f = 0; f < NIT; f++) {
+            P.it_in[f] = (it & 1) ? bufB[f] : bufA[f];
+            P.it_out[f] = (it & 1) ? bufA[f] : bufB[f];
+        }
+        if (vec)
+            hipLaunchKernelGGL((k_sor_rb<Mdl, true>), grid, block, 0, s, P, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+        else
+            hipLaunchKernelGGL((k_sor_rb<Mdl, false>), grid, block, 0, s, P, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+        g.last_launches++;
+    }
+    if (iter & 1) // the last sweep wrote the scratch copy
+        for (int f = 0; f < NIT; f++)
+            HIPCHK(hipMemcpyAsync(bufA[f], bufB[f], n * nframes * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+dim3 pixel_grid(int nrows, int ncols, int nz) { return dim3((unsigned)((nrows + 255) / 256), (unsigned)ncols, (unsigned)nz); }
+
+// ------------------------------------------------------------------------------------------------
+// host staging: one arena per call, carved sequentially
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+    float *base = nullptr;
+    size_t cap = 0, used = 0;
+    int init(size_t nfloats)
+    {
+        // every plane starts 16-byte aligned so the vector path stays available
+        cap = nfloats;
+        used = 0;
+        return ws_get(WS_ARENA, nfloats * sizeof(float), &base);
+    }
+    float *take(size_t nfloats)
+    {
+        float *p = base + used;
+        used += (nfloats + 3) & ~(size_t)3;
+        return p;
+    }
+};
+size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+int upload(float *dst, const float *src, size_t nfloats)
+{
+    HIPCHK(hipMemcpy(dst, src, nfloats * sizeof(float), hipMemcpyHostToDevice));
+    return PDEIP_OK;
+}
+int download(float *dst, const float *src, size_t nfloats)
+{
+    HIPCHK(hipMemcpy(dst, src, nfloats * sizeof(float), hipMemcpyDeviceToHost));
+    return PDEIP_OK;
+}
+
+#define RC(expr)                  \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_) return rc_;      \
+    } while (0)
+
+#define NONNULL(who, p)                                                                    \
+    do {                                                                                   \
+        if ((p) == nullptr) return set_err(PDEIP_ERR_ARG, "%s: argument '%s' is NULL", who, #p); \
+    } while (0)
+
+int use_device()
+{
+    HIPCHK(hipSetDevice(g.device));
+    return PDEIP_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// library state
+// ------------------------------------------------------------------------------------------------
+extern "C" const char *pdeip_version(void) { return "pdeip-mi355x 0.1 (gfx950)"; }
+extern "C" const char *pdeip_last_error(void) { return g.err; }
+extern "C" int pdeip_set_mode(int mode)
+{
+    RC(check_mode("pdeip_set_mode", mode));
+    g.mode = mode;
+    return PDEIP_OK;
+}
+extern "C" int pdeip_get_mode(void) { return g.mode; }
+extern "C" int pdeip_set_device(int device_id)
+{
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return set_err(PDEIP_ERR_ARG, "pdeip_set_device: no device %d (have %d)", device_id, n);
+    if (device_id != g.device) pdeip_release();
+    g.device = device_id;
+    return PDEIP_OK;
+}
+extern "C" int pdeip_release(void)
+{
+    for (int s = 0; s < WS_NSLOT; s++) {
+        if (g.ws[s]) (void)hipFree(g.ws[s]);
+        g.ws[s] = nullptr;
+        g.ws_bytes[s] = 0;
+    }
+    return PDEIP_OK;
+}
+extern "C" int pdeip_last_launch_count(void) { return g.last_launches; }
+
+// ------------------------------------------------------------------------------------------------
+// device-pointer entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int pdeip_oflow_sor_elin4_dev(void *stream, float *U, float *V, const float *M, const float *Cu,
+                                         const float *Cv, const float *Du, const float *Dv, const float *wW,
+                                         const float *wN, const float *wE, const float *wS, int nrows,
+                                         int ncols, int iter, float omega, int mode, int col0)
+{
+    const char *who = "pdeip_oflow_sor_elin4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (iter <= 0) return PDEIP_OK;
+    const size_t n = (size_t)nrows * ncols;
+    float *divU, *divV;
+    RC(ws_get(WS_AUX0, n * sizeof(float), &divU));
+    RC(ws_get(WS_AUX1, n * sizeof(float), &divV));
+    hipLaunchKernelGGL(k_oflow_divisors, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, divU, divV, Du, Dv, wW, wN, wE, wS, nrows, ncols);
+    SweepPlanes<ModelElin4> P{};
+    P.it_out[0] = U;
+    P.it_out[1] = V;
+    const float *cf[9] = {M, Cu, Cv, divU, divV, wW, wN, wE, wS};
+    for (int f = 0; f < 9; f++) P.cf[f] = cf[f];
+    RC(run_sweeps<ModelElin4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
+    g.last_launches++;
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_sor_llin4_dev(void *stream, const float *U, const float *V, float *dU, float *dV,
+                                         const float *M, const float *Cu, const float *Cv, const float *Du,
+                                         const float *Dv, const float *wW, const float *wN, const float *wE,
+                                         const float *wS, int nrows, int ncols, int iter, float omega,
+                                         int mode, int col0)
+{
+    const char *who = "pdeip_oflow_sor_llin4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (iter <= 0) return PDEIP_OK;
+    const size_t n = (size_t)nrows * ncols;
+    float *divU, *divV;
+    RC(ws_get(WS_AUX0, n * sizeof(float), &divU));
+    RC(ws_get(WS_AUX1, n * sizeof(float), &divV));
+    hipLaunchKernelGGL(k_oflow_divisors, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, divU, divV, Du, Dv, wW, wN, wE, wS, nrows, ncols);
+    SweepPlanes<ModelLlin4> P{};
+    P.it_out[0] = dU;
+    P.it_out[1] = dV;
+    P.ro[0] = U;
+    P.ro[1] = V;
+    const float *cf[9] = {M, Cu, Cv, divU, divV, wW, wN, wE, wS};
+    for (int f = 0; f < 9; f++) P.cf[f] = cf[f];
+    RC(run_sweeps<ModelLlin4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
+    g.last_launches++;
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_disp_sor_llin4_dev(void *stream, const float *U, float *dU, const float *Cu,
+                                        const float *Du, const float *wW, const float *wN, const float *wE,
+                                        const float *wS, int nrows, int ncols, int iter, float omega,
+                                        int mode, int col0)
+{
+    const char *who = "pdeip_disp_sor_llin4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (iter <= 0) return PDEIP_OK;
+    const size_t n = (size_t)nrows * ncols;
+    float *dividend, *div;
+    RC(ws_get(WS_AUX0, n * sizeof(float), &dividend));
+    RC(ws_get(WS_AUX1, n * sizeof(float), &div));
+    hipLaunchKernelGGL(k_disp_divisors, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, dividend, div, Cu, Du, wW, wN, wE, wS, nrows, ncols);
+    SweepPlanes<ModelDisp4> P{};
+    P.it_out[0] = dU;
+    P.ro[0] = U;
+    const float *cf[6] = {dividend, div, wW, wN, wE, wS};
+    for (int f = 0; f < 6; f++) P.cf[f] = cf[f];
+    RC(run_sweeps<ModelDisp4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
+    g.last_launches++;
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_pde_sor4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
+                                  const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                                  int nframes, int iter, float omega, int mode, int col0)
+{
+    const char *who = "pdeip_pde_sor4_dev";
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (iter <= 0) return PDEIP_OK;
+    const size_t n = (size_t)nrows * ncols;
+    float *bt, *inv;
+    RC(ws_get(WS_AUX0, n * nframes * sizeof(float), &bt));
+    RC(ws_get(WS_AUX1, n * nframes * sizeof(float), &inv));
+    hipLaunchKernelGGL(k_pde4_divisors, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, bt, inv, TRACE, B, wW, wN, wE, wS, nrows, ncols, n);
+    SweepPlanes<ModelPde4> P{};
+    P.it_out[0] = X;
+    const float *cf[6] = {bt, inv, wW, wN, wE, wS};
+    for (int f = 0; f < 6; f++) P.cf[f] = cf[f];
+    RC(run_sweeps<ModelPde4>(s, P, nrows, ncols, nframes, iter, omega, mode, col0));
+    g.last_launches++;
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
+                                  const float *wNW, const float *wN, const float *wNE, const float *wE,
+                                  const float *wSE, const float *wS, const float *wSW, int nrows, int ncols,
+                                  int nframes, int iter, float omega, int mode, int col0)
+{
+    const char *who = "pdeip_pde_sor8_dev";
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    g.last_launches = 0;
+    if (iter <= 0) return PDEIP_OK;
+    const size_t n = (size_t)nrows * ncols;
+    float *bt, *inv, *scratch;
+    RC(ws_get(WS_AUX0, n * nframes * sizeof(float), &bt));
+    RC(ws_get(WS_AUX1, n * nframes * sizeof(float), &inv));
+    hipLaunchKernelGGL(k_pde8_divisors, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, bt, inv, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, nrows, ncols, n);
+    g.last_launches++;
+    Pde8Planes P{};
+    P.x = X;
+    const float *cf[ModelPde8::NCF] = {bt, inv, wW, wNW, wN, wNE, wE, wSE, wS, wSW};
+    for (int f = 0; f < ModelPde8::NCF; f++) P.cf[f] = cf[f];
+    if (mode == PDEIP_MODE_EXACT_ORDER) {
+        RC(ws_get(WS_PING, pde8_exact_scratch_floats(nrows, ncols, nframes, iter) * sizeof(float), &scratch));
+        g.last_launches += pde8_run_exact(s, P, scratch, nrows, ncols, nframes, iter, omega);
+    } else {
+        g.last_launches += pde8_run_colour(s, P, nrows, ncols, nframes, iter, omega, col0);
+    }
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_res_elin4_dev(void *stream, float *RU, float *RV, const float *U, const float *V,
+                                         const float *M, const float *Cu, const float *Cv, const float *Du,
+                                         const float *Dv, const float *wW, const float *wN, const float *wE,
+                                         const float *wS, int nrows, int ncols, int nframes_coef)
+{
+    RC(check_dims("pdeip_oflow_res_elin4_dev", nrows, ncols, nframes_coef));
+    hipLaunchKernelGGL((k_oflow_operator<false, false>), pixel_grid(nrows, ncols, nframes_coef), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), RU, RV, U, V, nullptr, nullptr, M, Cu, Cv, Du, Dv, wW,
+                       wN, wE, wS, nrows, ncols, (size_t)nrows * ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_lhs_elin4_dev(void *stream, float *AU, float *AV, const float *U, const float *V,
+                                         const float *M, const float *Du, const float *Dv, const float *wW,
+                                         const float *wN, const float *wE, const float *wS, int nrows,
+                                         int ncols, int nframes_coef)
+{
+    RC(check_dims("pdeip_oflow_lhs_elin4_dev", nrows, ncols, nframes_coef));
+    hipLaunchKernelGGL((k_oflow_operator<false, true>), pixel_grid(nrows, ncols, nframes_coef), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), AU, AV, U, V, nullptr, nullptr, M, nullptr, nullptr, Du, Dv,
+                       wW, wN, wE, wS, nrows, ncols, (size_t)nrows * ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_res_llin4_dev(void *stream, float *RU, float *RV, const float *U, const float *V,
+                                         const float *dU, const float *dV, const float *M, const float *Cu,
+                                         const float *Cv, const float *Du, const float *Dv, const float *wW,
+                                         const float *wN, const float *wE, const float *wS, int nrows,
+                                         int ncols, int nframes_coef)
+{
+    RC(check_dims("pdeip_oflow_res_llin4_dev", nrows, ncols, nframes_coef));
+    hipLaunchKernelGGL((k_oflow_operator<true, false>), pixel_grid(nrows, ncols, nframes_coef), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), RU, RV, U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS,
+                       nrows, ncols, (size_t)nrows * ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_lhs_llin4_dev(void *stream, float *AU, float *AV, const float *U, const float *V,
+                                         const float *dU, const float *dV, const float *M, const float *Du,
+                                         const float *Dv, const float *wW, const float *wN, const float *wE,
+                                         const float *wS, int nrows, int ncols, int nframes_coef)
+{
+    RC(check_dims("pdeip_oflow_lhs_llin4_dev", nrows, ncols, nframes_coef));
+    hipLaunchKernelGGL((k_oflow_operator<true, true>), pixel_grid(nrows, ncols, nframes_coef), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), AU, AV, U, V, dU, dV, M, nullptr, nullptr, Du, Dv, wW, wN,
+                       wE, wS, nrows, ncols, (size_t)nrows * ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_diffweights6_dev(void *stream, const float *D, int nrows, int ncols, int nframes,
+                                      float eps, float *wW, float *wN, float *wE, float *wS)
+{
+    RC(check_dims("pdeip_diffweights6_dev", nrows, ncols, nframes));
+    hipLaunchKernelGGL(k_diffweights6, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       wW, wN, wE, wS, D, nrows, ncols, nframes, eps);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_warp_bilinear_dev(void *stream, const float *Iin, const float *X, const float *Y,
+                                       int nrows, int ncols, int nframes, float *Iout)
+{
+    RC(check_dims("pdeip_warp_bilinear_dev", nrows, ncols, nframes));
+    hipLaunchKernelGGL(k_warp_bilinear, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       Iout, Iin, X, Y, nrows, ncols, nframes);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-pointer drop-in entry points (gateway semantics)
+// ------------------------------------------------------------------------------------------------
+
+// Shared body of Oflow_sor_elin4_2d / Oflow_sor_llin4_2d / Oflow_sor_llin8_2d.
+static int oflow_sor_host(const char *who, bool llin, bool fill_residuals, const float *U, const float *V,
+                          const float *dU, const float *dV, const float *M, const float *Cu, const float *Cv,
+                          const float *Du, const float *Dv, const float *wW, const float *wN, const float *wE,
+                          const float *wS, int nrows, int ncols, int F, int iter, float omega, int solver,
+                          float *o0, float *o1, float *RU, float *RV)
+{
+    NONNULL(who, U); NONNULL(who, V); NONNULL(who, M); NONNULL(who, Cu); NONNULL(who, Cv); NONNULL(who, Du);
+    NONNULL(who, Dv); NONNULL(who, wW); NONNULL(who, wN); NONNULL(who, wE); NONNULL(who, wS);
+    NONNULL(who, o0); NONNULL(who, o1);
+    if (llin) { NONNULL(who, dU); NONNULL(who, dV); }
+    if ((RU == nullptr) != (RV == nullptr))
+        return set_err(PDEIP_ERR_ARG, "%s: residual outputs RU and RV must be requested together", who);
+    RC(check_dims(who, nrows, ncols, F));
+    RC(check_solver(who, solver));
+    RC(use_device());
+    const size_t n = (size_t)nrows * ncols, nf = n * (size_t)F;
+
+    Arena ar;
+    RC(ar.init(pad4(n) * 12 + pad4(nf) * 7));
+    float *dUin = ar.take(n), *dVin = ar.take(n), *ddU = ar.take(n), *ddV = ar.take(n);
+    float *dM = ar.take(nf), *dCu = ar.take(nf), *dCv = ar.take(nf), *dDu = ar.take(nf), *dDv = ar.take(nf);
+    float *dwW = ar.take(n), *dwN = ar.take(n), *dwE = ar.take(n), *dwS = ar.take(n);
+    float *do0 = ar.take(n), *do1 = ar.take(n), *dRU = ar.take(nf), *dRV = ar.take(nf);
+    (void)ar.take(n); (void)ar.take(n);
+    RC(upload(dUin, U, n)); RC(upload(dVin, V, n));
+    if (llin) { RC(upload(ddU, dU, n)); RC(upload(ddV, dV, n)); }
+    RC(upload(dM, M, nf)); RC(upload(dCu, Cu, nf)); RC(upload(dCv, Cv, nf)); RC(upload(dDu, Du, nf)); RC(upload(dDv, Dv, nf));
+    RC(upload(dwW, wW, n)); RC(upload(dwN, wN, n)); RC(upload(dwE, wE, n)); RC(upload(dwS, wS, n));
+
+    if (iter > 0) { // copy the iterate in, relax it in place (Oflow_sor_elin4_2d.c:341-346)
+        HIPCHK(hipMemcpyAsync(do0, llin ? ddU : dUin, n * sizeof(float), hipMemcpyDeviceToDevice, 0));
+        HIPCHK(hipMemcpyAsync(do1, llin ? ddV : dVin, n * sizeof(float), hipMemcpyDeviceToDevice, 0));
+        if (llin)
+            RC(pdeip_oflow_sor_llin4_dev(nullptr, dUin, dVin, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
+        else
+            RC(pdeip_oflow_sor_elin4_dev(nullptr, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
+        RC(download(o0, do0, n));
+        RC(download(o1, do1, n));
+    } else { // outputs stay as mxCreateNumericArray made them: zero
+        memset(o0, 0, n * sizeof(float));
+        memset(o1, 0, n * sizeof(float));
+    }
+    if (RU) { // residuals of the INPUT iterate (:349-350)
+        if (!fill_residuals) {
+            memset(RU, 0, nf * sizeof(float));
+            memset(RV, 0, nf * sizeof(float));
+        } else {
+            if (llin)
+                RC(pdeip_oflow_res_llin4_dev(nullptr, dRU, dRV, dUin, dVin, ddU, ddV, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, F));
+            else
+                RC(pdeip_oflow_res_elin4_dev(nullptr, dRU, dRV, dUin, dVin, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, F));
+            RC(download(RU, dRU, nf));
+            RC(download(RV, dRV, nf));
+        }
+    }
+    HIPCHK(hipDeviceSynchronize());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_sor_elin4(const float *U, const float *V, const float *M, const float *Cu,
+                                     const float *Cv, const float *Du, const float *Dv, const float *wW,
+                                     const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                                     int nframes_coef, int iter, float omega, int solver, float *U_out,
+                                     float *V_out, float *RU, float *RV)
+{
+    return oflow_sor_host("Oflow_sor_elin4_2d", false, true, U, V, nullptr, nullptr, M, Cu, Cv, Du, Dv, wW, wN, wE,
+                          wS, nrows, ncols, nframes_coef, iter, omega, solver, U_out, V_out, RU, RV);
+}
+
+extern "C" int pdeip_oflow_sor_llin4(const float *U, const float *V, const float *dU, const float *dV,
+                                     const float *M, const float *Cu, const float *Cv, const float *Du,
+                                     const float *Dv, const float *wW, const float *wN, const float *wE,
+                                     const float *wS, int nrows, int ncols, int nframes_coef, int iter,
+                                     float omega, int solver, float *dU_out, float *dV_out, float *RU, float *RV)
+{
+    return oflow_sor_host("Oflow_sor_llin4_2d", true, true, U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, nrows,
+                          ncols, nframes_coef, iter, omega, solver, dU_out, dV_out, RU, RV);
+}
+
+extern "C" int pdeip_oflow_sor_llin8(const float *U, const float *V, const float *dU, const float *dV,
+                                     const float *M, const float *Cu, const float *Cv, const float *Du,
+                                     const float *Dv, const float *wW, const float *wNW, const float *wN,
+                                     const float *wNE, const float *wE, const float *wSE, const float *wS,
+                                     const float *wSW, int nrows, int ncols, int nframes_coef, int iter,
+                                     float omega, int solver, float *dU_out, float *dV_out, float *RU, float *RV)
+{
+    const char *who = "Oflow_sor_llin8_2d";
+    NONNULL(who, wNW); NONNULL(who, wNE); NONNULL(who, wSE); NONNULL(who, wSW);
+    // GS_SOR_llin8_2d never reads the diagonal weights (opticalflowSolvers.c:1550-1591), and the gateway
+    // leaves RU,RV unfilled (Oflow_sor_llin8_2d.c:466-488).
+    return oflow_sor_host(who, true, false, U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, nrows, ncols,
+                          nframes_coef, iter, omega, solver, dU_out, dV_out, RU, RV);
+}
+
+static int oflow_lhs_host(const char *who, bool llin, const float *U, const float *V, const float *dU,
+                          const float *dV, const float *M, const float *Du, const float *Dv, const float *wW,
+                          const float *wN, const float *wE, const float *wS, int nrows, int ncols, int F,
+                          float *AU, float *AV)
+{
+    NONNULL(who, U); NONNULL(who, V); NONNULL(who, M); NONNULL(who, Du); NONNULL(who, Dv); NONNULL(who, wW);
+    NONNULL(who, wN); NONNULL(who, wE); NONNULL(who, wS); NONNULL(who, AU); NONNULL(who, AV);
+    if (llin) { NONNULL(who, dU); NONNULL(who, dV); }
+    RC(check_dims(who, nrows, ncols, F));
+    RC(use_device());
+    const size_t n = (size_t)nrows * ncols, nf = n * (size_t)F;
+    Arena ar;
+    RC(ar.init(pad4(n) * 8 + pad4(nf) * 5));
+    float *dUin = ar.take(n), *dVin = ar.take(n), *ddU = ar.take(n), *ddV = ar.take(n);
+    float *dM = ar.take(nf), *dDu = ar.take(nf), *dDv = ar.take(nf);
+    float *dwW = ar.take(n), *dwN = ar.take(n), *dwE = ar.take(n), *dwS = ar.take(n);
+    float *dAU = ar.take(nf), *dAV = ar.take(nf);
+    RC(upload(dUin, U, n)); RC(upload(dVin, V, n));
+    if (llin) { RC(upload(ddU, dU, n)); RC(upload(ddV, dV, n)); }
+    RC(upload(dM, M, nf)); RC(upload(dDu, Du, nf)); RC(upload(dDv, Dv, nf));
+    RC(upload(dwW, wW, n)); RC(upload(dwN, wN, n)); RC(upload(dwE, wE, n)); RC(upload(dwS, wS, n));
+    if (llin) RC(pdeip_oflow_lhs_llin4_dev(nullptr, dAU, dAV, dUin, dVin, ddU, ddV, dM, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, F));
+    else RC(pdeip_oflow_lhs_elin4_dev(nullptr, dAU, dAV, dUin, dVin, dM, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, F));
+    RC(download(AU, dAU, nf));
+    RC(download(AV, dAV, nf));
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_lhs_elin4(const float *U, const float *V, const float *M, const float *Du,
+                                     const float *Dv, const float *wW, const float *wN, const float *wE,
+                                     const float *wS, int nrows, int ncols, int nframes_coef, float *AU, float *AV)
+{
+    return oflow_lhs_host("Oflow_lhs_elin4_2d", false, U, V, nullptr, nullptr, M, Du, Dv, wW, wN, wE, wS, nrows,
+                          ncols, nframes_coef, AU, AV);
+}
+
+extern "C" int pdeip_oflow_lhs_llin4(const float *U, const float *V, const float *dU, const float *dV,
+                                     const float *M, const float *Du, const float *Dv, const float *wW,
+                                     const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                                     int nframes_coef, float *AU, float *AV)
+{
+    return oflow_lhs_host("Oflow_lhs_llin4_2d", true, U, V, dU, dV, M, Du, Dv, wW, wN, wE, wS, nrows, ncols,
+                          nframes_coef, AU, AV);
+}
+
+extern "C" int pdeip_disp_sor_llin4(const float *U, const float *dU, const float *Cu, const float *Du,
+                                    const float *wW, const float *wN, const float *wE, const float *wS,
+                                    int nrows, int ncols, int iter, float omega, int solver, float *dU_out, float *RU)
+{
+    const char *who = "Disp_sor_llin4_2d";
+    NONNULL(who, U); NONNULL(who, dU); NONNULL(who, Cu); NONNULL(who, Du); NONNULL(who, wW); NONNULL(who, wN);
+    NONNULL(who, wE); NONNULL(who, wS); NONNULL(who, dU_out);
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_solver(who, solver));
+    RC(use_device());
+    const size_t n = (size_t)nrows * ncols;
+    if (RU) memset(RU, 0, n * sizeof(float)); // allocated, never computed (Disp_sor_llin4_2d.c:251-281)
+    if (iter <= 0) { // output stays zero (:276-280)
+        memset(dU_out, 0, n * sizeof(float));
+        return PDEIP_OK;
+    }
+    Arena ar;
+    RC(ar.init(pad4(n) * 8));
+    float *dUin = ar.take(n), *ddU = ar.take(n), *dCu = ar.take(n), *dDu = ar.take(n);
+    float *dwW = ar.take(n), *dwN = ar.take(n), *dwE = ar.take(n), *dwS = ar.take(n);
+    RC(upload(dUin, U, n)); RC(upload(ddU, dU, n)); RC(upload(dCu, Cu, n)); RC(upload(dDu, Du, n));
+    RC(upload(dwW, wW, n)); RC(upload(dwN, wN, n)); RC(upload(dwE, wE, n)); RC(upload(dwS, wS, n));
+    RC(pdeip_disp_sor_llin4_dev(nullptr, dUin, ddU, dCu, dDu, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
+    RC(download(dU_out, ddU, n));
+    return PDEIP_OK;
+}
+
+// The PDE gateways accept solver 3 and then call an unbound function pointer (PDEsolver4.c:228);
+// that is rejected here like any other unknown solver.
+extern "C" int pdeip_pde_sor4(const float *X, const float *TRACE, const float *B, const float *wW, const float *wN,
+                              const float *wE, const float *wS, int nrows, int ncols, int nframes, int iter,
+                              float omega, int solver, float *X_out)
+{
+    const char *who = "PDEsolver4";
+    NONNULL(who, X); NONNULL(who, TRACE); NONNULL(who, B); NONNULL(who, wW); NONNULL(who, wN); NONNULL(who, wE);
+    NONNULL(who, wS); NONNULL(who, X_out);
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(check_solver(who, solver));
+    RC(use_device());
+    const size_t nf = (size_t)nrows * ncols * nframes;
+    if (iter <= 0) { // copy-in, zero sweeps (PDEsolver4.c:239-240)
+        memcpy(X_out, X, nf * sizeof(float));
+        return PDEIP_OK;
+    }
+    Arena ar;
+    RC(ar.init(pad4(nf) * 7));
+    float *dX = ar.take(nf), *dT = ar.take(nf), *dB = ar.take(nf);
+    float *dwW = ar.take(nf), *dwN = ar.take(nf), *dwE = ar.take(nf), *dwS = ar.take(nf);
+    RC(upload(dX, X, nf)); RC(upload(dT, TRACE, nf)); RC(upload(dB, B, nf));
+    RC(upload(dwW, wW, nf)); RC(upload(dwN, wN, nf)); RC(upload(dwE, wE, nf)); RC(upload(dwS, wS, nf));
+    RC(pdeip_pde_sor4_dev(nullptr, dX, dT, dB, dwW, dwN, dwE, dwS, nrows, ncols, nframes, iter, omega, g.mode, 0));
+    RC(download(X_out, dX, nf));
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_pde_sor8(const float *X, const float *TRACE, const float *B, const float *wW, const float *wNW,
+                              const float *wN, const float *wNE, const float *wE, const float *wSE, const float *wS,
+                              const float *wSW, int nrows, int ncols, int nframes, int iter, float omega,
+                              int solver, float *X_out)
+{
+    const char *who = "PDEsolver8";
+    NONNULL(who, X); NONNULL(who, TRACE); NONNULL(who, B); NONNULL(who, wW); NONNULL(who, wNW); NONNULL(who, wN);
+    NONNULL(who, wNE); NONNULL(who, wE); NONNULL(who, wSE); NONNULL(who, wS); NONNULL(who, wSW); NONNULL(who, X_out);
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(check_solver(who, solver));
+    RC(use_device());
+    const size_t nf = (size_t)nrows * ncols * nframes;
+    if (iter <= 0) {
+        memcpy(X_out, X, nf * sizeof(float));
+        return PDEIP_OK;
+    }
+    Arena ar;
+    RC(ar.init(pad4(nf) * 11));
+    float *dX = ar.take(nf), *dT = ar.take(nf), *dB = ar.take(nf);
+    const float *hw[8] = {wW, wNW, wN, wNE, wE, wSE, wS, wSW};
+    float *dw[8];
+    RC(upload(dX, X, nf)); RC(upload(dT, TRACE, nf)); RC(upload(dB, B, nf));
+    for (int k = 0; k < 8; k++) {
+        dw[k] = ar.take(nf);
+        RC(upload(dw[k], hw[k], nf));
+    }
+    RC(pdeip_pde_sor8_dev(nullptr, dX, dT, dB, dw[0], dw[1], dw[2], dw[3], dw[4], dw[5], dw[6], dw[7], nrows, ncols,
+                          nframes, iter, omega, g.mode, 0));
+    RC(download(X_out, dX, nf));
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_diffweights6(const float *D, int nrows, int ncols, int nframes, float eps, float *wW,
+                                  float *wN, float *wE, float *wS)
+{
+    const char *who = "DdiffWeights";
+    NONNULL(who, D); NONNULL(who, wW); NONNULL(who, wN); NONNULL(who, wE); NONNULL(who, wS);
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(use_device());
+    const size_t n = (size_t)nrows * ncols, nf = n * (size_t)nframes;
+    Arena ar;
+    RC(ar.init(pad4(nf) + pad4(n) * 4));
+    float *dD = ar.take(nf), *d0 = ar.take(n), *d1 = ar.take(n), *d2 = ar.take(n), *d3 = ar.take(n);
+    RC(upload(dD, D, nf));
+    RC(pdeip_diffweights6_dev(nullptr, dD, nrows, ncols, nframes, eps, d0, d1, d2, d3));
+    float *outs[4] = {wW, wN, wE, wS};
+    float *dev[4] = {d0, d1, d2, d3};
+    for (int k = 0; k < 4; k++) {
+        RC(download(outs[k], dev[k], n));
+        // outputs carry D's dimensions; only frame 0 is written (DdiffWeights.c:97-138)
+        if (nframes > 1) memset(outs[k] + n, 0, (nf - n) * sizeof(float));
+    }
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_warp_bilinear(const float *Iin, const float *X, const float *Y, int nrows, int ncols,
+                                   int nframes, float *Iout)
+{
+    const char *who = "BilinInterp_2d";
+    NONNULL(who, Iin); NONNULL(who, X); NONNULL(who, Y); NONNULL(who, Iout);
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(use_device());
+    const size_t n = (size_t)nrows * ncols, nf = n * (size_t)nframes;
+    Arena ar;
+    RC(ar.init(pad4(nf) * 2 + pad4(n) * 2));
+    float *dI = ar.take(nf), *dX = ar.take(n), *dY = ar.take(n), *dO = ar.take(nf);
+    RC(upload(dI, Iin, nf)); RC(upload(dX, X, n)); RC(upload(dY, Y, n));
+    RC(pdeip_warp_bilinear_dev(nullptr, dI, dX, dY, nrows, ncols, nframes, dO));
+    RC(download(Iout, dO, nf));
+    return PDEIP_OK;
+}

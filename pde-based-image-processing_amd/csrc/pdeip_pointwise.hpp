@@ -1,0 +1,289 @@
+// pdeip_pointwise.hpp -- the embarrassingly parallel kernels of the path (gfx950):
+// divisor prologues, residual / LHS operators, diffusion weights and the bilinear warp.
+//
+// Thread mapping for all of them: threadIdx.x runs along the image row index i (the
+// contiguous direction), so every plane access of a wave is one coalesced segment.
+// Residual/LHS outputs include the reference's border replicate by evaluating the operator at
+// the clamped interior coordinate, so no second pass (and no inter-workgroup ordering) is needed.
+#pragma once
+#include "pdeip_models.hpp"
+
+namespace pdeip {
+
+#define PDEIP_PIXEL_INDEX()                                          \
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;             \
+    const int j = blockIdx.y;                                        \
+    if (i >= nrows) return;                                          \
+    const size_t pos = (size_t)j * nrows + i
+
+// ---- divisor prologues (what the reference builds during its first sweep) -------------------
+
+// opticalflowSolvers.c:111-127 / :606-622
+__global__ void k_oflow_divisors(float *divU, float *divV, const float *Du, const float *Dv,
+                                 const float *wW, const float *wN, const float *wE,
+                                 const float *wS, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    float t1 = wW[pos] + wE[pos];
+    float t2 = wN[pos] + wS[pos];
+    t1 += t2;
+    const float du = Du[pos], dv = Dv[pos];
+    divU[pos] = is_nan(du) ? 1.0f / t1 : 1.0f / (t1 + du);
+    divV[pos] = is_nan(dv) ? 1.0f / t1 : 1.0f / (t1 + dv);
+}
+
+// disparitySolvers.c:94-113
+__global__ void k_disp_divisors(float *dividend, float *div, const float *Cu, const float *Du,
+                                const float *wW, const float *wN, const float *wE,
+                                const float *wS, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    const float cu = Cu[pos];
+    const bool ok = !is_nan(cu);
+    float t = ok ? Du[pos] + wE[pos] : wE[pos];
+    t = t + wW[pos];
+    t = t + wS[pos];
+    t = t + wN[pos];
+    dividend[pos] = ok ? cu : 0.0f;
+    div[pos] = 1.0f / t;
+}
+
+// pdeSolvers.c:99-115
+__global__ void k_pde4_divisors(float *bt, float *inv, const float *TRACE, const float *B,
+                                const float *wW, const float *wN, const float *wE,
+                                const float *wS, int nrows, int ncols, size_t frame_stride)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t p = pos + (size_t)blockIdx.z * frame_stride;
+    const float tr = TRACE[p];
+    float t = wE[p] + wW[p];
+    t += wS[p] + wN[p];
+    const bool ok = !is_nan(tr);
+    inv[p] = ok ? 1.0f / tr : 1.0f / t;
+    bt[p] = ok ? B[p] : 0.0f;
+}
+
+// pdeSolvers.c:217-237
+__global__ void k_pde8_divisors(float *bt, float *inv, const float *TRACE, const float *B,
+                                const float *wW, const float *wNW, const float *wN,
+                                const float *wNE, const float *wE, const float *wSE,
+                                const float *wS, const float *wSW, int nrows, int ncols,
+                                size_t frame_stride)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t p = pos + (size_t)blockIdx.z * frame_stride;
+    const float tr = TRACE[p];
+    float t = wE[p] + wW[p];
+    t += wS[p] + wN[p];
+    t += wSW[p] + wNW[p];
+    t += wSE[p] + wNE[p];
+    const bool ok = !is_nan(tr);
+    inv[p] = ok ? 1.0f / tr : 1.0f / t;
+    bt[p] = ok ? B[p] : 0.0f;
+}
+
+// ---- residual / LHS of the coupled (u,v) systems ---------------------------------------------
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// LLIN: late linearization (iterate = dU,dV on top of U,V); else early linearization.
+// LHS : A*x instead of b - A*x.
+// opticalflowSolvers.c:269-380, :387-496, :766-916, :923-1070
+template <bool LLIN, bool LHS>
+__device__ __forceinline__ void oflow_operator(float &outU, float &outV, int ii, int jj, int nrows,
+                                               size_t fo, const float *U, const float *V,
+                                               const float *dU, const float *dV, const float *M,
+                                               const float *Cu, const float *Cv, const float *Du,
+                                               const float *Dv, const float *wW, const float *wN,
+                                               const float *wE, const float *wS)
+{
+    const size_t pos = (size_t)jj * nrows + ii, os = pos + fo;
+    const float ww = wW[pos], wn = wN[pos], we = wE[pos], ws = wS[pos];
+    float nbU, nbV, xu, xv; // neighbourhood sums and the centre unknowns
+    if (LLIN) {
+        float a = dU[pos - nrows] + U[pos - nrows], b = dU[pos + nrows] + U[pos + nrows];
+        float c = dU[pos - 1] + U[pos - 1], d = dU[pos + 1] + U[pos + 1];
+        const float uc = U[pos];
+        a -= uc; b -= uc; c -= uc; d -= uc;
+        a *= ww; b *= we; c *= wn; d *= ws;
+        a += b; c += d; a += c;
+        nbU = a;
+        a = dV[pos - nrows] + V[pos - nrows]; b = dV[pos + nrows] + V[pos + nrows];
+        c = dV[pos - 1] + V[pos - 1]; d = dV[pos + 1] + V[pos + 1];
+        const float vc = V[pos];
+        a -= vc; b -= vc; c -= vc; d -= vc;
+        a *= ww; b *= we; c *= wn; d *= ws;
+        a += b; c += d; a += c;
+        nbV = a;
+        xu = dU[pos];
+        xv = dV[pos];
+    } else {
+        nbU = U[pos - nrows] * ww;
+        nbU = nbU + U[pos + nrows] * we;
+        nbU = nbU + U[pos - 1] * wn;
+        nbU = nbU + U[pos + 1] * ws;
+        nbV = V[pos - nrows] * ww;
+        nbV = nbV + V[pos + nrows] * we;
+        nbV = nbV + V[pos - 1] * wn;
+        nbV = nbV + V[pos + 1] * ws;
+        xu = U[pos];
+        xv = V[pos];
+    }
+    float s = ww + we;
+    const float s2 = wn + ws;
+    s += s2;
+    const float m = M[os];
+    if (LHS) {
+        const float du = Du[os], dv = Dv[os];
+        float t = m * xv - nbU;
+        outU = !is_nan(du) ? t + (du + s) * xu : -nbU + s * xu;
+        t = m * xu - nbV;
+        outV = !is_nan(dv) ? t + (dv + s) * xv : -nbV + s * xv;
+    } else {
+        const float cu = Cu[os], cv = Cv[os];
+        float t = cu - m * xv;
+        t = t + nbU;
+        outU = !is_nan(cu) ? t - (Du[os] + s) * xu : nbU - s * xu;
+        t = cv - m * xu;
+        t = t + nbV;
+        outV = !is_nan(cv) ? t - (Dv[os] + s) * xv : nbV - s * xv;
+    }
+}
+
+template <bool LLIN, bool LHS>
+__global__ void k_oflow_operator(float *OU, float *OV, const float *U, const float *V,
+                                 const float *dU, const float *dV, const float *M, const float *Cu,
+                                 const float *Cv, const float *Du, const float *Dv, const float *wW,
+                                 const float *wN, const float *wE, const float *wS, int nrows,
+                                 int ncols, size_t frame_stride)
+{
+    PDEIP_PIXEL_INDEX();
+    const int k = blockIdx.z;
+    const size_t fo = (size_t)k * frame_stride;
+    const int ii = clampi(i, 1, nrows - 2);
+    int jj = clampi(j, 1, ncols - 2);
+    float ou, ov;
+    oflow_operator<LLIN, LHS>(ou, ov, ii, jj, nrows, fo, U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS);
+    if (LLIN && !LHS && j == 0 && k > 0) {
+        // Residuals_llin4_2d fills the west border of RV from frame 0 (opticalflowSolvers.c:912)
+        float dummy;
+        oflow_operator<LLIN, LHS>(dummy, ov, ii, 1, nrows, 0, U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS);
+    }
+    if (LLIN && LHS && i == 0) {
+        // LHS_llin4_2d fills the north border of AV from a stale frame-0 cell
+        // (opticalflowSolvers.c:1056): zero in frame 0, AV(nrows-2, ncols-2, frame 0) afterwards
+        if (k == 0) ov = 0.0f;
+        else {
+            float dummy;
+            oflow_operator<LLIN, LHS>(dummy, ov, nrows - 2, ncols - 2, nrows, 0, U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS);
+        }
+    }
+    OU[pos + fo] = ou;
+    OV[pos + fo] = ov;
+}
+
+// ---- diffusion weights: diffWeights6_2D_c (imageDiffusionWeights.c:341-378) -------------------
+
+__device__ __forceinline__ float dw_ver(const float *d, int i, int j, int nrows)
+{ // Dver :44-69: 0.25*D(north) - 0.25*D(south), replicate ends
+    const size_t pos = (size_t)j * nrows + i;
+    const float up = d[i > 0 ? pos - 1 : pos], dn = d[i < nrows - 1 ? pos + 1 : pos];
+    const float A = 0.25f * up, B = -0.25f * dn;
+    return A + B;
+}
+__device__ __forceinline__ float dw_hor(const float *d, int i, int j, int nrows, int ncols)
+{ // Dhor :85-108
+    const size_t pos = (size_t)j * nrows + i;
+    const float lf = d[j > 0 ? pos - nrows : pos], rt = d[j < ncols - 1 ? pos + nrows : pos];
+    const float A = 0.25f * lf, B = -0.25f * rt;
+    return A + B;
+}
+__device__ __forceinline__ float dw_inv_sqrt(float t, float eps)
+{ // :156  1.0f/(float)sqrt(temp+eps): correctly rounded f32 sqrt, then f32 divide.
+  // sqrtf() is the correctly rounded form here (v_sqrt_f32 + fma fix-up); __fsqrt_rn is the bare
+  // 1-ulp v_sqrt_f32 on this toolchain.
+    const float s = t + eps;
+    return 1.0f / sqrtf(s);
+}
+
+__global__ void k_diffweights6(float *wW, float *wN, float *wE, float *wS, const float *D,
+                               int nrows, int ncols, int nframes, float eps)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t n = (size_t)nrows * ncols;
+    float tW = 0.f, tN = 0.f, tE = 0.f, tS = 0.f;
+    for (int k = 0; k < nframes; k++) {
+        const float *d = D + (size_t)k * n;
+        const float dc = d[pos];
+        const float vc = dw_ver(d, i, j, nrows), hc = dw_hor(d, i, j, nrows, ncols);
+        float A, B, t;
+        if (j >= 1) { // Calc_wW :123-147
+            A = dc - d[pos - nrows];
+            B = vc + dw_ver(d, i, j - 1, nrows);
+            A = A * A; B = B * B; t = A + B;
+            if (k == 0) tW = t; else if (t > tW) tW = t;
+        }
+        if (i >= 1) { // Calc_wN :177-200
+            A = dc - d[pos - 1];
+            B = hc + dw_hor(d, i - 1, j, nrows, ncols);
+            A = A * A; B = B * B; t = A + B;
+            if (k == 0) tN = t; else if (t > tN) tN = t;
+        }
+        if (j <= ncols - 2) { // Calc_wE :236-258
+            A = dc - d[pos + nrows];
+            B = vc + dw_ver(d, i, j + 1, nrows);
+            A = A * A; B = B * B; t = A + B;
+            if (k == 0) tE = t; else if (t > tE) tE = t;
+        }
+        if (i <= nrows - 2) { // Calc_wS :289-311
+            A = dc - d[pos + 1];
+            B = hc + dw_hor(d, i + 1, j, nrows, ncols);
+            A = A * A; B = B * B; t = A + B;
+            if (k == 0) tS = t; else if (t > tS) tS = t;
+        }
+    }
+    // cells the reference never writes keep the gateway's zero initialisation
+    wW[pos] = (j >= 1) ? dw_inv_sqrt(tW, eps) : 0.0f;
+    wN[pos] = (i >= 1) ? dw_inv_sqrt(tN, eps) : 0.0f;
+    wE[pos] = (j <= ncols - 2) ? dw_inv_sqrt(tE, eps) : 0.0f;
+    wS[pos] = (i <= nrows - 2) ? dw_inv_sqrt(tS, eps) : 0.0f;
+}
+
+// ---- bilinear warp: bilinInterp2 (imageInterpolation.c:44-140) --------------------------------
+
+__global__ void k_warp_bilinear(float *Iout, const float *Iin, const float *X, const float *Y,
+                                int nrows, int ncols, int nframes)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t n = (size_t)nrows * ncols;
+    // :82-86.  The reference casts floor() to unsigned and lets negatives wrap out of range; HIP's
+    // float->unsigned conversion saturates instead, so the range test is explicit and signed.
+    const float xm = X[pos] - 1.0f, ym = Y[pos] - 1.0f;
+    const float fx = floorf(xm), fy = floorf(ym);
+    const bool inside = (fx >= 0.0f) && (fx < (float)ncols) && (fy >= 0.0f) && (fy < (float)nrows);
+    if (inside) {
+        const int x = (int)fx, y = (int)fy;
+        const float xf = xm - (float)x, yf = ym - (float)y; // :89-90
+        const float w00 = (1.0f - xf) * (1.0f - yf);        // :93-96
+        const float w10 = xf * (1.0f - yf);
+        const float w01 = (1.0f - xf) * yf;
+        const float w11 = xf * yf;
+        const size_t p00 = (size_t)nrows * x + y;
+        const size_t dx = (x < ncols - 1) ? (size_t)nrows : 0, dy = (y < nrows - 1) ? 1 : 0; // :105-110
+        const size_t p10 = p00 + dx, p01 = p00 + dy;
+        const size_t p11 = (x < ncols - 1 && y < nrows - 1) ? p00 + nrows + 1 : p00;
+        for (int k = 0; k < nframes; k++) {
+            const float *src = Iin + (size_t)k * n;
+            float r = w00 * src[p00]; // :120-123, left to right
+            r = r + w10 * src[p10];
+            r = r + w01 * src[p01];
+            r = r + w11 * src[p11];
+            Iout[(size_t)k * n + pos] = r;
+        }
+    } else {
+        const float nanv = __int_as_float(0x7fc00000);
+        for (int k = 0; k < nframes; k++) Iout[(size_t)k * n + pos] = nanv; // :129-135
+    }
+}
+
+} // namespace pdeip

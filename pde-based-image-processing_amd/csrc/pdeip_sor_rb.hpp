@@ -1,0 +1,273 @@
+// pdeip_sor_rb.hpp -- one fused red+black SOR sweep for the 5-point solvers (gfx950).
+//
+// Layout reminder: the buffers are MATLAB column-major, i.e. row-major [ncols][nrows] seen
+// from here; the contiguous direction is the image row index i.
+//
+// Design (register marching, no LDS):
+//   * one wave owns a unit = 248 image rows x TJ image columns.  Lane l holds four
+//     consecutive rows r..r+3 of the current column (r = 248*a - 4 + 4*l), so every plane is
+//     read with one 16-byte load per lane = 1 KiB per wave instruction, fully coalesced.
+//     Lanes 0 and 63 are halo lanes (4 rows each) that are recomputed, never stored.
+//   * the wave marches along the columns keeping a window of columns in registers:
+//     O(c-1..c+1) old values, R(c-2..c) values after the red half-sweep.  Per step it
+//     computes the red update of column c and the black update of column c-1, then stores
+//     the finished column c-1.  North/south neighbours come from the lane's own float4 or
+//     from the adjacent lane through a wavefront shuffle.
+//   * colour of pixel (i,j) is (i + j + col0) & 1; because r is a multiple of 4 the red
+//     pixels of a column are elements {p, p+2} of every lane with p = (c + col0) & 1, so a
+//     half-sweep is branch-uniform across the wave.
+//   * sweeps ping-pong between two iterate buffers (in -> out): no inter-workgroup race,
+//     each plane is read once and the iterate written once per sweep (plus the unit halo).
+//   * the image border is never relaxed; the unit that finishes column 1 / ncols-2 (row 1 /
+//     nrows-2) also writes the replicated border cells, which reproduces the reference's
+//     rows-then-columns border fill (opticalflowSolvers.c:161-179).
+#pragma once
+#include "pdeip_models.hpp"
+
+namespace pdeip {
+
+constexpr int RB_OWN_ROWS = 248; // 62 storing lanes x 4 rows
+constexpr int RB_WAVES_PER_BLOCK = 4;
+
+template <bool VEC>
+__device__ __forceinline__ void rb_load4(float (&d)[4], const float *__restrict__ p, int c, int r,
+                                         int nrows, int ncols)
+{
+    d[0] = d[1] = d[2] = d[3] = 0.0f;
+    if (c < 0 || c >= ncols) return; // wave-uniform
+    const float *q = p + (size_t)c * nrows;
+    if (VEC) {
+        if (r >= 0 && r < nrows) {
+            const float4 t = *reinterpret_cast<const float4 *>(q + r);
+            d[0] = t.x;
+            d[1] = t.y;
+            d[2] = t.z;
+            d[3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = r + e;
+            if (i >= 0 && i < nrows) d[e] = q[i];
+        }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void rb_store4(const float (&d)[4], float *__restrict__ p, int c, int r,
+                                          int nrows)
+{
+    float *q = p + (size_t)c * nrows;
+    if (VEC) {
+        if (r >= 0 && r < nrows) *reinterpret_cast<float4 *>(q + r) = make_float4(d[0], d[1], d[2], d[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = r + e;
+            if (i >= 0 && i < nrows) q[i] = d[e];
+        }
+    }
+}
+
+// Relax elements {E0, E0+2} of column C (the pixels of one colour) in place.
+template <class Mdl, int E0>
+__device__ __forceinline__ void rb_phase(float (&C)[Mdl::NIT][4], const float (&W)[Mdl::NIT][4],
+                                         const float (&E)[Mdl::NIT][4],
+                                         const float (&rC)[at_least_one<Mdl::NRO>::value][4],
+                                         const float (&rW)[at_least_one<Mdl::NRO>::value][4],
+                                         const float (&rE)[at_least_one<Mdl::NRO>::value][4],
+                                         const float (&cf)[Mdl::NCF][4], int r, int nrows,
+                                         float omega, float om1)
+{
+    constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NRO1 = at_least_one<NRO>::value;
+    // values held by the neighbouring lane (executed by the whole wave)
+    float edge[NIT], redge[NRO1];
+#pragma unroll
+    for (int f = 0; f < NIT; f++)
+        edge[f] = (E0 == 0) ? __shfl_up(C[f][3], 1) : __shfl_down(C[f][0], 1);
+#pragma unroll
+    for (int f = 0; f < NRO1; f++)
+        redge[f] = (NRO == 0) ? 0.0f : ((E0 == 0) ? __shfl_up(rC[f][3], 1) : __shfl_down(rC[f][0], 1));
+
+#pragma unroll
+    for (int e = E0; e < 4; e += 2) {
+        const int i = r + e;
+        if (i >= 1 && i <= nrows - 2) {
+            float c[NIT], w[NIT], ea[NIT], n[NIT], s[NIT];
+            float rc[NRO1], rw[NRO1], re[NRO1], rn[NRO1], rs[NRO1], k[Mdl::NCF];
+#pragma unroll
+            for (int f = 0; f < NIT; f++) {
+                c[f] = C[f][e];
+                w[f] = W[f][e];
+                ea[f] = E[f][e];
+                n[f] = (e == 0) ? edge[f] : C[f][e == 0 ? 0 : e - 1];
+                s[f] = (e == 3) ? edge[f] : C[f][e == 3 ? 3 : e + 1];
+            }
+#pragma unroll
+            for (int f = 0; f < NRO1; f++) {
+                rc[f] = rC[f][e];
+                rw[f] = rW[f][e];
+                re[f] = rE[f][e];
+                rn[f] = (e == 0) ? redge[f] : rC[f][e == 0 ? 0 : e - 1];
+                rs[f] = (e == 3) ? redge[f] : rC[f][e == 3 ? 3 : e + 1];
+            }
+#pragma unroll
+            for (int f = 0; f < Mdl::NCF; f++) k[f] = cf[f][e];
+            Mdl::update(c, w, ea, n, s, rc, rw, re, rn, rs, k, omega, om1);
+#pragma unroll
+            for (int f = 0; f < NIT; f++) C[f][e] = c[f];
+        }
+    }
+}
+
+template <class Mdl, bool VEC>
+__global__ void __launch_bounds__(64 * RB_WAVES_PER_BLOCK)
+k_sor_rb(SweepPlanes<Mdl> P, int nrows, int ncols, int TJ, int ntiles_r, int nunits, float omega,
+         int col0, size_t frame_stride)
+{
+    constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NRO1 = at_least_one<NRO>::value, NCF = Mdl::NCF;
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * RB_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (unit >= nunits) return; // whole wave leaves; no workgroup barrier is used below
+    const size_t fo = (size_t)blockIdx.y * frame_stride;
+#pragma unroll
+    for (int f = 0; f < NIT; f++) {
+        P.it_in[f] += fo;
+        P.it_out[f] += fo;
+    }
+#pragma unroll
+    for (int f = 0; f < NRO1; f++)
+        if (NRO > 0) P.ro[f] += fo;
+#pragma unroll
+    for (int f = 0; f < NCF; f++) P.cf[f] += fo;
+
+    const int a = unit % ntiles_r, b = unit / ntiles_r;
+    const int r = a * RB_OWN_ROWS - 4 + 4 * lane;
+    const int j0 = b * TJ;
+    const int j1 = (j0 + TJ < ncols) ? j0 + TJ : ncols;
+    const float om1 = 1.0f - omega;
+    const bool store_lane = (lane >= 1) && (lane <= 62);
+
+    // register windows (column index relative to the column c whose red update is due)
+    float Om[NIT][4], Oc[NIT][4], Op[NIT][4];    // old iterate, columns c-1, c, c+1
+    float Rmm[NIT][4], Rm[NIT][4];               // after red, columns c-2, c-1
+    float ROmm[NRO1][4], ROm[NRO1][4], ROc[NRO1][4], ROp[NRO1][4]; // read-only, c-2..c+1
+    float CFm[NCF][4], CFc[NCF][4];              // coefficients, columns c-1, c
+
+    int c = j0 - 1;
+#pragma unroll
+    for (int f = 0; f < NIT; f++) {
+        rb_load4<VEC>(Om[f], P.it_in[f], c - 1, r, nrows, ncols);
+        rb_load4<VEC>(Oc[f], P.it_in[f], c, r, nrows, ncols);
+        rb_load4<VEC>(Op[f], P.it_in[f], c + 1, r, nrows, ncols);
+#pragma unroll
+        for (int e = 0; e < 4; e++) Rmm[f][e] = Rm[f][e] = 0.0f;
+    }
+#pragma unroll
+    for (int f = 0; f < NRO1; f++) {
+        if (NRO > 0) {
+            rb_load4<VEC>(ROm[f], P.ro[f], c - 1, r, nrows, ncols);
+            rb_load4<VEC>(ROc[f], P.ro[f], c, r, nrows, ncols);
+            rb_load4<VEC>(ROp[f], P.ro[f], c + 1, r, nrows, ncols);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            ROmm[f][e] = 0.0f;
+            if (NRO == 0) ROm[f][e] = ROc[f][e] = ROp[f][e] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < NCF; f++) {
+        rb_load4<VEC>(CFc[f], P.cf[f], c, r, nrows, ncols);
+#pragma unroll
+        for (int e = 0; e < 4; e++) CFm[f][e] = 0.0f;
+    }
+
+    for (; c <= j1; c++) {
+        // prefetch what the next step needs; consumed after the rotation below
+        float On[NIT][4], ROn[NRO1][4], CFn[NCF][4];
+#pragma unroll
+        for (int f = 0; f < NIT; f++) rb_load4<VEC>(On[f], P.it_in[f], c + 2, r, nrows, ncols);
+#pragma unroll
+        for (int f = 0; f < NRO1; f++) {
+            if (NRO > 0) rb_load4<VEC>(ROn[f], P.ro[f], c + 2, r, nrows, ncols);
+            else ROn[f][0] = ROn[f][1] = ROn[f][2] = ROn[f][3] = 0.0f;
+        }
+#pragma unroll
+        for (int f = 0; f < NCF; f++) rb_load4<VEC>(CFn[f], P.cf[f], c + 1, r, nrows, ncols);
+
+        const int p = (c + col0) & 1;
+
+        // red half-sweep on column c: R(c) from O(c-1), O(c), O(c+1)
+        float Rc[NIT][4];
+#pragma unroll
+        for (int f = 0; f < NIT; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Rc[f][e] = Oc[f][e];
+        if (c >= 1 && c <= ncols - 2) {
+            if (p == 0) rb_phase<Mdl, 0>(Rc, Om, Op, ROc, ROm, ROp, CFc, r, nrows, omega, om1);
+            else        rb_phase<Mdl, 1>(Rc, Om, Op, ROc, ROm, ROp, CFc, r, nrows, omega, om1);
+        }
+
+        // black half-sweep on column c-1: F(c-1) from R(c-2), R(c-1), R(c); then store it.
+        // The red pixels of column c-1 are elements {1-p, 3-p}, so its black ones are {p, p+2}:
+        // the same element set as the red update of column c above.
+        const int cb = c - 1;
+        if (cb >= j0 && cb >= 1 && cb <= ncols - 2) {
+            float F[NIT][4];
+#pragma unroll
+            for (int f = 0; f < NIT; f++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) F[f][e] = Rm[f][e];
+            if (p == 0) rb_phase<Mdl, 0>(F, Rmm, Rc, ROm, ROmm, ROc, CFm, r, nrows, omega, om1);
+            else        rb_phase<Mdl, 1>(F, Rmm, Rc, ROm, ROmm, ROc, CFm, r, nrows, omega, om1);
+            // replicate into the border rows 0 and nrows-1 (rows first, opticalflowSolvers.c:161-170)
+#pragma unroll
+            for (int f = 0; f < NIT; f++) {
+                const float prev3 = VEC ? 0.0f : __shfl_up(F[f][3], 1);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = r + e;
+                    if (i == 0) F[f][e] = F[f][e == 3 ? 3 : e + 1];
+                    if (i == nrows - 1) F[f][e] = (e == 0) ? prev3 : F[f][e == 0 ? 0 : e - 1];
+                }
+                if (store_lane) {
+                    rb_store4<VEC>(F[f], P.it_out[f], cb, r, nrows);
+                    // then columns (:172-179): column 0 copies column 1, the last copies ncols-2
+                    if (cb == 1) rb_store4<VEC>(F[f], P.it_out[f], 0, r, nrows);
+                    if (cb == ncols - 2) rb_store4<VEC>(F[f], P.it_out[f], ncols - 1, r, nrows);
+                }
+            }
+        }
+
+        // rotate the windows
+#pragma unroll
+        for (int f = 0; f < NIT; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                Rmm[f][e] = Rm[f][e];
+                Rm[f][e] = Rc[f][e];
+                Om[f][e] = Oc[f][e];
+                Oc[f][e] = Op[f][e];
+                Op[f][e] = On[f][e];
+            }
+#pragma unroll
+        for (int f = 0; f < NRO1; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                ROmm[f][e] = ROm[f][e];
+                ROm[f][e] = ROc[f][e];
+                ROc[f][e] = ROp[f][e];
+                ROp[f][e] = ROn[f][e];
+            }
+#pragma unroll
+        for (int f = 0; f < NCF; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                CFm[f][e] = CFc[f][e];
+                CFc[f][e] = CFn[f][e];
+            }
+    }
+}
+
+} // namespace pdeip

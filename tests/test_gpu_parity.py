@@ -1,0 +1,149 @@
+"""GPU parity: every gateway of the hot path, through the C-ABI, against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact (float32 arithmetic in the reference's operation order).
+
+EXACT_ORDER mode is compared with the oracle's lexicographic (reference) order; RED_BLACK mode
+with the oracle's colour order (same per-pixel arithmetic, red-black / four-colour sweeps).
+"""
+import numpy as np
+import pytest
+
+import problems as pb
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(32, 48), (97, 131), (64, 200), (131, 70), (3, 3), (5, 300), (260, 7), (388, 584)]
+MODES = [(0, 0), (1, 1)]  # (product mode, oracle order)
+
+
+def check(got, want, what):
+    got = got if isinstance(got, tuple) else (got,)
+    want = want if isinstance(want, tuple) else (want,)
+    assert len(got) == len(want)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert pb.bit_equal(g, w), "%s output %d: %s" % (what, k, pb.describe_mismatch(g, w))
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+@pytest.mark.parametrize("shape", SIZES)
+@pytest.mark.parametrize("it", [1, 4, 7])
+def test_oflow_sor_elin4(pdeip, oracle, mode, order, shape, it):
+    p = pb.elin4(11, *shape)
+    pdeip.mex_api.set_mode(mode)
+    got = pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(it), np.float32(1.9), np.float32(1))
+    want = oracle.Oflow_sor_elin4_2d(*p.values(), it, 1.9, order=order)
+    check(got, want, "elin4 %s it=%d mode=%d" % (shape, it, mode))
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+def test_oflow_sor_elin4_nan_frames_residuals(pdeip, oracle, mode, order):
+    pdeip.mex_api.set_mode(mode)
+    for nan_mode in ("all", "C", "D"):
+        p = pb.elin4(12, 97, 131, nframes=3, nan_frac=0.05, nan_mode=nan_mode)
+        got = pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(5), np.float32(1.7), np.float32(1), nargout=4)
+        want = oracle.Oflow_sor_elin4_2d(*p.values(), 5, 1.7, nargout=4, order=order)
+        check(got, want, "elin4 nan=%s mode=%d" % (nan_mode, mode))
+    # iter = 0: zero iterate outputs, residuals of the input (FMG driver usage)
+    p = pb.elin4(13, 64, 48, nframes=2)
+    got = pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(0), np.float32(1.9), np.float32(1), nargout=4)
+    want = oracle.Oflow_sor_elin4_2d(*p.values(), 0, 1.9, nargout=4, order=order)
+    check(got, want, "elin4 iter=0")
+    assert not got[0].any() and not got[1].any()
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+@pytest.mark.parametrize("shape", SIZES)
+def test_oflow_sor_llin4(pdeip, oracle, mode, order, shape):
+    pdeip.mex_api.set_mode(mode)
+    for it, nan_frac in ((1, 0.0), (4, 0.04)):
+        p = pb.llin4(21, *shape, nan_frac=nan_frac)
+        got = pdeip.mex_api.Oflow_sor_llin4_2d(*p.values(), np.float32(it), np.float32(1.9), np.float32(1), nargout=4)
+        want = oracle.Oflow_sor_llin4_2d(*p.values(), it, 1.9, nargout=4, order=order)
+        check(got, want, "llin4 %s it=%d mode=%d" % (shape, it, mode))
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+def test_oflow_sor_llin4_frames_quirk(pdeip, oracle, mode, order):
+    """Multi-frame residuals incl. the frame-0 west-border quirk of Residuals_llin4_2d (:912)."""
+    pdeip.mex_api.set_mode(mode)
+    p = pb.llin4(22, 50, 37, nframes=3, nan_frac=0.03)
+    got = pdeip.mex_api.Oflow_sor_llin4_2d(*p.values(), np.float32(3), np.float32(1.5), np.float32(1), nargout=4)
+    want = oracle.Oflow_sor_llin4_2d(*p.values(), 3, 1.5, nargout=4, order=order)
+    check(got, want, "llin4 frames")
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+def test_oflow_sor_llin8(pdeip, oracle, mode, order):
+    pdeip.mex_api.set_mode(mode)
+    p = pb.llin8(23, 97, 131, nan_frac=0.02)
+    got = pdeip.mex_api.Oflow_sor_llin8_2d(*p.values(), np.float32(4), np.float32(1.9), np.float32(1), nargout=4)
+    want = oracle.Oflow_sor_llin8_2d(*p.values(), 4, 1.9, nargout=4, order=order)
+    check(got, want, "llin8")
+    assert not got[2].any() and not got[3].any()  # residual outputs are never filled by the gateway
+
+
+def test_oflow_lhs(pdeip, oracle):
+    for shape, F in (((97, 131), 1), ((40, 56), 3), ((3, 3), 1)):
+        p = pb.elin4(31, *shape, nframes=F, nan_frac=0.05, nan_mode="D")
+        args = [p[k] for k in ("U", "V", "M", "Du", "Dv", "wW", "wN", "wE", "wS")]
+        check(pdeip.mex_api.Oflow_lhs_elin4_2d(*args), oracle.oflow_lhs_elin4(*args), "lhs_elin4 %s F=%d" % (shape, F))
+        q = pb.llin4(32, *shape, nframes=F, nan_frac=0.05, nan_mode="D")
+        args = [q[k] for k in ("U", "V", "dU", "dV", "M", "Du", "Dv", "wW", "wN", "wE", "wS")]
+        check(pdeip.mex_api.Oflow_lhs_llin4_2d(*args), oracle.oflow_lhs_llin4(*args), "lhs_llin4 %s F=%d" % (shape, F))
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+@pytest.mark.parametrize("shape", SIZES)
+def test_disp_sor_llin4(pdeip, oracle, mode, order, shape):
+    pdeip.mex_api.set_mode(mode)
+    for it, nan_frac in ((1, 0.0), (6, 0.05)):
+        p = pb.disp4(41, *shape, nan_frac=nan_frac)
+        got = pdeip.mex_api.Disp_sor_llin4_2d(*p.values(), np.float32(it), np.float32(1.9), np.float32(1), nargout=2)
+        want = oracle.Disp_sor_llin4_2d(*p.values(), it, 1.9, nargout=2, order=order)
+        check(got, want, "disp %s it=%d mode=%d" % (shape, it, mode))
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+@pytest.mark.parametrize("shape,F", [((32, 48), 1), ((97, 131), 3), ((3, 3), 1), ((260, 7), 2), ((64, 200), 1)])
+def test_pde_sor4(pdeip, oracle, mode, order, shape, F):
+    pdeip.mex_api.set_mode(mode)
+    for it, nan_frac in ((1, 0.0), (5, 0.05), (0, 0.0)):
+        p = pb.pde4(51, *shape, nframes=F, nan_frac=nan_frac)
+        got = pdeip.mex_api.PDEsolver4(*p.values(), np.float32(it), np.float32(1.75), np.float32(1))
+        want = oracle.PDEsolver4(*p.values(), it, 1.75, order=order)
+        check(got, want, "pde4 %s F=%d it=%d mode=%d" % (shape, F, it, mode))
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+@pytest.mark.parametrize("shape,F", [((32, 48), 1), ((97, 131), 3), ((3, 3), 1), ((260, 7), 2), ((5, 300), 1),
+                                     ((64, 200), 1), ((200, 190), 1)])
+def test_pde_sor8(pdeip, oracle, mode, order, shape, F):
+    pdeip.mex_api.set_mode(mode)
+    for it, nan_frac in ((1, 0.0), (2, 0.0), (5, 0.05), (0, 0.0)):
+        p = pb.pde8(61, *shape, nframes=F, nan_frac=nan_frac)
+        got = pdeip.mex_api.PDEsolver8(*p.values(), np.float32(it), np.float32(1.75), np.float32(1))
+        want = oracle.PDEsolver8(*p.values(), it, 1.75, order=order)
+        check(got, want, "pde8 %s F=%d it=%d mode=%d" % (shape, F, it, mode))
+
+
+@pytest.mark.parametrize("shape,F", [((32, 48), 1), ((97, 131), 3), ((3, 3), 2), ((260, 7), 1), ((388, 584), 1)])
+def test_diffweights(pdeip, oracle, shape, F):
+    p = pb.diffweights(71, *shape, nframes=F)
+    check(pdeip.mex_api.DdiffWeights(p["D"], np.float32(1e-5)), oracle.DdiffWeights(p["D"], 1e-5), "diffweights %s F=%d" % (shape, F))
+
+
+@pytest.mark.parametrize("shape,F", [((32, 48), 1), ((97, 131), 3), ((6, 6), 2), ((388, 584), 6)])
+def test_warp(pdeip, oracle, shape, F):
+    p = pb.warp(81, *shape, nframes=F)
+    check(pdeip.mex_api.BilinInterp_2d(p["Iin"], p["X"], p["Y"]), oracle.BilinInterp_2d(p["Iin"], p["X"], p["Y"]),
+          "warp %s F=%d" % (shape, F))
+
+
+def test_solver_errors(pdeip):
+    p = pb.elin4(91, 16, 16)
+    with pytest.raises(pdeip.mex_api.MexError, match="no such solver"):
+        pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(1), np.float32(1.9), np.float32(7))
+    with pytest.raises(pdeip.mex_api.MexError, match="alternating line relaxation"):
+        pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(1), np.float32(1.9), np.float32(2))
+    q = pb.pde4(92, 16, 16)
+    with pytest.raises(pdeip.mex_api.MexError, match="no such solver"):
+        pdeip.mex_api.PDEsolver4(*q.values(), np.float32(1), np.float32(1.9), np.float32(3))
