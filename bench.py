@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- SOR sweeps ("iterations")/s and achieved HBM GB/s on a 3840x2160 flow problem.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1: launched by
+torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.md row "M"/"C4"; BASELINE.json metric): the early-linearization (Horn-Schunck
+type) point solver `Oflow_sor_elin4_2d` / GS_SOR_elin4_2d on one 2160 x 3840 float32 frame
+(nrows=2160, ncols=3840), synthetic motion-tensor coefficients, weights U(0.5,5), omega 1.9.
+One STEP = one solver call of iter=4 sweeps on buffers resident in HBM (what the FMG smoother
+issues per call, FlowEminNDFASFMG_elin_2D_v10.m:55-56,398-411), so value = 4*K / time.
+
+  * value        RED_BLACK ordering (the ordering that decomposes across GPUs; the same kernel
+                 at every N so the driver's scaling series is one algorithm).  N>1: the frame is
+                 cut into column slabs with a 2*iter-column halo, one RCCL exchange per step.
+  * exact_order  (N=1 only) the same workload in the reference's lexicographic order, the
+                 library's default and the bit-parity mode, reported beside it.
+  * roofline     algorithmic bytes (52 B/pixel/sweep: 11 planes read + 2 written) / average
+                 sweep-kernel launch duration, measured with HIP events on the launch stream
+                 inside this run (pdeip_profile_*), vs 8 TB/s HBM3E peak.
+  * cpu_baseline the CPU oracle (plain-C port of the reference loop, lexicographic order) on
+                 the same frame on ONE host core, a bounded number of calls.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NROWS, NCOLS = 2160, 3840
+ITER, OMEGA = 4, 1.9
+BYTES_PER_PIXEL_SWEEP = 52.0  # 11 R + 2 W float32 planes
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_planes(torch, device, nrows, ncols, seed=0):
+    """Motion-tensor structured coefficients (positive semi-definite data term), U(0.5,5) weights."""
+    g = torch.Generator(device=device).manual_seed(seed)
+
+    def u(lo, hi):
+        return torch.empty((ncols, nrows), device=device, dtype=torch.float32).uniform_(lo, hi, generator=g)
+
+    # image-gradient sized data terms (|Ix|,|Iy| <= 0.5) against weights in [0.5, 5]: the relaxation
+    # converges at omega = 1.9, so the in-place iterate stays finite over any number of timed steps
+    a, b, c = u(-0.5, 0.5), u(-0.5, 0.5), u(-1.0, 1.0)
+    coef = [a * b, -a * c, -b * c, a * a, b * b] + [u(0.5, 5.0) for _ in range(4)]  # M,Cu,Cv,Du,Dv,wW,wN,wE,wS
+    U, V = u(-1.0, 1.0), u(-1.0, 1.0)
+    return U, V, [t.contiguous() for t in coef]
+
+
+def cpu_baseline(U, V, coef, calls):
+    """Time the CPU oracle (reference order, 1 thread) on the same frame.  Returns (sweeps/s, result U,V)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    lib = oracle_lib.lib()
+    hu, hv = U.cpu().numpy().copy(), V.cpu().numpy().copy()   # [ncols, nrows] C-order == MATLAB column-major
+    hc = [t.cpu().numpy() for t in coef]
+    first = None
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        lib.orc_oflow_sor_elin4(hu.ctypes.data, hv.ctypes.data, *[a.ctypes.data for a in hc], NROWS, NCOLS, ITER,
+                                ctypes.c_float(OMEGA), 0)
+        if first is None:
+            first = (hu.copy(), hv.copy())
+    dt = time.perf_counter() - t0
+    return calls * ITER / dt, first
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cpu-calls", type=int, default=5, help="solver calls timed for the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library is the product, there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    pkg = importlib.import_module("pde-based-image-processing_amd")
+    dev = importlib.import_module("pde-based-image-processing_amd.device")
+    slab = importlib.import_module("pde-based-image-processing_amd.slab")
+    capi = pkg.capi
+    capi.load()
+
+    U0, V0, coef_full = make_planes(torch, device, NROWS, NCOLS)
+    N = NROWS * NCOLS
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        barrier()
+        capi.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        ms, nl = capi.profile_read()
+        capi.profile_enable(False)
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, ms, nl
+
+    # ---- RED_BLACK ordering: value ----------------------------------------------------------------
+    dom = slab.SlabDomain(NCOLS, NROWS, rank, world, halo=2 * ITER)
+    U, V = dom.slice_local(U0), dom.slice_local(V0)
+    coef = [dom.slice_local(t) for t in coef_full]
+    solver = slab.SlabSolver(dom, "elin4", sweeps_per_exchange=ITER)
+
+    def step_rb():
+        solver.solve([U, V], coef, ITER, OMEGA)
+
+    dt, ms, nl = timed(step_rb, args.steps, args.warmup)
+    value = args.steps * ITER / dt
+    # per launch: this rank's pixels (owned + halo columns are all relaxed by the launch; count owned only)
+    own_px = (dom.c1 - dom.c0) * NROWS
+    launch_s = ms * 1e-3 / max(nl, 1)
+    achieved = BYTES_PER_PIXEL_SWEEP * own_px / launch_s / 1e9
+
+    out = {
+        "metric": "SOR iterations/sec (3840x2160 flow)", "value": round(value, 2), "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Oflow_sor_elin4_2d point SOR, 2160x3840 f32 frame, iter=4/call, omega=1.9, resident in HBM",
+                   "ordering": "red_black", "decomposition": "column slabs, %d-column halo, 1 RCCL exchange/step" % (2 * ITER)
+                   if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": "k_sor_rb<ModelElin4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "launch_us": round(launch_s * 1e6, 2), "algorithmic_bytes_per_launch": BYTES_PER_PIXEL_SWEEP * own_px},
+    }
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if world == 1 and os.path.exists(tr):
+        try:
+            out["roofline"]["traffic"] = json.load(open(tr)).get("k_sor_rb_elin4_2160x3840_bytes_per_launch")
+        except (ValueError, OSError):
+            pass
+
+    if world == 1:
+        # ---- exact (reference) ordering on the same workload -------------------------------------
+        Ue, Ve = U0.clone(), V0.clone()
+
+        def step_exact():
+            dev.oflow_sor_elin4(Ue, Ve, *coef_full, ITER, OMEGA, capi.MODE_EXACT_ORDER)
+
+        e_steps = max(5, args.steps // 10)
+        edt, ems, enl = timed(step_exact, e_steps, max(2, args.warmup // 10))
+        e_launch_s = ems * 1e-3 / max(enl, 1)
+        e_bytes = BYTES_PER_PIXEL_SWEEP * N * ITER * e_steps / max(enl, 1)  # tiles of one front per launch
+        out["exact_order"] = {
+            "value": round(e_steps * ITER / edt, 2), "unit": "iterations/s", "ms_per_step": round(edt / e_steps * 1e3, 4),
+            "launches_per_step": enl // e_steps,
+            "roofline": {"bound": "hbm", "kernel": "k_sor_exact<ModelElin4>", "achieved": round(e_bytes / e_launch_s / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e_bytes / e_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None, "launch_us": round(e_launch_s * 1e6, 2)},
+        }
+        # ---- CPU baseline + parity of the first call -----------------------------------------------
+        if args.cpu_calls > 0:
+            cpu_rate, first = cpu_baseline(U0, V0, coef_full, args.cpu_calls)
+            Up, Vp = U0.clone(), V0.clone()
+            dev.oflow_sor_elin4(Up, Vp, *coef_full, ITER, OMEGA, capi.MODE_EXACT_ORDER)
+            torch.cuda.synchronize()
+            du = Up.cpu().numpy().astype(np.float64) - first[0]
+            dv = Vp.cpu().numpy().astype(np.float64) - first[1]
+            out["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "iterations/s", "cores": 1, "kind": "port",
+                                   "sample": "%d calls x iter=%d of the same 2160x3840 frame, reference (lexicographic) order, "
+                                             "oracle/pdeip_oracle.c built -O2 -ffp-contract=off" % (args.cpu_calls, ITER),
+                                   "host_cpus": os.cpu_count()}
+            out["parity"] = {"mode": "exact_order vs cpu oracle, first call", "rms_u": float(np.sqrt((du * du).mean())),
+                             "rms_v": float(np.sqrt((dv * dv).mean())), "max_abs": float(max(np.abs(du).max(), np.abs(dv).max()))}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,12 @@ int pdeip_set_device(int device_id);
 int pdeip_release(void);
 /* Number of kernel launches the last *_dev solver call enqueued (diagnostic). */
 int pdeip_last_launch_count(void);
+/* Sweep-kernel timing for bench.py's roofline figure.  While enabled, every *_dev solver call
+ * brackets its back-to-back sweep launches (not its prologue) with a pair of HIP events on the
+ * call's stream.  pdeip_profile_read() waits for the recorded events, returns the summed elapsed
+ * milliseconds and the number of sweep launches they cover, and clears the record. */
+int pdeip_profile_enable(int on);
+int pdeip_profile_read(double *elapsed_ms, int *sweep_launches);
 
 /* ---- host-pointer drop-in entry points -------------------------------------------------
  * Output pointers marked "optional" may be NULL (the corresponding MATLAB output was not

@@ -32,16 +32,19 @@ static void fill_borders(float *P, int nrows, int ncols)
     }
 }
 
+/* bit 1 of `order`: parity of the global index of local column 0 (slab decomposition) */
+#define ORC_CPAR(order) (((order) >> 1) & 1)
+
 /* Visit the interior in the requested order: lexicographic (j outer, i inner) in one
  * pass, or ncolours passes where pass c touches the pixels whose colour is c. */
 #define FOR_INTERIOR(order, ncolours, COLOUR_EXPR, ...)                               \
     do {                                                                              \
-        int pass_, npass_ = ((order) == ORC_ORDER_LEX) ? 1 : (ncolours);              \
+        int pass_, npass_ = (((order) & 1) == ORC_ORDER_LEX) ? 1 : (ncolours);        \
         for (pass_ = 0; pass_ < npass_; pass_++) {                                    \
             int i, j;                                                                 \
             for (j = 1; j < ncols - 1; j++)                                           \
                 for (i = 1; i < nrows - 1; i++) {                                     \
-                    if ((order) != ORC_ORDER_LEX && (COLOUR_EXPR) != pass_) continue; \
+                    if (((order) & 1) != ORC_ORDER_LEX && (COLOUR_EXPR) != pass_) continue; \
                     __VA_ARGS__                                                       \
                 }                                                                     \
         }                                                                             \
@@ -80,7 +83,7 @@ void orc_oflow_sor_elin4(float *U, float *V, const float *M, const float *Cu, co
     oflow_divisors(divU, divV, Du, Dv, wW, wN, wE, wS, nrows, ncols);
 
     for (it = 0; it < iter; it++) {
-        FOR_INTERIOR(order, 2, ((i + j) & 1), {
+        FOR_INTERIOR(order, 2, ((i + j + ORC_CPAR(order)) & 1), {
             size_t pos = (size_t)j * nrows + i;
             float nbU, nbV, t1, t2, t3, Unew, Vnew;
             /* opticalflowSolvers.c:89-97 */
@@ -169,7 +172,7 @@ void orc_oflow_sor_llin4(const float *U, const float *V, float *dU, float *dV, c
     oflow_divisors(divU, divV, Du, Dv, wW, wN, wE, wS, nrows, ncols);
 
     for (it = 0; it < iter; it++) {
-        FOR_INTERIOR(order, 2, ((i + j) & 1), {
+        FOR_INTERIOR(order, 2, ((i + j + ORC_CPAR(order)) & 1), {
             size_t pos = (size_t)j * nrows + i;
             float nbU = llin_neigh(U, dU, pos, nrows, wW, wN, wE, wS);
             float nbV = llin_neigh(V, dV, pos, nrows, wW, wN, wE, wS);
@@ -448,7 +451,7 @@ void orc_disp_sor_llin4(const float *U, float *dU, const float *Cu, const float 
             }
     }
     for (it = 0; it < iter; it++) {
-        FOR_INTERIOR(order, 2, ((i + j) & 1), {
+        FOR_INTERIOR(order, 2, ((i + j + ORC_CPAR(order)) & 1), {
             size_t pos = (size_t)j * nrows + i;
             float nb = disp_neigh(U, dU, pos, nrows, wW, wN, wE, wS);
             /* :116-118 */
@@ -519,7 +522,7 @@ void orc_pde_sor4(float *X, const float *TRACE, const float *B, const float *wW,
     for (it = 0; it < iter; it++)
         for (k = 0; k < nframes; k++) {
             size_t fo = (size_t)k * n;
-            FOR_INTERIOR(order, 2, ((i + j) & 1), {
+            FOR_INTERIOR(order, 2, ((i + j + ORC_CPAR(order)) & 1), {
                 size_t pos = (size_t)j * nrows + i + fo;
                 float nb, t;
                 /* :94-97 */
@@ -570,7 +573,7 @@ void orc_pde_sor8(float *X, const float *TRACE, const float *B, const float *wW,
     for (it = 0; it < iter; it++)
         for (k = 0; k < nframes; k++) {
             size_t fo = (size_t)k * n;
-            FOR_INTERIOR(order, 4, ((i & 1) | ((j & 1) << 1)), {
+            FOR_INTERIOR(order, 4, ((i & 1) | (((j + ORC_CPAR(order)) & 1) << 1)), {
                 size_t pos = (size_t)j * nrows + i + fo;
                 size_t wpos = pos - nrows, epos = pos + nrows;
                 float nb, t;

@@ -31,6 +31,10 @@ extern "C" {
 
 #define ORC_ORDER_LEX 0
 #define ORC_ORDER_COLOUR 1
+/* `order` argument: bit 0 selects the ordering; bit 1, used with ORC_ORDER_COLOUR only, is the
+ * parity of the global column index of local column 0 when the arrays are one column slab of a
+ * larger frame (colour = (i + j_global) & 1). */
+#define ORC_ORDER_COLOUR_ODD_COL0 3
 
 /* opticalflowSolvers.c:41-186 (GS_SOR_elin4_2d); U,V updated in place. */
 void orc_oflow_sor_elin4(float *U, float *V, const float *M, const float *Cu, const float *Cv,

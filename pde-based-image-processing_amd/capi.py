@@ -66,6 +66,8 @@ SIGNATURES = {
     "pdeip_set_device": [_I],
     "pdeip_release": [],
     "pdeip_last_launch_count": [],
+    "pdeip_profile_enable": [_I],
+    "pdeip_profile_read": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
 }
 STRING_FUNCS = ("pdeip_version", "pdeip_last_error")
 
@@ -117,6 +119,17 @@ def set_mode(mode):
 
 def get_mode():
     return load().pdeip_get_mode()
+
+
+def profile_enable(on=True):
+    call("pdeip_profile_enable", 1 if on else 0)
+
+
+def profile_read():
+    """(elapsed milliseconds of the bracketed sweep launches, number of sweep launches) since the last read."""
+    ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+    call("pdeip_profile_read", ctypes.byref(ms), ctypes.byref(n))
+    return ms.value, n.value
 
 
 def version():

@@ -34,8 +34,36 @@ struct Context {
     void *ws[WS_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     size_t ws_bytes[WS_NSLOT] = {0, 0, 0, 0};
     int rb_tj = 0; // columns per red-black unit (0 = default)
+    // sweep-kernel timing (pdeip_profile_*)
+    bool profile = false;
+    static constexpr int MAX_EV = 4096;
+    hipEvent_t ev[MAX_EV][2];
+    int ev_launches[MAX_EV];
+    int n_ev = 0, n_ev_created = 0;
 };
 Context g;
+
+// Records an event pair around a run of sweep launches when profiling is on.
+struct SweepTimer {
+    hipStream_t s;
+    int slot = -1;
+    explicit SweepTimer(hipStream_t stream) : s(stream)
+    {
+        if (!g.profile || g.n_ev >= Context::MAX_EV) return;
+        if (g.n_ev == g.n_ev_created) {
+            if (hipEventCreate(&g.ev[g.n_ev][0]) != hipSuccess || hipEventCreate(&g.ev[g.n_ev][1]) != hipSuccess) return;
+            g.n_ev_created++;
+        }
+        slot = g.n_ev++;
+        (void)hipEventRecord(g.ev[slot][0], s);
+    }
+    void stop(int launches)
+    {
+        if (slot < 0) return;
+        (void)hipEventRecord(g.ev[slot][1], s);
+        g.ev_launches[slot] = launches;
+    }
+};
 
 int set_err(int code, const char *fmt, ...)
 {
@@ -125,10 +153,12 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         const int last_m = (A - 1) + 2 * (B - 1) + 3 * (iter - 1);
         for (int f = 0; f < NIT; f++) P.it_in[f] = P.it_out[f];
         const dim3 grid((unsigned)(B * iter), (unsigned)nframes);
+        SweepTimer timer(s);
         for (int m = 0; m <= last_m; m++) {
             hipLaunchKernelGGL(k_sor_exact<Mdl>, grid, dim3(64), 0, s, P, nrows, ncols, A, B, iter, m, omega, n);
             g.last_launches++;
         }
+        timer.stop(last_m + 1);
         const int nb = 2 * ncols + 2 * (nrows - 2);
         hipLaunchKernelGGL(k_fill_borders, dim3((nb + 255) / 256, nframes, NIT), dim3(256), 0, s,
                            P.it_out[0], P.it_out[NIT - 1], NIT, nrows, ncols, n);
@@ -158,6 +188,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     const int nunits = ntiles_r * nstrips;
     const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);
     const dim3 block(64 * RB_WAVES_PER_BLOCK);
+    SweepTimer timer(s);
     for (int it = 0; it < iter; it++) {
         for (int f = 0; f < NIT; f++) {
             P.it_in[f] = (it & 1) ? bufB[f] : bufA[f];
@@ -169,6 +200,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             hipLaunchKernelGGL((k_sor_rb<Mdl, false>), grid, block, 0, s, P, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
         g.last_launches++;
     }
+    timer.stop(iter);
     if (iter & 1) // the last sweep wrote the scratch copy
         for (int f = 0; f < NIT; f++)
             HIPCHK(hipMemcpyAsync(bufA[f], bufB[f], n * nframes * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -261,6 +293,28 @@ extern "C" int pdeip_release(void)
     return PDEIP_OK;
 }
 extern "C" int pdeip_last_launch_count(void) { return g.last_launches; }
+extern "C" int pdeip_profile_enable(int on)
+{
+    g.profile = (on != 0);
+    g.n_ev = 0;
+    return PDEIP_OK;
+}
+extern "C" int pdeip_profile_read(double *elapsed_ms, int *sweep_launches)
+{
+    double ms = 0.0;
+    int launches = 0;
+    for (int k = 0; k < g.n_ev; k++) {
+        HIPCHK(hipEventSynchronize(g.ev[k][1]));
+        float t = 0.0f;
+        HIPCHK(hipEventElapsedTime(&t, g.ev[k][0], g.ev[k][1]));
+        ms += t;
+        launches += g.ev_launches[k];
+    }
+    g.n_ev = 0;
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (sweep_launches) *sweep_launches = launches;
+    return PDEIP_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // device-pointer entry points
@@ -378,7 +432,7 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
     g.last_launches = 0;
     if (iter <= 0) return PDEIP_OK;
     const size_t n = (size_t)nrows * ncols;
-    float *bt, *inv, *scratch;
+    float *bt, *inv, *scratch = nullptr;
     RC(ws_get(WS_AUX0, n * nframes * sizeof(float), &bt));
     RC(ws_get(WS_AUX1, n * nframes * sizeof(float), &inv));
     hipLaunchKernelGGL(k_pde8_divisors, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, bt, inv, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, nrows, ncols, n);
@@ -387,12 +441,13 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
     P.x = X;
     const float *cf[ModelPde8::NCF] = {bt, inv, wW, wNW, wN, wNE, wE, wSE, wS, wSW};
     for (int f = 0; f < ModelPde8::NCF; f++) P.cf[f] = cf[f];
-    if (mode == PDEIP_MODE_EXACT_ORDER) {
+    if (mode == PDEIP_MODE_EXACT_ORDER)
         RC(ws_get(WS_PING, pde8_exact_scratch_floats(nrows, ncols, nframes, iter) * sizeof(float), &scratch));
-        g.last_launches += pde8_run_exact(s, P, scratch, nrows, ncols, nframes, iter, omega);
-    } else {
-        g.last_launches += pde8_run_colour(s, P, nrows, ncols, nframes, iter, omega, col0);
-    }
+    SweepTimer timer(s);
+    const int nl = (mode == PDEIP_MODE_EXACT_ORDER) ? pde8_run_exact(s, P, scratch, nrows, ncols, nframes, iter, omega)
+                                                    : pde8_run_colour(s, P, nrows, ncols, nframes, iter, omega, col0);
+    timer.stop(nl);
+    g.last_launches += nl;
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

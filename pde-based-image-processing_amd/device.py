@@ -1,0 +1,110 @@
+"""Device-resident calls: the `_dev` entry points of libpdeip.so on torch tensors.
+
+torch is plumbing here (device memory, streams); all arithmetic is in the HIP library.
+
+Layout.  A MATLAB `single` array [nrows x ncols (x F)] in column-major order is, byte for byte, a
+C-contiguous array [(F x) ncols x nrows].  Device planes are therefore torch float32 tensors of
+shape [ncols, nrows] or [F, ncols, nrows]; `to_device` / `to_matlab` convert from/to the numpy
+arrays `mex_api` uses.  Kernels run on torch's current stream.
+"""
+import numpy as np
+import torch
+
+from . import capi
+
+
+def to_device(a, device="cuda"):
+    """numpy [nrows, ncols(, F)] (any order) -> torch [(F,) ncols, nrows] on `device`, same bytes as MATLAB."""
+    a = np.asarray(a, dtype=np.float32)
+    t = a.transpose(2, 1, 0) if a.ndim == 3 else a.T
+    return torch.from_numpy(np.ascontiguousarray(t)).to(device)
+
+
+def to_matlab(t):
+    """torch [(F,) ncols, nrows] -> numpy [nrows, ncols(, F)] column-major."""
+    a = t.detach().cpu().numpy()
+    return np.asfortranarray(a.transpose(2, 1, 0) if a.ndim == 3 else a.T)
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+            raise capi.PdeipError(capi.PDEIP_ERR_ARG, "device planes must be contiguous float32 CUDA tensors")
+
+
+def _dims(t):
+    return int(t.shape[-1]), int(t.shape[-2]), (int(t.shape[0]) if t.dim() == 3 else 1)  # nrows, ncols, F
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(*ts):
+    return [t.data_ptr() for t in ts]
+
+
+def oflow_sor_elin4(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER, col0=0):
+    """In place on U, V (GS_SOR_elin4_2d, opticalflowSolvers.c:41)."""
+    _chk(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_oflow_sor_elin4_dev", _stream(), *_p(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS), nrows, ncols,
+              int(iter), float(omega), int(mode), int(col0))
+
+
+def oflow_sor_llin4(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER, col0=0):
+    """In place on dU, dV (GS_SOR_llin4_2d, opticalflowSolvers.c:504)."""
+    _chk(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_oflow_sor_llin4_dev", _stream(), *_p(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS), nrows,
+              ncols, int(iter), float(omega), int(mode), int(col0))
+
+
+def disp_sor_llin4(U, dU, Cu, Du, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER, col0=0):
+    """In place on dU (disparitySolvers.c:41)."""
+    _chk(U, dU, Cu, Du, wW, wN, wE, wS)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_disp_sor_llin4_dev", _stream(), *_p(U, dU, Cu, Du, wW, wN, wE, wS), nrows, ncols, int(iter),
+              float(omega), int(mode), int(col0))
+
+
+def pde_sor4(X, TRACE, B, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER, col0=0):
+    """In place on X (GS_SOR_4_2d, pdeSolvers.c:44)."""
+    _chk(X, TRACE, B, wW, wN, wE, wS)
+    nrows, ncols, F = _dims(X)
+    capi.call("pdeip_pde_sor4_dev", _stream(), *_p(X, TRACE, B, wW, wN, wE, wS), nrows, ncols, F, int(iter),
+              float(omega), int(mode), int(col0))
+
+
+def pde_sor8(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, iter, omega, mode=capi.MODE_EXACT_ORDER, col0=0):
+    """In place on X (GS_SOR_8_2d, pdeSolvers.c:153)."""
+    _chk(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW)
+    nrows, ncols, F = _dims(X)
+    capi.call("pdeip_pde_sor8_dev", _stream(), *_p(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW), nrows, ncols, F,
+              int(iter), float(omega), int(mode), int(col0))
+
+
+def oflow_res_elin4(RU, RV, U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS):
+    _chk(RU, RV, U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_oflow_res_elin4_dev", _stream(), *_p(RU, RV, U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS), nrows,
+              ncols, _dims(M)[2])
+
+
+def oflow_lhs_elin4(AU, AV, U, V, M, Du, Dv, wW, wN, wE, wS):
+    _chk(AU, AV, U, V, M, Du, Dv, wW, wN, wE, wS)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_oflow_lhs_elin4_dev", _stream(), *_p(AU, AV, U, V, M, Du, Dv, wW, wN, wE, wS), nrows, ncols,
+              _dims(M)[2])
+
+
+def diffweights6(D, eps, wW, wN, wE, wS):
+    _chk(D, wW, wN, wE, wS)
+    nrows, ncols, F = _dims(D)
+    capi.call("pdeip_diffweights6_dev", _stream(), D.data_ptr(), nrows, ncols, F, float(eps), *_p(wW, wN, wE, wS))
+
+
+def warp_bilinear(Iin, X, Y, Iout):
+    _chk(Iin, X, Y, Iout)
+    nrows, ncols, F = _dims(Iin)
+    capi.call("pdeip_warp_bilinear_dev", _stream(), *_p(Iin, X, Y), nrows, ncols, F, Iout.data_ptr())

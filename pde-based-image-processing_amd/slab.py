@@ -1,0 +1,148 @@
+"""One frame across several GPUs: column slabs + wide-halo exchange (RED_BLACK ordering).
+
+Why column slabs.  The buffers are MATLAB column-major, so a block of consecutive MATLAB columns
+is one contiguous byte range of every plane: a slab is a zero-copy slice, and a halo of H
+columns is one contiguous message of H*nrows floats per field ("row tiles with a one-row halo"
+in BASELINE.json's wording, seen from the transposed image the kernels work on).
+
+Why a wide halo.  A red-black sweep moves information by at most two columns, so a slab that
+carries H = 2k halo columns on each cut side can run k sweeps with no communication and still
+have bit-exact values in the columns it owns; the halo's outer columns go stale and are simply
+refreshed by the next exchange.  One exchange per solver call (k = iter, typically 4) replaces
+the 2*iter per-colour exchanges a one-column halo would need: the messages (H*nrows*4 B per
+field, 69 KB at 2160 rows and iter=4) stay latency-bound either way, so fewer is better on
+point-to-point xGMI.  The exact-order (lexicographic) mode does not decompose this way -- its
+dependency front crosses the whole frame -- so it is single-GPU (replicas) only.
+
+Exchange = torch.distributed batched isend/irecv (backend "nccl" is RCCL on ROCm; "gloo" in the
+CPU tests).  There is no reduction collective on the path: iteration counts are fixed.
+
+The local relaxation is injected (`sweep_fn`) so the decomposition logic can be tested on CPU
+with world_size 2 against the single-domain oracle; the product default is the HIP library.
+"""
+import torch
+import torch.distributed as dist
+
+
+def split_columns(ncols, world):
+    """Contiguous, near-equal column ranges [c0, c1) per rank."""
+    base, rem = divmod(ncols, world)
+    bounds, c = [], 0
+    for r in range(world):
+        w = base + (1 if r < rem else 0)
+        bounds.append((c, c + w))
+        c += w
+    return bounds
+
+
+class SlabDomain:
+    """Geometry of this rank's slab of a [ncols, nrows] frame and its halo exchange."""
+
+    def __init__(self, ncols, nrows, rank, world, halo, group=None):
+        if world > 1 and min(c1 - c0 for c0, c1 in split_columns(ncols, world)) < halo:
+            raise ValueError("slabs of %d columns are narrower than the halo (%d)" % (ncols // world, halo))
+        self.ncols, self.nrows, self.rank, self.world, self.halo, self.group = ncols, nrows, rank, world, halo, group
+        self.c0, self.c1 = split_columns(ncols, world)[rank]
+        self.lo = max(0, self.c0 - halo)          # first global column held locally
+        self.hi = min(ncols, self.c1 + halo)      # one past the last
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+
+    @property
+    def col0(self):
+        """Global index of local column 0 (colour parity for the kernels)."""
+        return self.lo
+
+    @property
+    def ncols_local(self):
+        return self.hi - self.lo
+
+    def slice_local(self, plane):
+        """Global plane [(F,) ncols, nrows] -> this rank's slab incl. halo (a copy: it becomes resident)."""
+        return plane[..., self.lo:self.hi, :].clone(memory_format=torch.contiguous_format)
+
+    def owned(self, local):
+        """View of the columns this rank owns inside a local plane."""
+        return local[..., self.c0 - self.lo:self.c1 - self.lo, :]
+
+    def exchange(self, fields):
+        """Refresh the halo columns of every local 2-D plane in `fields` from the neighbours' owned columns."""
+        if self.world == 1:
+            return
+        H, ops, keep = self.halo, [], []
+        for t in fields:
+            own0, own1 = self.c0 - self.lo, self.c1 - self.lo
+            if self.left is not None:
+                ops.append(dist.P2POp(dist.isend, t[own0:own0 + H], self.left, self.group))
+                ops.append(dist.P2POp(dist.irecv, t[own0 - H:own0], self.left, self.group))
+            if self.right is not None:
+                ops.append(dist.P2POp(dist.isend, t[own1 - H:own1], self.right, self.group))
+                ops.append(dist.P2POp(dist.irecv, t[own1:own1 + H], self.right, self.group))
+            keep.append(t)
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def gather_owned(self, local, dst=0):
+        """Rank `dst` gets the assembled [ncols, nrows] plane (others get None)."""
+        mine = self.owned(local).contiguous()
+        if self.world == 1:
+            return mine
+        if self.rank == dst:
+            parts = [torch.empty((c1 - c0, self.nrows), dtype=mine.dtype, device=mine.device)
+                     for c0, c1 in split_columns(self.ncols, self.world)]
+            parts[dst] = mine
+            reqs = [dist.irecv(parts[r], r, self.group) for r in range(self.world) if r != dst]
+            for q in reqs:
+                q.wait()
+            return torch.cat(parts, dim=0)
+        dist.send(mine, dst, self.group)
+        return None
+
+
+def _hip_elin4(it, coef, n_sweeps, omega, col0):
+    from . import capi, device
+    device.oflow_sor_elin4(it[0], it[1], *coef, n_sweeps, omega, mode=capi.MODE_RED_BLACK, col0=col0)
+
+
+def _hip_llin4(it, coef, n_sweeps, omega, col0):
+    from . import capi, device
+    device.oflow_sor_llin4(coef[0], coef[1], it[0], it[1], *coef[2:], n_sweeps, omega, mode=capi.MODE_RED_BLACK,
+                           col0=col0)
+
+
+def _hip_disp4(it, coef, n_sweeps, omega, col0):
+    from . import capi, device
+    device.disp_sor_llin4(coef[0], it[0], *coef[1:], n_sweeps, omega, mode=capi.MODE_RED_BLACK, col0=col0)
+
+
+def _hip_pde4(it, coef, n_sweeps, omega, col0):
+    from . import capi, device
+    device.pde_sor4(it[0], *coef, n_sweeps, omega, mode=capi.MODE_RED_BLACK, col0=col0)
+
+
+HIP_SWEEPS = {"elin4": _hip_elin4, "llin4": _hip_llin4, "disp4": _hip_disp4, "pde4": _hip_pde4}
+
+
+class SlabSolver:
+    """`iter` red-black SOR sweeps of one 5-point solver on this rank's slab.
+
+    iterate : list of local planes relaxed in place (U,V / dU,dV / dU / X), each [ncols_local, nrows]
+    coef    : list of local read-only planes in the order the kernel takes them
+              elin4: M,Cu,Cv,Du,Dv,wW,wN,wE,wS   llin4: U,V,M,Cu,Cv,Du,Dv,wW,wN,wE,wS
+              disp4: U,Cu,Du,wW,wN,wE,wS          pde4 : TRACE,B,wW,wN,wE,wS
+    sweeps_per_exchange : k; the domain's halo must be >= 2k.
+    """
+
+    def __init__(self, domain, kind="elin4", sweeps_per_exchange=4, sweep_fn=None):
+        if domain.world > 1 and domain.halo < 2 * sweeps_per_exchange:
+            raise ValueError("halo %d < 2 * sweeps_per_exchange (%d)" % (domain.halo, sweeps_per_exchange))
+        self.dom, self.k = domain, sweeps_per_exchange
+        self.sweep_fn = sweep_fn if sweep_fn is not None else HIP_SWEEPS[kind]
+
+    def solve(self, iterate, coef, iters, omega):
+        done = 0
+        while done < iters:
+            k = min(self.k, iters - done)
+            self.dom.exchange(iterate)
+            self.sweep_fn(iterate, coef, k, omega, self.dom.col0)
+            done += k

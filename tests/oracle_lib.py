@@ -224,3 +224,11 @@ def DdiffWeights(D, eps):
 
 def BilinInterp_2d(Iin, X, Y):
     return warp_bilinear(Iin, X, Y)
+
+
+def Oflow_lhs_elin4_2d(U, V, M, Du, Dv, wW, wN, wE, wS):
+    return oflow_lhs_elin4(U, V, M, Du, Dv, wW, wN, wE, wS)
+
+
+def Oflow_lhs_llin4_2d(U, V, dU, dV, M, Du, Dv, wW, wN, wE, wS):
+    return oflow_lhs_llin4(U, V, dU, dV, M, Du, Dv, wW, wN, wE, wS)

@@ -1,0 +1,108 @@
+"""CPU, world_size 2 and 3 over gloo: the column-slab decomposition + wide-halo exchange (slab.py) gives,
+on the columns each rank owns, bit for bit what the single-domain red-black sweep gives.
+
+The local relaxation is the injected oracle sweep (no GPU here); on the GPU box the same SlabSolver runs
+the HIP kernels (tests/test_gpu_slab.py, bench.py --gpus N)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NROWS, NCOLS = 37, 61   # odd sizes: slabs of unequal width, odd col0 on some ranks
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_sweep(kind):
+    import oracle_lib as orc
+
+    def np_view(t):  # torch [ncols_local, nrows] C-order  ==  numpy [nrows, ncols_local] F-order (zero copy)
+        return t.numpy().T
+
+    def fn(iterate, coef, k, omega, col0):
+        order = orc.COLOUR | ((col0 & 1) << 1)
+        it = [np_view(t) for t in iterate]
+        cf = [np_view(t) for t in coef]
+        if kind == "elin4":
+            U, V = orc.oflow_sor_elin4(it[0], it[1], *cf, k, omega, order)
+            it[0][...], it[1][...] = U, V
+        elif kind == "llin4":
+            dU, dV = orc.oflow_sor_llin4(cf[0], cf[1], it[0], it[1], *cf[2:], k, omega, order)
+            it[0][...], it[1][...] = dU, dV
+        elif kind == "disp4":
+            it[0][...] = orc.disp_sor_llin4(cf[0], it[0], *cf[1:], k, omega, order)
+        elif kind == "pde4":
+            it[0][...] = orc.pde_sor4(it[0], *cf, k, omega, order)
+    return fn
+
+
+def _problem(kind):
+    import problems as pb
+
+    if kind == "elin4":
+        p = pb.elin4(401, NROWS, NCOLS, nan_frac=0.03)
+        return [p["U"], p["V"]], [p[k] for k in ("M", "Cu", "Cv", "Du", "Dv", "wW", "wN", "wE", "wS")]
+    if kind == "llin4":
+        p = pb.llin4(402, NROWS, NCOLS)
+        return [p["dU"], p["dV"]], [p[k] for k in ("U", "V", "M", "Cu", "Cv", "Du", "Dv", "wW", "wN", "wE", "wS")]
+    if kind == "disp4":
+        p = pb.disp4(403, NROWS, NCOLS)
+        return [p["dU"]], [p[k] for k in ("U", "Cu", "Du", "wW", "wN", "wE", "wS")]
+    p = pb.pde4(404, NROWS, NCOLS)
+    return [p["X"]], [p[k] for k in ("TRACE", "B", "wW", "wN", "wE", "wS")]
+
+
+def _worker(rank, world, port, kind, iters, k, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        slab = importlib.import_module("pde-based-image-processing_amd.slab")
+        iterate, coef = _problem(kind)
+        to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a.T))  # MATLAB [nrows,ncols] -> [ncols,nrows]
+        dom = slab.SlabDomain(NCOLS, NROWS, rank, world, halo=2 * k)
+        it_l = [dom.slice_local(to_t(a)) for a in iterate]
+        cf_l = [dom.slice_local(to_t(a)) for a in coef]
+        slab.SlabSolver(dom, kind, sweeps_per_exchange=k, sweep_fn=_oracle_sweep(kind)).solve(it_l, cf_l, iters, 1.7)
+        gathered = [dom.gather_owned(t) for t in it_l]
+        if rank == 0:
+            np.savez(out_path, *[g.numpy().T for g in gathered])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kind,iters,k", [("elin4", 4, 4), ("elin4", 7, 3), ("llin4", 4, 2), ("disp4", 5, 4), ("pde4", 4, 4)])
+def test_slabs_match_single_domain(tmp_path, oracle, world, kind, iters, k):
+    out = str(tmp_path / "gathered.npz")
+    mp.spawn(_worker, args=(world, _free_port(), kind, iters, k, out), nprocs=world, join=True)
+    got = np.load(out)
+    iterate, coef = _problem(kind)
+    single = [t.clone() for t in map(lambda a: torch.from_numpy(np.ascontiguousarray(a.T)), iterate)]
+    _oracle_sweep(kind)(single, [torch.from_numpy(np.ascontiguousarray(a.T)) for a in coef], iters, 1.7, 0)
+    import problems as pb
+    for f, s in enumerate(single):
+        assert pb.bit_equal(got["arr_%d" % f], s.numpy().T), "%s field %d: %s" % (kind, f, pb.describe_mismatch(got["arr_%d" % f], s.numpy().T))
+
+
+def test_split_columns_and_halo_checks():
+    slab = importlib.import_module("pde-based-image-processing_amd.slab")
+    assert slab.split_columns(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    d = slab.SlabDomain(3840, 2160, 3, 8, halo=8)
+    assert (d.c0, d.c1, d.lo, d.hi, d.col0) == (1440, 1920, 1432, 1928, 1432)
+    with pytest.raises(ValueError):
+        slab.SlabDomain(40, 10, 0, 8, halo=8)
+    with pytest.raises(ValueError):
+        slab.SlabSolver(slab.SlabDomain(3840, 2160, 1, 2, halo=4), sweeps_per_exchange=4)
