@@ -81,6 +81,12 @@ int set_err(int code, const char *fmt, ...)
             return set_err(PDEIP_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));     \
     } while (0)
 
+#define RC(expr)                  \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_) return rc_;      \
+    } while (0)
+
 // Grow-only device workspace.  Growing synchronises the device (old buffer may be in use).
 int ws_get(int slot, size_t bytes, float **out)
 {
@@ -136,8 +142,11 @@ int env_int(const char *name, int dflt)
 // sweep drivers (5-point models)
 // ------------------------------------------------------------------------------------------------
 
+dim3 pixel_grid(int nrows, int ncols, int nz) { return dim3((unsigned)((nrows + 255) / 256), (unsigned)ncols, (unsigned)nz); }
+
 // Runs `iter` sweeps of model Mdl on the iterate buffers P.it_out (in place from the caller's
-// point of view).  P.cf / P.ro must be set; P.it_in is ignored.
+// point of view).  P.ro and P.cf must be set, with the RAW planes in the two derived slots
+// (Mdl::D0, Mdl::D1); the derived planes (divisors) are built into workspace here.
 template <class Mdl>
 int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nframes, int iter,
                float omega, int mode, int col0)
@@ -146,16 +155,29 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     const size_t n = (size_t)nrows * ncols;
     g.last_launches = 0;
     if (iter <= 0) return PDEIP_OK;
+    float *aux0 = nullptr, *aux1 = nullptr;
+    RC(ws_get(WS_AUX0, n * nframes * sizeof(float), &aux0));
+    RC(ws_get(WS_AUX1, n * nframes * sizeof(float), &aux1));
 
     if (mode == PDEIP_MODE_EXACT_ORDER) {
+        hipLaunchKernelGGL(k_derive<Mdl>, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, P, aux0, aux1, nrows, ncols, n);
+        g.last_launches++;
+        P.cf[Mdl::D0] = aux0;
+        P.cf[Mdl::D1] = aux1;
         const int A = (nrows - 2 + 63 + EX_R - 1) / EX_R;
         const int B = (ncols - 2 + 63) / 64;
         const int last_m = (A - 1) + 2 * (B - 1) + 3 * (iter - 1);
         for (int f = 0; f < NIT; f++) P.it_in[f] = P.it_out[f];
         const dim3 grid((unsigned)(B * iter), (unsigned)nframes);
+        constexpr size_t lds = ExactLayout<Mdl>::LDS_BYTES;
+        static bool lds_opt_in = false; // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
+        if (!lds_opt_in) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sor_exact<Mdl>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_opt_in = true;
+        }
         SweepTimer timer(s);
         for (int m = 0; m <= last_m; m++) {
-            hipLaunchKernelGGL(k_sor_exact<Mdl>, grid, dim3(64), 0, s, P, nrows, ncols, A, B, iter, m, omega, n);
+            hipLaunchKernelGGL(k_sor_exact<Mdl>, grid, dim3(64), lds, s, P, nrows, ncols, A, B, iter, m, omega, n);
             g.last_launches++;
         }
         timer.stop(last_m + 1);
@@ -179,9 +201,10 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         vec = vec && aligned16(bufA[f]) && aligned16(bufB[f]);
     }
     for (int f = 0; f < Mdl::NCF; f++) vec = vec && aligned16(P.cf[f]);
+    vec = vec && aligned16(aux0) && aligned16(aux1);
     for (int f = 0; f < Mdl::NRO; f++) vec = vec && aligned16(P.ro[f]);
 
-    int TJ = g.rb_tj > 0 ? g.rb_tj : env_int("PDEIP_RB_TJ", 32);
+    int TJ = g.rb_tj > 0 ? g.rb_tj : env_int("PDEIP_RB_TJ", 12);
     if (TJ < 2) TJ = 2;
     const int ntiles_r = (nrows + RB_OWN_ROWS - 1) / RB_OWN_ROWS;
     const int nstrips = (ncols + TJ - 1) / TJ;
@@ -194,10 +217,17 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             P.it_in[f] = (it & 1) ? bufB[f] : bufA[f];
             P.it_out[f] = (it & 1) ? bufA[f] : bufB[f];
         }
-        if (vec)
-            hipLaunchKernelGGL((k_sor_rb<Mdl, true>), grid, block, 0, s, P, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+        if (it == 0) { // sweep 0 also builds the divisor planes
+            if (vec)
+                hipLaunchKernelGGL((k_sor_rb<Mdl, true, true>), grid, block, 0, s, P, aux0, aux1, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+            else
+                hipLaunchKernelGGL((k_sor_rb<Mdl, false, true>), grid, block, 0, s, P, aux0, aux1, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+            P.cf[Mdl::D0] = aux0;
+            P.cf[Mdl::D1] = aux1;
+        } else if (vec)
+            hipLaunchKernelGGL((k_sor_rb<Mdl, true, false>), grid, block, 0, s, P, nullptr, nullptr, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
         else
-            hipLaunchKernelGGL((k_sor_rb<Mdl, false>), grid, block, 0, s, P, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+            hipLaunchKernelGGL((k_sor_rb<Mdl, false, false>), grid, block, 0, s, P, nullptr, nullptr, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
         g.last_launches++;
     }
     timer.stop(iter);
@@ -207,8 +237,6 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }
-
-dim3 pixel_grid(int nrows, int ncols, int nz) { return dim3((unsigned)((nrows + 255) / 256), (unsigned)ncols, (unsigned)nz); }
 
 // ------------------------------------------------------------------------------------------------
 // host staging: one arena per call, carved sequentially
@@ -242,12 +270,6 @@ int download(float *dst, const float *src, size_t nfloats)
     HIPCHK(hipMemcpy(dst, src, nfloats * sizeof(float), hipMemcpyDeviceToHost));
     return PDEIP_OK;
 }
-
-#define RC(expr)                  \
-    do {                          \
-        int rc_ = (expr);         \
-        if (rc_) return rc_;      \
-    } while (0)
 
 #define NONNULL(who, p)                                                                    \
     do {                                                                                   \
@@ -329,18 +351,12 @@ extern "C" int pdeip_oflow_sor_elin4_dev(void *stream, float *U, float *V, const
     RC(check_mode(who, mode));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (iter <= 0) return PDEIP_OK;
-    const size_t n = (size_t)nrows * ncols;
-    float *divU, *divV;
-    RC(ws_get(WS_AUX0, n * sizeof(float), &divU));
-    RC(ws_get(WS_AUX1, n * sizeof(float), &divV));
-    hipLaunchKernelGGL(k_oflow_divisors, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, divU, divV, Du, Dv, wW, wN, wE, wS, nrows, ncols);
     SweepPlanes<ModelElin4> P{};
     P.it_out[0] = U;
     P.it_out[1] = V;
-    const float *cf[9] = {M, Cu, Cv, divU, divV, wW, wN, wE, wS};
+    const float *cf[9] = {M, Cu, Cv, Du, Dv, wW, wN, wE, wS}; // Du,Dv: raw planes in the divisor slots
     for (int f = 0; f < 9; f++) P.cf[f] = cf[f];
     RC(run_sweeps<ModelElin4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
-    g.last_launches++;
     return PDEIP_OK;
 }
 
@@ -355,20 +371,14 @@ extern "C" int pdeip_oflow_sor_llin4_dev(void *stream, const float *U, const flo
     RC(check_mode(who, mode));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (iter <= 0) return PDEIP_OK;
-    const size_t n = (size_t)nrows * ncols;
-    float *divU, *divV;
-    RC(ws_get(WS_AUX0, n * sizeof(float), &divU));
-    RC(ws_get(WS_AUX1, n * sizeof(float), &divV));
-    hipLaunchKernelGGL(k_oflow_divisors, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, divU, divV, Du, Dv, wW, wN, wE, wS, nrows, ncols);
     SweepPlanes<ModelLlin4> P{};
     P.it_out[0] = dU;
     P.it_out[1] = dV;
     P.ro[0] = U;
     P.ro[1] = V;
-    const float *cf[9] = {M, Cu, Cv, divU, divV, wW, wN, wE, wS};
+    const float *cf[9] = {M, Cu, Cv, Du, Dv, wW, wN, wE, wS}; // Du,Dv: raw planes in the divisor slots
     for (int f = 0; f < 9; f++) P.cf[f] = cf[f];
     RC(run_sweeps<ModelLlin4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
-    g.last_launches++;
     return PDEIP_OK;
 }
 
@@ -382,18 +392,12 @@ extern "C" int pdeip_disp_sor_llin4_dev(void *stream, const float *U, float *dU,
     RC(check_mode(who, mode));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (iter <= 0) return PDEIP_OK;
-    const size_t n = (size_t)nrows * ncols;
-    float *dividend, *div;
-    RC(ws_get(WS_AUX0, n * sizeof(float), &dividend));
-    RC(ws_get(WS_AUX1, n * sizeof(float), &div));
-    hipLaunchKernelGGL(k_disp_divisors, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, dividend, div, Cu, Du, wW, wN, wE, wS, nrows, ncols);
     SweepPlanes<ModelDisp4> P{};
     P.it_out[0] = dU;
     P.ro[0] = U;
-    const float *cf[6] = {dividend, div, wW, wN, wE, wS};
+    const float *cf[6] = {Cu, Du, wW, wN, wE, wS}; // Cu,Du: raw planes in the dividend/divisor slots
     for (int f = 0; f < 6; f++) P.cf[f] = cf[f];
     RC(run_sweeps<ModelDisp4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
-    g.last_launches++;
     return PDEIP_OK;
 }
 
@@ -406,17 +410,11 @@ extern "C" int pdeip_pde_sor4_dev(void *stream, float *X, const float *TRACE, co
     RC(check_mode(who, mode));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (iter <= 0) return PDEIP_OK;
-    const size_t n = (size_t)nrows * ncols;
-    float *bt, *inv;
-    RC(ws_get(WS_AUX0, n * nframes * sizeof(float), &bt));
-    RC(ws_get(WS_AUX1, n * nframes * sizeof(float), &inv));
-    hipLaunchKernelGGL(k_pde4_divisors, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, bt, inv, TRACE, B, wW, wN, wE, wS, nrows, ncols, n);
     SweepPlanes<ModelPde4> P{};
     P.it_out[0] = X;
-    const float *cf[6] = {bt, inv, wW, wN, wE, wS};
+    const float *cf[6] = {B, TRACE, wW, wN, wE, wS}; // B,TRACE: raw planes in the derived slots
     for (int f = 0; f < 6; f++) P.cf[f] = cf[f];
     RC(run_sweeps<ModelPde4>(s, P, nrows, ncols, nframes, iter, omega, mode, col0));
-    g.last_launches++;
     return PDEIP_OK;
 }
 

@@ -25,6 +25,17 @@ template <int N> struct at_least_one { static constexpr int value = N > 0 ? N : 
 struct ModelElin4 {
     static constexpr int NIT = 2, NRO = 0, NCF = 9;
     enum { cM = 0, cCu, cCv, cDivU, cDivV, cWW, cWN, cWE, cWS };
+    static constexpr int D0 = cDivU, D1 = cDivV; // derived planes; their slots hold Du, Dv before derive()
+    // opticalflowSolvers.c:111-127: the divisors the reference builds during its first sweep
+    __device__ __forceinline__ static void derive(float (&k)[9])
+    {
+        float t1 = k[cWW] + k[cWE];
+        const float t2 = k[cWN] + k[cWS];
+        t1 += t2;
+        const float du = k[cDivU], dv = k[cDivV];
+        k[cDivU] = is_nan(du) ? 1.0f / t1 : 1.0f / (t1 + du);
+        k[cDivV] = is_nan(dv) ? 1.0f / t1 : 1.0f / (t1 + dv);
+    }
     __device__ __forceinline__ static void update(float (&c)[2], const float (&W)[2],
                                                   const float (&E)[2], const float (&N)[2],
                                                   const float (&S)[2], const float (&)[1],
@@ -70,6 +81,8 @@ struct ModelElin4 {
 struct ModelLlin4 {
     static constexpr int NIT = 2, NRO = 2, NCF = 9;
     enum { cM = 0, cCu, cCv, cDivU, cDivV, cWW, cWN, cWE, cWS };
+    static constexpr int D0 = cDivU, D1 = cDivV;
+    __device__ __forceinline__ static void derive(float (&k)[9]) { ModelElin4::derive(k); } // :606-622
     __device__ __forceinline__ static float neigh(float dW, float dE, float dN, float dS, float uW,
                                                   float uE, float uN, float uS, float uc,
                                                   const float (&cf)[9])
@@ -121,6 +134,19 @@ struct ModelLlin4 {
 struct ModelDisp4 {
     static constexpr int NIT = 1, NRO = 1, NCF = 6;
     enum { cDividend = 0, cDiv, cWW, cWN, cWE, cWS };
+    static constexpr int D0 = cDividend, D1 = cDiv; // slots hold Cu, Du before derive()
+    // disparitySolvers.c:94-113
+    __device__ __forceinline__ static void derive(float (&k)[6])
+    {
+        const float cu = k[cDividend];
+        const bool ok = !is_nan(cu);
+        float t = ok ? k[cDiv] + k[cWE] : k[cWE];
+        t = t + k[cWW];
+        t = t + k[cWS];
+        t = t + k[cWN];
+        k[cDividend] = ok ? cu : 0.0f;
+        k[cDiv] = 1.0f / t;
+    }
     __device__ __forceinline__ static float neigh(float dW, float dE, float dN, float dS, float uW,
                                                   float uE, float uN, float uS, float uc,
                                                   const float (&cf)[6])
@@ -155,6 +181,17 @@ struct ModelDisp4 {
 struct ModelPde4 {
     static constexpr int NIT = 1, NRO = 0, NCF = 6;
     enum { cB = 0, cInv, cWW, cWN, cWE, cWS };
+    static constexpr int D0 = cB, D1 = cInv; // slots hold B, TRACE before derive()
+    // pdeSolvers.c:99-115
+    __device__ __forceinline__ static void derive(float (&k)[6])
+    {
+        const float tr = k[cInv];
+        float t = k[cWE] + k[cWW];
+        t += k[cWS] + k[cWN];
+        const bool ok = !is_nan(tr);
+        k[cInv] = ok ? 1.0f / tr : 1.0f / t;
+        k[cB] = ok ? k[cB] : 0.0f;
+    }
     __device__ __forceinline__ static void update(float (&c)[1], const float (&W)[1],
                                                   const float (&E)[1], const float (&N)[1],
                                                   const float (&S)[1], const float (&)[1],

@@ -18,49 +18,20 @@ namespace pdeip {
 
 // ---- divisor prologues (what the reference builds during its first sweep) -------------------
 
-// opticalflowSolvers.c:111-127 / :606-622
-__global__ void k_oflow_divisors(float *divU, float *divV, const float *Du, const float *Dv,
-                                 const float *wW, const float *wN, const float *wE,
-                                 const float *wS, int nrows, int ncols)
+// Generic form for the 5-point models: P.cf[D0], P.cf[D1] point at the raw planes; the derived
+// planes go to out0/out1.  Used by the exact-order path (the red-black path fuses this into its
+// first sweep).  Loads of slots derive() does not read are dead code.
+template <class Mdl>
+__global__ void k_derive(SweepPlanes<Mdl> P, float *out0, float *out1, int nrows, int ncols, size_t frame_stride)
 {
     PDEIP_PIXEL_INDEX();
-    float t1 = wW[pos] + wE[pos];
-    float t2 = wN[pos] + wS[pos];
-    t1 += t2;
-    const float du = Du[pos], dv = Dv[pos];
-    divU[pos] = is_nan(du) ? 1.0f / t1 : 1.0f / (t1 + du);
-    divV[pos] = is_nan(dv) ? 1.0f / t1 : 1.0f / (t1 + dv);
-}
-
-// disparitySolvers.c:94-113
-__global__ void k_disp_divisors(float *dividend, float *div, const float *Cu, const float *Du,
-                                const float *wW, const float *wN, const float *wE,
-                                const float *wS, int nrows, int ncols)
-{
-    PDEIP_PIXEL_INDEX();
-    const float cu = Cu[pos];
-    const bool ok = !is_nan(cu);
-    float t = ok ? Du[pos] + wE[pos] : wE[pos];
-    t = t + wW[pos];
-    t = t + wS[pos];
-    t = t + wN[pos];
-    dividend[pos] = ok ? cu : 0.0f;
-    div[pos] = 1.0f / t;
-}
-
-// pdeSolvers.c:99-115
-__global__ void k_pde4_divisors(float *bt, float *inv, const float *TRACE, const float *B,
-                                const float *wW, const float *wN, const float *wE,
-                                const float *wS, int nrows, int ncols, size_t frame_stride)
-{
-    PDEIP_PIXEL_INDEX();
-    const size_t p = pos + (size_t)blockIdx.z * frame_stride;
-    const float tr = TRACE[p];
-    float t = wE[p] + wW[p];
-    t += wS[p] + wN[p];
-    const bool ok = !is_nan(tr);
-    inv[p] = ok ? 1.0f / tr : 1.0f / t;
-    bt[p] = ok ? B[p] : 0.0f;
+    const size_t q = pos + (size_t)blockIdx.z * frame_stride;
+    float k[Mdl::NCF];
+#pragma unroll
+    for (int f = 0; f < Mdl::NCF; f++) k[f] = P.cf[f][q];
+    Mdl::derive(k);
+    out0[q] = k[Mdl::D0];
+    out1[q] = k[Mdl::D1];
 }
 
 // pdeSolvers.c:217-237

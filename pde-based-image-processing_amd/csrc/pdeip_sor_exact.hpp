@@ -10,12 +10,21 @@
 //   * a strip b is 64 adjacent interior columns, one per lane (lane l <-> column 1+64b+l);
 //   * a tile (a,b,t) is R=64 steps of strip b in sweep t; at step q lane l relaxes row
 //     1 + a*R + q - l, so a wave is a diagonal front: the value lane l-1 produced one step
-//     earlier is lane l's west neighbour (wavefront shuffle), the lane's own previous value
+//     earlier is lane l's west neighbour (one DPP wave shift), the lane's own previous value
 //     is its north neighbour, and its south/east neighbours are still sweep t-1 in memory.
 //   * tile (a,b,t) depends only on tiles with a smaller m = a + 2b + 3t, and nothing it
-//     overwrites is still needed by a tile with the same m (see DESIGN.md "exact order").
+//     overwrites is still needed by a tile with the same m (DESIGN.md "exact order").
 //     One launch relaxes every tile of one m; launches are stream-ordered, so there is no
 //     inter-workgroup synchronisation inside a launch and nothing that can spin.
+//
+// Memory.  Everything a tile reads was final before its launch, so it is all prefetchable.  A
+// tile runs as four chunks of 16 steps.  The parallelogram of each plane that a chunk touches
+// (64 columns x 16 rows, row offset = -lane) is fetched with coalesced 16-byte loads (lane ->
+// 4 consecutive rows of one column, 16 columns per instruction) into registers while the
+// previous chunk is being relaxed, then transposed through LDS ([plane][column][20-float row],
+// conflict-free ds_read_b128 of 4 steps at a time).  Results go back the same way: LDS, then
+// coalesced 16-byte stores.  The naive form (each lane streaming its own column) issues 64
+// cache lines per load instruction and ran 15x slower.
 //
 // Borders.  The reference replicates the border after every sweep (:161-179).  For a 5-point
 // stencil an interior pixel only ever reads the border cell next to itself, whose value
@@ -27,119 +36,244 @@
 
 namespace pdeip {
 
-constexpr int EX_R = 64; // steps per tile; the dependency analysis needs EX_R >= 63
+constexpr int EX_R = 64;   // steps per tile; the dependency analysis needs EX_R >= 63
+constexpr int EX_CH = 16;  // steps per chunk
+constexpr int EX_STR = 20; // LDS floats per (plane, column) row: 16 + 4 pad -> conflict-free b128 reads
+
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; }; // 16-byte access at 4-byte alignment
+
+__device__ __forceinline__ float dpp_from_lower_lane(float v, float lane0_value)
+{ // lane l <- lane l-1 (v_mov_b32_dpp wave_shr:1); lane 0 keeps lane0_value
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0_value), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_upper_lane(float v, float lane63_value)
+{ // lane l <- lane l+1 (wave_shl:1); lane 63 keeps lane63_value
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane63_value), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+template <class Mdl> struct ExactLayout {
+    static constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NF = NIT + NRO, NCF = Mdl::NCF, NP = NF + NCF;
+    static constexpr int STAGE = NP * 64 * EX_STR;  // chunk of every plane
+    static constexpr int OUTB = NIT * 64 * EX_STR;  // relaxed values of the chunk
+    static constexpr int EDGE = 2 * NF * EX_CH;     // west column of lane 0, east column of lane 63
+    static constexpr size_t LDS_BYTES = (size_t)(STAGE + OUTB + EDGE) * sizeof(float);
+};
 
 template <class Mdl>
 __global__ void __launch_bounds__(64)
 k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m, float omega,
             size_t frame_stride)
 {
-    constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NRO1 = at_least_one<NRO>::value, NCF = Mdl::NCF;
+    using L = ExactLayout<Mdl>;
+    constexpr int NIT = L::NIT, NRO = L::NRO, NRO1 = at_least_one<NRO>::value, NF = L::NF, NCF = L::NCF, NP = L::NP;
+    constexpr int NCHUNK = EX_R / EX_CH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *stage = smem, *outb = smem + L::STAGE, *edge = outb + L::OUTB;
+
     const int lane = threadIdx.x;
     const int b = blockIdx.x % B, t = blockIdx.x / B;
     const int a = m - 2 * b - 3 * t;
     if (a < 0 || a >= A) return;
     const size_t fo = (size_t)blockIdx.y * frame_stride;
+
+    // planes in staging order: iterate fields, read-only neighbour fields, coefficients
+    const float *pl[NP];
     float *it[NIT];
-    const float *ro[NRO1], *cfp[NCF];
-#pragma unroll
-    for (int f = 0; f < NIT; f++) it[f] = P.it_out[f] + fo;
-#pragma unroll
-    for (int f = 0; f < NRO1; f++) ro[f] = (NRO > 0) ? P.ro[f] + fo : nullptr;
-#pragma unroll
-    for (int f = 0; f < NCF; f++) cfp[f] = P.cf[f] + fo;
-
-    const int j = 1 + 64 * b + lane;              // this lane's column
-    const bool col_in = j <= ncols - 1;           // inside the buffer (may be the border column)
-    const bool col_ok = j <= ncols - 2;           // interior column: relaxed
-    const size_t cb = (size_t)j * nrows;          // column base offset
-    const float om1 = 1.0f - omega;
-    const bool first_sweep = (t == 0);
-    const int i0 = 1 + a * EX_R - lane;           // row at step 0
-
-    float prev[NIT], cen[NIT], rcen[NRO1], rnorth[NRO1];
 #pragma unroll
     for (int f = 0; f < NIT; f++) {
+        it[f] = P.it_out[f] + fo;
+        pl[f] = it[f];
+    }
+#pragma unroll
+    for (int f = 0; f < NRO; f++) pl[NIT + f] = P.ro[f] + fo;
+#pragma unroll
+    for (int f = 0; f < NCF; f++) pl[NF + f] = P.cf[f] + fo;
+
+    const int jbase = 1 + 64 * b;                 // column of lane 0
+    const int j = jbase + lane;                   // this lane's column
+    const bool col_ok = j <= ncols - 2;           // interior column: relaxed
+    const int jc = j < ncols - 1 ? j : ncols - 1; // clamped (valid address, value unused)
+    const size_t cb = (size_t)jc * nrows;
+    const float om1 = 1.0f - omega;
+    const bool first_sweep = (t == 0);
+    const int i00 = 1 + a * EX_R;                 // row of lane 0 at step 0
+    const int i0 = i00 - lane;                    // row of this lane at step 0
+    auto crow = [&](int i) { return i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i); };
+
+    // loader geometry: instruction g covers columns 16g..16g+15; this lane takes 4 consecutive rows
+    const int lcol = lane >> 2, lrq = lane & 3;
+
+    // ---- chunk fetch: global -> registers (coalesced), registers -> LDS ------------------------
+    f4u pre[NP][4], epre[NF];
+    auto fetch = [&](int k) {
+        // wave-uniform: every row any lane touches in this chunk lies inside the buffer
+        const bool inside = (i00 - 63 + EX_CH * k >= 0) && (i00 + EX_CH * k + EX_CH <= nrows - 1);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 16 * g + lcol;
+                int jj = jbase + col;
+                jj = jj < ncols - 1 ? jj : ncols - 1;
+                // centre rows for coefficients, south rows (one further) for the neighbour fields
+                const int row = i00 - col + EX_CH * k + (p < NF ? 1 : 0) + 4 * lrq;
+                const float *src = pl[p] + (size_t)jj * nrows;
+                if (inside) {
+                    pre[p][g] = *reinterpret_cast<const f4u *>(src + row);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pre[p][g].v[e] = src[crow(row + e)];
+                }
+            }
+        }
+        // edge columns: lanes 0-3 fetch the west column of lane 0 (centre rows of lane 0), lanes 4-7 the
+        // east column of lane 63 (centre rows of lane 63); the other lanes repeat them (same addresses)
+        const int which = (lane >> 2) & 1;
+        const int ecol = which ? (jbase + 64 < ncols - 1 ? jbase + 64 : ncols - 1) : jbase - 1;
+        const int erow = (which ? i00 - 63 : i00) + EX_CH * k + 4 * lrq;
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const float *src = pl[f] + (size_t)ecol * nrows;
+            if (inside) {
+                epre[f] = *reinterpret_cast<const f4u *>(src + erow);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) epre[f].v[e] = src[crow(erow + e)];
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 16 * g + lcol;
+                *reinterpret_cast<float4 *>(&stage[(p * 64 + col) * EX_STR + 4 * lrq]) =
+                    make_float4(pre[p][g].v[0], pre[p][g].v[1], pre[p][g].v[2], pre[p][g].v[3]);
+            }
+        if (lane < 8) {
+            const int which = (lane >> 2) & 1;
+#pragma unroll
+            for (int f = 0; f < NF; f++)
+                *reinterpret_cast<float4 *>(&edge[(which * NF + f) * EX_CH + 4 * lrq]) =
+                    make_float4(epre[f].v[0], epre[f].v[1], epre[f].v[2], epre[f].v[3]);
+        }
+    };
+
+    // ---- per-lane state at step 0 (scattered loads, once per tile) --------------------------------
+    float prev[NIT], cen[NIT], north0[NIT], west0[NIT], topb[NIT], rcen[NRO1], rnorth[NRO1];
+#pragma unroll
+    for (int f = 0; f < NIT; f++) {
+        cen[f] = it[f][cb + crow(i0)];
+        north0[f] = it[f][cb + crow(i0 - 1)];            // relaxed by tile a-1 (an earlier launch)
+        west0[f] = it[f][cb - nrows + crow(i0)];         // column j-1 >= 0; relaxed by an earlier launch
+        topb[f] = it[f][cb];                             // border row 0 (used in sweep 0 only)
         prev[f] = 0.0f;
-        cen[f] = (col_in && i0 >= 0 && i0 <= nrows - 1) ? it[f][cb + i0] : 0.0f;
     }
 #pragma unroll
     for (int f = 0; f < NRO1; f++) {
-        rcen[f] = (NRO > 0 && col_in && i0 >= 0 && i0 <= nrows - 1) ? ro[f][cb + i0] : 0.0f;
-        rnorth[f] = (NRO > 0 && col_in && i0 - 1 >= 0 && i0 - 1 <= nrows - 1) ? ro[f][cb + i0 - 1] : 0.0f;
+        rcen[f] = (NRO > 0) ? pl[NIT + (NRO > 0 ? f : 0)][cb + crow(i0)] : 0.0f;
+        rnorth[f] = (NRO > 0) ? pl[NIT + (NRO > 0 ? f : 0)][cb + crow(i0 - 1)] : 0.0f;
     }
 
-    for (int q = 0; q < EX_R; q++) {
-        const int i = i0 + q;
-        const bool row_ok = (i >= 1) && (i <= nrows - 2);
-        const bool active = col_ok && row_ok;
-        const bool can_load_s = col_in && (i + 1 >= 0) && (i + 1 <= nrows - 1);
+    fetch(0);
+    stash();
 
-        // south neighbours, raw memory (sweep t-1 for the iterate)
-        float sraw[NIT], rsouth[NRO1];
-#pragma unroll
-        for (int f = 0; f < NIT; f++) sraw[f] = can_load_s ? it[f][cb + i + 1] : 0.0f;
-#pragma unroll
-        for (int f = 0; f < NRO1; f++) rsouth[f] = (NRO > 0 && can_load_s) ? ro[f][cb + i + 1] : 0.0f;
+    for (int k = 0; k < NCHUNK; k++) {
+        if (k + 1 < NCHUNK) fetch(k + 1); // in flight while this chunk is relaxed
 
-        // east neighbours: lane l+1 sits one row higher, so its south value is (i, j+1)
-        float eraw[NIT], reast[NRO1];
 #pragma unroll
-        for (int f = 0; f < NIT; f++) {
-            eraw[f] = __shfl_down(sraw[f], 1);
-            if (lane == 63) eraw[f] = (row_ok && j + 1 <= ncols - 1) ? it[f][cb + nrows + i] : 0.0f;
-        }
+        for (int mq = 0; mq < EX_CH / 4; mq++) {
+            float4 ck[NCF], s4[NF], e4[NF], res[NIT];
 #pragma unroll
-        for (int f = 0; f < NRO1; f++) {
-            reast[f] = (NRO > 0) ? __shfl_down(rsouth[f], 1) : 0.0f;
-            if (NRO > 0 && lane == 63) reast[f] = (row_ok && j + 1 <= ncols - 1) ? ro[f][cb + nrows + i] : 0.0f;
-        }
-
-        // west neighbours: lane l-1 relaxed (i, j-1) one step ago; at step 0 and for lane 0 the
-        // value was written by an earlier launch and is read from memory
-        float wnew[NIT], rwest[NRO1];
-        const bool w_from_mem = (q == 0) || (lane == 0);
+            for (int f = 0; f < NCF; f++) ck[f] = *reinterpret_cast<const float4 *>(&stage[((NF + f) * 64 + lane) * EX_STR + 4 * mq]);
 #pragma unroll
-        for (int f = 0; f < NIT; f++) {
-            wnew[f] = __shfl_up(prev[f], 1);
-            if (w_from_mem) wnew[f] = (active) ? it[f][cb - nrows + i] : 0.0f;
-        }
-#pragma unroll
-        for (int f = 0; f < NRO1; f++) {
-            rwest[f] = (NRO > 0) ? __shfl_up(rnorth[f], 1) : 0.0f; // lane l-1's centre of the previous step
-            if (NRO > 0 && w_from_mem) rwest[f] = (active) ? ro[f][cb - nrows + i] : 0.0f;
-        }
-
-        if (active) {
-            float c[NIT], w[NIT], e[NIT], n[NIT], s[NIT], k[NCF];
-#pragma unroll
-            for (int f = 0; f < NIT; f++) {
-                c[f] = cen[f];
-                // north: own previous result; from memory at step 0 (earlier launch); border rule at row 1
-                float nv = (q == 0) ? it[f][cb + i - 1] : prev[f];
-                if (i == 1) nv = first_sweep ? it[f][cb] : cen[f];
-                n[f] = nv;
-                s[f] = (i + 1 == nrows - 1 && !first_sweep) ? cen[f] : sraw[f];
-                e[f] = (j + 1 == ncols - 1 && !first_sweep) ? cen[f] : eraw[f];
-                w[f] = (j - 1 == 0 && !first_sweep) ? cen[f] : wnew[f];
+            for (int f = 0; f < NF; f++) {
+                s4[f] = *reinterpret_cast<const float4 *>(&stage[(f * 64 + lane) * EX_STR + 4 * mq]);
+                e4[f] = *reinterpret_cast<const float4 *>(&edge[((lane == 63 ? 1 : 0) * NF + f) * EX_CH + 4 * mq]);
             }
 #pragma unroll
-            for (int f = 0; f < NCF; f++) k[f] = cfp[f][cb + i];
-            Mdl::update(c, w, e, n, s, rcen, rwest, reast, rnorth, rsouth, k, omega, om1);
+            for (int x = 0; x < 4; x++) {
+                const int q = EX_CH * k + 4 * mq + x;
+                const int i = i0 + q;
+                const bool row_ok = (i >= 1) && (i <= nrows - 2);
+                const bool active = col_ok && row_ok;
+                auto el = [&](const float4 &v) { return x == 0 ? v.x : (x == 1 ? v.y : (x == 2 ? v.z : v.w)); };
+
+                float c[NIT], w[NIT], e[NIT], n[NIT], s[NIT], kk[NCF];
+                float rsouth[NRO1], reast[NRO1], rwest[NRO1];
 #pragma unroll
-            for (int f = 0; f < NIT; f++) {
-                it[f][cb + i] = c[f];
-                prev[f] = c[f];
+                for (int f = 0; f < NIT; f++) {
+                    const float sraw = el(s4[f]);
+                    // east: lane l+1 sits one row higher, its south value is (i, j+1); lane 63 reads the edge column
+                    const float eraw = dpp_from_upper_lane(sraw, el(e4[f]));
+                    // west: lane l-1 relaxed (i, j-1) one step ago; lane 0 reads the edge column (earlier launch)
+                    float wnew = dpp_from_lower_lane(prev[f], el(e4[f]));
+                    if (q == 0 && lane != 0) wnew = west0[f];
+                    float nv = (q == 0) ? north0[f] : prev[f];
+                    if (i == 1) nv = first_sweep ? topb[f] : cen[f];
+                    c[f] = cen[f];
+                    n[f] = nv;
+                    s[f] = (i + 1 == nrows - 1 && !first_sweep) ? cen[f] : sraw;
+                    e[f] = (j + 1 == ncols - 1 && !first_sweep) ? cen[f] : eraw;
+                    w[f] = (j - 1 == 0 && !first_sweep) ? cen[f] : wnew;
+                    cen[f] = sraw; // next step's centre
+                }
+#pragma unroll
+                for (int f = 0; f < NRO1; f++) {
+                    if (NRO > 0) {
+                        rsouth[f] = el(s4[NIT + (NRO > 0 ? f : 0)]);
+                        reast[f] = dpp_from_upper_lane(rsouth[f], el(e4[NIT + (NRO > 0 ? f : 0)]));
+                        rwest[f] = dpp_from_lower_lane(rnorth[f], el(e4[NIT + (NRO > 0 ? f : 0)])); // lane l-1's north is (i, j-1)
+                    } else {
+                        rsouth[f] = reast[f] = rwest[f] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < NCF; f++) kk[f] = el(ck[f]);
+                Mdl::update(c, w, e, n, s, rcen, rwest, reast, rnorth, rsouth, kk, omega, om1);
+#pragma unroll
+                for (int f = 0; f < NIT; f++) {
+                    if (active) prev[f] = c[f];
+                    const float r = c[f];
+                    if (x == 0) res[f].x = r; else if (x == 1) res[f].y = r; else if (x == 2) res[f].z = r; else res[f].w = r;
+                }
+#pragma unroll
+                for (int f = 0; f < NRO1; f++) {
+                    rnorth[f] = rcen[f];
+                    rcen[f] = rsouth[f];
+                }
             }
-        }
-        // advance one row
 #pragma unroll
-        for (int f = 0; f < NIT; f++) cen[f] = sraw[f];
-#pragma unroll
-        for (int f = 0; f < NRO1; f++) {
-            rnorth[f] = rcen[f];
-            rcen[f] = rsouth[f];
+            for (int f = 0; f < NIT; f++) *reinterpret_cast<float4 *>(&outb[(f * 64 + lane) * EX_STR + 4 * mq]) = res[f];
         }
+
+        // ---- relaxed chunk: LDS -> global, coalesced; only interior pixels are written -----------------
+        {
+            const int lo_row = i00 - 63 + EX_CH * k, hi_row = i00 + EX_CH * k + EX_CH - 1;
+            const bool all_valid = (lo_row >= 1) && (hi_row <= nrows - 2) && (jbase + 63 <= ncols - 2);
+#pragma unroll
+            for (int f = 0; f < NIT; f++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = 16 * g + lcol;
+                    const int jj = jbase + col;
+                    const int row = i00 - col + EX_CH * k + 4 * lrq;
+                    const float4 v = *reinterpret_cast<const float4 *>(&outb[(f * 64 + col) * EX_STR + 4 * lrq]);
+                    float *dst = it[f] + (size_t)(jj < ncols - 1 ? jj : ncols - 1) * nrows;
+                    if (all_valid) {
+                        f4u o;
+                        o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
+                        *reinterpret_cast<f4u *>(dst + row) = o;
+                    } else if (jj <= ncols - 2) {
+                        if (row >= 1 && row <= nrows - 2) dst[row] = v.x;
+                        if (row + 1 >= 1 && row + 1 <= nrows - 2) dst[row + 1] = v.y;
+                        if (row + 2 >= 1 && row + 2 <= nrows - 2) dst[row + 2] = v.z;
+                        if (row + 3 >= 1 && row + 3 <= nrows - 2) dst[row + 3] = v.w;
+                    }
+                }
+        }
+        if (k + 1 < NCHUNK) stash(); // all reads of this chunk are done (one wave, in-order LDS)
     }
 }
 

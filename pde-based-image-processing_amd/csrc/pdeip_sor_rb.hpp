@@ -29,26 +29,28 @@ namespace pdeip {
 constexpr int RB_OWN_ROWS = 248; // 62 storing lanes x 4 rows
 constexpr int RB_WAVES_PER_BLOCK = 4;
 
+// Loads rows r..r+3 of column c.  Always issued, never branched on: a bounds check around a load
+// makes the compiler wait for it inside the branch, which serialises the thirteen loads of a step.
+// Out-of-image lanes/columns read a clamped (valid) address instead; their values are never used
+// for a stored result (they only feed border cells, which are not relaxed).
 template <bool VEC>
 __device__ __forceinline__ void rb_load4(float (&d)[4], const float *__restrict__ p, int c, int r,
                                          int nrows, int ncols)
 {
-    d[0] = d[1] = d[2] = d[3] = 0.0f;
-    if (c < 0 || c >= ncols) return; // wave-uniform
-    const float *q = p + (size_t)c * nrows;
+    const int cc = c < 0 ? 0 : (c > ncols - 1 ? ncols - 1 : c);
+    const float *q = p + (size_t)cc * nrows;
     if (VEC) {
-        if (r >= 0 && r < nrows) {
-            const float4 t = *reinterpret_cast<const float4 *>(q + r);
-            d[0] = t.x;
-            d[1] = t.y;
-            d[2] = t.z;
-            d[3] = t.w;
-        }
+        const int rr = r < 0 ? 0 : (r > nrows - 4 ? nrows - 4 : r);
+        const float4 t = *reinterpret_cast<const float4 *>(q + rr);
+        d[0] = t.x;
+        d[1] = t.y;
+        d[2] = t.z;
+        d[3] = t.w;
     } else {
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int i = r + e;
-            if (i >= 0 && i < nrows) d[e] = q[i];
+            d[e] = q[i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i)];
         }
     }
 }
@@ -120,16 +122,33 @@ __device__ __forceinline__ void rb_phase(float (&C)[Mdl::NIT][4], const float (&
     }
 }
 
-template <class Mdl, bool VEC>
+// FIRST: this is sweep 0 of a call.  The two derived coefficient planes (divisors) do not exist
+// yet: their slots in P.cf point at the raw planes (e.g. Du, Dv), every column is passed through
+// Mdl::derive() as it becomes current, and the owning unit stores the derived planes to
+// dout0/dout1 for the later sweeps -- what the reference does inside its first sweep
+// (opticalflowSolvers.c:111-127), at the cost of two plane writes instead of a separate pass.
+template <class Mdl, bool VEC, bool FIRST>
 __global__ void __launch_bounds__(64 * RB_WAVES_PER_BLOCK)
-k_sor_rb(SweepPlanes<Mdl> P, int nrows, int ncols, int TJ, int ntiles_r, int nunits, float omega,
-         int col0, size_t frame_stride)
+k_sor_rb(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, int TJ, int ntiles_r,
+         int nunits, float omega, int col0, size_t frame_stride)
 {
     constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NRO1 = at_least_one<NRO>::value, NCF = Mdl::NCF;
     const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * RB_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    // XCD-aware unit order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+    // contiguous range of units (neighbouring strips share their halo columns through one L2).
+    // Placement only changes speed, never results.
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, per = nb >> 3;
+        if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
+    }
+    const int unit = bid * RB_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (unit >= nunits) return; // whole wave leaves; no workgroup barrier is used below
     const size_t fo = (size_t)blockIdx.y * frame_stride;
+    if (FIRST) {
+        dout0 += fo;
+        dout1 += fo;
+    }
 #pragma unroll
     for (int f = 0; f < NIT; f++) {
         P.it_in[f] += fo;
@@ -197,6 +216,22 @@ k_sor_rb(SweepPlanes<Mdl> P, int nrows, int ncols, int TJ, int ntiles_r, int nun
         for (int f = 0; f < NCF; f++) rb_load4<VEC>(CFn[f], P.cf[f], c + 1, r, nrows, ncols);
 
         const int p = (c + col0) & 1;
+
+        if (FIRST) { // column c becomes current: build its divisors, keep them for the later sweeps
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float k[NCF];
+#pragma unroll
+                for (int f = 0; f < NCF; f++) k[f] = CFc[f][e];
+                Mdl::derive(k);
+                CFc[Mdl::D0][e] = k[Mdl::D0];
+                CFc[Mdl::D1][e] = k[Mdl::D1];
+            }
+            if (store_lane && c >= j0 && c < j1) {
+                rb_store4<VEC>(CFc[Mdl::D0], dout0, c, r, nrows);
+                rb_store4<VEC>(CFc[Mdl::D1], dout1, c, r, nrows);
+            }
+        }
 
         // red half-sweep on column c: R(c) from O(c-1), O(c), O(c+1)
         float Rc[NIT][4];
