@@ -315,6 +315,14 @@ extern "C" int pdeip_release(void)
     return PDEIP_OK;
 }
 extern "C" int pdeip_last_launch_count(void) { return g.last_launches; }
+#ifdef PDEIP_EXACT_STAMPS
+extern "C" int pdeip_debug_read_stamps(unsigned long long *out)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_exact_stamps), 64 * sizeof(unsigned long long)));
+    return PDEIP_OK;
+}
+#endif
 extern "C" int pdeip_profile_enable(int on)
 {
     g.profile = (on != 0);

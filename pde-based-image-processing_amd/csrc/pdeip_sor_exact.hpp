@@ -32,6 +32,8 @@
 // cell.  So border cells are read from memory in sweep 0, substituted by the pixel's own
 // old value in later sweeps, never written during the sweeps, and filled once at the end.
 #pragma once
+#include <type_traits>
+
 #include "pdeip_models.hpp"
 
 namespace pdeip {
@@ -40,7 +42,24 @@ constexpr int EX_R = 64;   // steps per tile; the dependency analysis needs EX_R
 constexpr int EX_CH = 16;  // steps per chunk
 constexpr int EX_STR = 20; // LDS floats per (plane, column) row: 16 + 4 pad -> conflict-free b128 reads
 
-struct __attribute__((packed, aligned(4))) f4u { float v[4]; }; // 16-byte access at 4-byte alignment
+// 16-byte global access at 4-byte alignment (rows of a column start anywhere).  A vector typedef with
+// reduced alignment keeps the access one global_load/store_dwordx4; a packed struct gets split into
+// four dword accesses by SROA.
+typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+struct f4u {
+    float v[4];
+    __device__ __forceinline__ void load(const float *p)
+    {
+        const v4f_a4 t = *reinterpret_cast<const v4f_a4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ __forceinline__ void store(float *p) const
+    {
+        v4f_a4 t;
+        t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        *reinterpret_cast<v4f_a4 *>(p) = t;
+    }
+};
 
 __device__ __forceinline__ float dpp_from_lower_lane(float v, float lane0_value)
 { // lane l <- lane l-1 (v_mov_b32_dpp wave_shr:1); lane 0 keeps lane0_value
@@ -50,6 +69,20 @@ __device__ __forceinline__ float dpp_from_upper_lane(float v, float lane63_value
 { // lane l <- lane l+1 (wave_shl:1); lane 63 keeps lane63_value
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane63_value), __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
+
+#ifdef PDEIP_EXACT_STAMPS // diagnostic build only (tools/): phase stamps of one tile, never in the product
+__device__ unsigned long long g_exact_stamps[64];
+#define EX_STAMP(n)                                                                                   \
+    do {                                                                                              \
+        if (stamp_tile) {                                                                             \
+            unsigned long long t_;                                                                    \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            if (lane == 0) g_exact_stamps[n] = t_;                                                    \
+        }                                                                                             \
+    } while (0)
+#else
+#define EX_STAMP(n)
+#endif
 
 template <class Mdl> struct ExactLayout {
     static constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NF = NIT + NRO, NCF = Mdl::NCF, NP = NF + NCF;
@@ -75,6 +108,10 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
     const int a = m - 2 * b - 3 * t;
     if (a < 0 || a >= A) return;
     const size_t fo = (size_t)blockIdx.y * frame_stride;
+#ifdef PDEIP_EXACT_STAMPS
+    const bool stamp_tile = (a == 10 && b == 10 && t == 0);
+#endif
+    EX_STAMP(0);
 
     // planes in staging order: iterate fields, read-only neighbour fields, coefficients
     const float *pl[NP];
@@ -100,14 +137,16 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
     const int i0 = i00 - lane;                    // row of this lane at step 0
     auto crow = [&](int i) { return i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i); };
 
-    // loader geometry: instruction g covers columns 16g..16g+15; this lane takes 4 consecutive rows
+    // loader geometry: instruction g covers columns 16g..16g+15 x 16 rows; this lane takes 4 consecutive
+    // rows (quad lrq) of column 16g+lcol.  Four consecutive lanes cover one column's 64 contiguous bytes,
+    // which costs the texture path fewer cache-line accesses per instruction than lane -> column
+    // (measured 6.1k vs 7.0k cycles per chunk fetch); the LDS stash is issue-bound either way.
     const int lcol = lane >> 2, lrq = lane & 3;
 
     // ---- chunk fetch: global -> registers (coalesced), registers -> LDS ------------------------
     f4u pre[NP][4], epre[NF];
-    auto fetch = [&](int k) {
-        // wave-uniform: every row any lane touches in this chunk lies inside the buffer
-        const bool inside = (i00 - 63 + EX_CH * k >= 0) && (i00 + EX_CH * k + EX_CH <= nrows - 1);
+    auto fetch_rows = [&](int k, auto inside_tag) {
+        constexpr bool INSIDE = decltype(inside_tag)::value;
 #pragma unroll
         for (int p = 0; p < NP; p++) {
 #pragma unroll
@@ -118,8 +157,8 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
                 // centre rows for coefficients, south rows (one further) for the neighbour fields
                 const int row = i00 - col + EX_CH * k + (p < NF ? 1 : 0) + 4 * lrq;
                 const float *src = pl[p] + (size_t)jj * nrows;
-                if (inside) {
-                    pre[p][g] = *reinterpret_cast<const f4u *>(src + row);
+                if (INSIDE) {
+                    pre[p][g].load(src + row);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; e++) pre[p][g].v[e] = src[crow(row + e)];
@@ -127,20 +166,28 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
             }
         }
         // edge columns: lanes 0-3 fetch the west column of lane 0 (centre rows of lane 0), lanes 4-7 the
-        // east column of lane 63 (centre rows of lane 63); the other lanes repeat them (same addresses)
+        // east column of lane 63 (centre rows of lane 63); the other lanes repeat them (same addresses).
+        // Always element-wise with clamped rows: column 0 / ncols-1 sit at the ends of the buffer.
         const int which = (lane >> 2) & 1;
         const int ecol = which ? (jbase + 64 < ncols - 1 ? jbase + 64 : ncols - 1) : jbase - 1;
-        const int erow = (which ? i00 - 63 : i00) + EX_CH * k + 4 * lrq;
+        const int erow = (which ? i00 - 63 : i00) + EX_CH * k + 4 * (lane & 3);
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             const float *src = pl[f] + (size_t)ecol * nrows;
-            if (inside) {
-                epre[f] = *reinterpret_cast<const f4u *>(src + erow);
-            } else {
 #pragma unroll
-                for (int e = 0; e < 4; e++) epre[f].v[e] = src[crow(erow + e)];
-            }
+            for (int e = 0; e < 4; e++) epre[f].v[e] = src[crow(erow + e)];
         }
+    };
+    auto fetch = [&](int k) {
+        // The planes are column-major and contiguous, and every staged column is >= 1, so a row index
+        // below 0 or above nrows-1 simply lands in the neighbouring column: a valid address whose value is
+        // never used (those rows belong to steps that relax nothing).  The 16-byte path is therefore
+        // safe everywhere except where it could run past the END of the buffer: the bottom chunks of the
+        // strip that holds column ncols-1.  Only those take the element-wise, row-clamped path.
+        const bool last_strip = jbase + 63 >= ncols - 1;
+        const bool overflow = i00 + EX_CH * k + EX_CH > nrows - 1;
+        if (!(last_strip && overflow)) fetch_rows(k, std::true_type{});
+        else fetch_rows(k, std::false_type{});
     };
     auto stash = [&]() {
 #pragma unroll
@@ -155,7 +202,7 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
             const int which = (lane >> 2) & 1;
 #pragma unroll
             for (int f = 0; f < NF; f++)
-                *reinterpret_cast<float4 *>(&edge[(which * NF + f) * EX_CH + 4 * lrq]) =
+                *reinterpret_cast<float4 *>(&edge[(which * NF + f) * EX_CH + 4 * (lane & 3)]) =
                     make_float4(epre[f].v[0], epre[f].v[1], epre[f].v[2], epre[f].v[3]);
         }
     };
@@ -172,16 +219,23 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
     }
 #pragma unroll
     for (int f = 0; f < NRO1; f++) {
-        rcen[f] = (NRO > 0) ? pl[NIT + (NRO > 0 ? f : 0)][cb + crow(i0)] : 0.0f;
-        rnorth[f] = (NRO > 0) ? pl[NIT + (NRO > 0 ? f : 0)][cb + crow(i0 - 1)] : 0.0f;
+        rcen[f] = (NRO > 0) ? pl[(NRO > 0 ? NIT + f : 0)][cb + crow(i0)] : 0.0f;
+        rnorth[f] = (NRO > 0) ? pl[(NRO > 0 ? NIT + f : 0)][cb + crow(i0 - 1)] : 0.0f;
     }
 
     fetch(0);
+    EX_STAMP(1);
     stash();
+    EX_STAMP(2);
 
     for (int k = 0; k < NCHUNK; k++) {
         if (k + 1 < NCHUNK) fetch(k + 1); // in flight while this chunk is relaxed
+        EX_STAMP(3 + 4 * k);
 
+        // INTERIOR chunk: every lane relaxes an interior pixel at every step and none of them touches the
+        // image border, so the activity masks and border substitutions below fold away (most chunks).
+        auto relax_chunk = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
         for (int mq = 0; mq < EX_CH / 4; mq++) {
             float4 ck[NCF], s4[NF], e4[NF], res[NIT];
@@ -196,8 +250,8 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
             for (int x = 0; x < 4; x++) {
                 const int q = EX_CH * k + 4 * mq + x;
                 const int i = i0 + q;
-                const bool row_ok = (i >= 1) && (i <= nrows - 2);
-                const bool active = col_ok && row_ok;
+                const bool row_ok = INTERIOR || ((i >= 1) && (i <= nrows - 2));
+                const bool active = INTERIOR || (col_ok && row_ok);
                 auto el = [&](const float4 &v) { return x == 0 ? v.x : (x == 1 ? v.y : (x == 2 ? v.z : v.w)); };
 
                 float c[NIT], w[NIT], e[NIT], n[NIT], s[NIT], kk[NCF];
@@ -211,20 +265,20 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
                     float wnew = dpp_from_lower_lane(prev[f], el(e4[f]));
                     if (q == 0 && lane != 0) wnew = west0[f];
                     float nv = (q == 0) ? north0[f] : prev[f];
-                    if (i == 1) nv = first_sweep ? topb[f] : cen[f];
+                    if (!INTERIOR && i == 1) nv = first_sweep ? topb[f] : cen[f];
                     c[f] = cen[f];
                     n[f] = nv;
-                    s[f] = (i + 1 == nrows - 1 && !first_sweep) ? cen[f] : sraw;
-                    e[f] = (j + 1 == ncols - 1 && !first_sweep) ? cen[f] : eraw;
-                    w[f] = (j - 1 == 0 && !first_sweep) ? cen[f] : wnew;
+                    s[f] = (!INTERIOR && i + 1 == nrows - 1 && !first_sweep) ? cen[f] : sraw;
+                    e[f] = (!INTERIOR && j + 1 == ncols - 1 && !first_sweep) ? cen[f] : eraw;
+                    w[f] = (!INTERIOR && j - 1 == 0 && !first_sweep) ? cen[f] : wnew;
                     cen[f] = sraw; // next step's centre
                 }
 #pragma unroll
                 for (int f = 0; f < NRO1; f++) {
                     if (NRO > 0) {
-                        rsouth[f] = el(s4[NIT + (NRO > 0 ? f : 0)]);
-                        reast[f] = dpp_from_upper_lane(rsouth[f], el(e4[NIT + (NRO > 0 ? f : 0)]));
-                        rwest[f] = dpp_from_lower_lane(rnorth[f], el(e4[NIT + (NRO > 0 ? f : 0)])); // lane l-1's north is (i, j-1)
+                        rsouth[f] = el(s4[(NRO > 0 ? NIT + f : 0)]);
+                        reast[f] = dpp_from_upper_lane(rsouth[f], el(e4[(NRO > 0 ? NIT + f : 0)]));
+                        rwest[f] = dpp_from_lower_lane(rnorth[f], el(e4[(NRO > 0 ? NIT + f : 0)])); // lane l-1's north is (i, j-1)
                     } else {
                         rsouth[f] = reast[f] = rwest[f] = 0.0f;
                     }
@@ -247,7 +301,15 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
 #pragma unroll
             for (int f = 0; f < NIT; f++) *reinterpret_cast<float4 *>(&outb[(f * 64 + lane) * EX_STR + 4 * mq]) = res[f];
         }
+        };
+        {
+            const int lo_row = i00 - 63 + EX_CH * k, hi_row = i00 + EX_CH * k + EX_CH - 1;
+            const bool interior = (lo_row >= 2) && (hi_row <= nrows - 3) && (jbase >= 2) && (jbase + 63 <= ncols - 3);
+            if (interior) relax_chunk(std::true_type{});
+            else relax_chunk(std::false_type{});
+        }
 
+        EX_STAMP(4 + 4 * k);
         // ---- relaxed chunk: LDS -> global, coalesced; only interior pixels are written -----------------
         {
             const int lo_row = i00 - 63 + EX_CH * k, hi_row = i00 + EX_CH * k + EX_CH - 1;
@@ -264,7 +326,7 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
                     if (all_valid) {
                         f4u o;
                         o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
-                        *reinterpret_cast<f4u *>(dst + row) = o;
+                        o.store(dst + row);
                     } else if (jj <= ncols - 2) {
                         if (row >= 1 && row <= nrows - 2) dst[row] = v.x;
                         if (row + 1 >= 1 && row + 1 <= nrows - 2) dst[row + 1] = v.y;
@@ -273,7 +335,9 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
                     }
                 }
         }
+        EX_STAMP(5 + 4 * k);
         if (k + 1 < NCHUNK) stash(); // all reads of this chunk are done (one wave, in-order LDS)
+        EX_STAMP(6 + 4 * k);
     }
 }
 
