@@ -1,0 +1,24 @@
+/* Mock of the few MEX API declarations the drop-in stubs in pde-based-image-processing_amd/mex/ use.
+ * TEST SCAFFOLDING for this repository's own stubs (there is no MATLAB in the image); it is not used to
+ * build anything of the reference. */
+#ifndef PDEIP_MOCK_MEX_H
+#define PDEIP_MOCK_MEX_H
+#include <stdbool.h>
+#include <stddef.h>
+
+typedef size_t mwSize;
+typedef struct mxArray_tag mxArray;
+typedef enum { mxDOUBLE_CLASS = 6, mxSINGLE_CLASS = 7 } mxClassID;
+typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
+
+bool mxIsSingle(const mxArray *a);
+bool mxIsComplex(const mxArray *a);
+void *mxGetData(const mxArray *a);
+size_t mxGetNumberOfElements(const mxArray *a);
+const mwSize *mxGetDimensions(const mxArray *a);
+mwSize mxGetNumberOfDimensions(const mxArray *a);
+mxArray *mxCreateNumericArray(mwSize ndim, const mwSize *dims, mxClassID classid, mxComplexity flag);
+void mexErrMsgTxt(const char *msg); /* does not return */
+
+void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]);
+#endif
