@@ -177,7 +177,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         }
         SweepTimer timer(s);
         for (int m = 0; m <= last_m; m++) {
-            hipLaunchKernelGGL(k_sor_exact<Mdl>, grid, dim3(64), lds, s, P, nrows, ncols, A, B, iter, m, omega, n);
+            hipLaunchKernelGGL(k_sor_exact<Mdl>, grid, dim3(128), lds, s, P, nrows, ncols, A, B, iter, m, omega, n);
             g.last_launches++;
         }
         timer.stop(last_m + 1);

@@ -87,29 +87,39 @@ __device__ unsigned long long g_exact_stamps[64];
 template <class Mdl> struct ExactLayout {
     static constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NF = NIT + NRO, NCF = Mdl::NCF, NP = NF + NCF;
     static constexpr int STAGE = NP * 64 * EX_STR;  // chunk of every plane
-    static constexpr int OUTB = NIT * 64 * EX_STR;  // relaxed values of the chunk
     static constexpr int EDGE = 2 * NF * EX_CH;     // west column of lane 0, east column of lane 63
-    static constexpr size_t LDS_BYTES = (size_t)(STAGE + OUTB + EDGE) * sizeof(float);
+    static constexpr int BUF = STAGE + EDGE;        // one chunk buffer; two of them (double buffering)
+    static constexpr int OUTB = NIT * 64 * EX_STR;  // relaxed values of one chunk; two of them as well
+    static constexpr size_t LDS_BYTES = (size_t)(2 * BUF + 2 * OUTB) * sizeof(float);
 };
 
+// Workgroup barrier that does NOT drain outstanding global loads (a __syncthreads() would add
+// s_waitcnt vmcnt(0) and stall the loader's prefetch): LDS traffic only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One workgroup = one tile = two waves.  Wave 1 (the mover) streams the tile's chunks global ->
+// registers -> LDS (double-buffered, loads of chunk k+2 in flight while chunk k is relaxed) and writes
+// the relaxed chunk k-1 back LDS -> global; wave 0 only relaxes.
 template <class Mdl>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(128)
 k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m, float omega,
             size_t frame_stride)
 {
     using L = ExactLayout<Mdl>;
     constexpr int NIT = L::NIT, NRO = L::NRO, NRO1 = at_least_one<NRO>::value, NF = L::NF, NCF = L::NCF, NP = L::NP;
     constexpr int NCHUNK = EX_R / EX_CH;
+    static_assert(NCHUNK == 4, "the loader/compute schedule below is written for four chunks");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *stage = smem, *outb = smem + L::STAGE, *edge = outb + L::OUTB;
+    float *outb_base = smem + 2 * L::BUF;
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool loader = (threadIdx.x >> 6) == 1; // wave-uniform
     const int b = blockIdx.x % B, t = blockIdx.x / B;
     const int a = m - 2 * b - 3 * t;
-    if (a < 0 || a >= A) return;
+    if (a < 0 || a >= A) return; // both waves leave together
     const size_t fo = (size_t)blockIdx.y * frame_stride;
 #ifdef PDEIP_EXACT_STAMPS
-    const bool stamp_tile = (a == 10 && b == 10 && t == 0);
+    const bool stamp_tile = (a == 10 && b == 10 && t == 0) && !loader;
 #endif
     EX_STAMP(0);
 
@@ -127,85 +137,158 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
     for (int f = 0; f < NCF; f++) pl[NF + f] = P.cf[f] + fo;
 
     const int jbase = 1 + 64 * b;                 // column of lane 0
+    const int i00 = 1 + a * EX_R;                 // row of lane 0 at step 0
+    auto crow = [&](int i) { return i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i); };
+    // loader/storer geometry: instruction g covers columns 16g..16g+15 x 16 rows; this lane takes 4
+    // consecutive rows (quad lrq) of column 16g+lcol: four consecutive lanes cover one column's 64
+    // contiguous bytes (fewer cache-line accesses per instruction than lane -> column; measured).
+    const int lcol = lane >> 2, lrq = lane & 3;
+
+    if (loader) {
+        // ================================ loader wave ==========================================
+        f4u preA[NP][4], preB[(NP <= 11) ? NP : 1][4], epreA[NF], epreB[NF];
+        auto fetch_rows = [&](int k, f4u (&pre)[NP][4], f4u (&epre)[NF], auto inside_tag) __attribute__((always_inline)) {
+            constexpr bool INSIDE = decltype(inside_tag)::value;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = 16 * g + lcol;
+                    int jj = jbase + col;
+                    jj = jj < ncols - 1 ? jj : ncols - 1;
+                    // centre rows for coefficients, south rows (one further) for the neighbour fields
+                    const int row = i00 - col + EX_CH * k + (p < NF ? 1 : 0) + 4 * lrq;
+                    const float *src = pl[p] + (size_t)jj * nrows;
+                    if (INSIDE) {
+                        pre[p][g].load(src + row);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) pre[p][g].v[e] = src[crow(row + e)];
+                    }
+                }
+            }
+            // edge columns: lanes 0-3 fetch the west column of lane 0 (centre rows of lane 0), lanes 4-7 the
+            // east column of lane 63 (centre rows of lane 63); the other lanes repeat them (same addresses).
+            // Always element-wise with clamped rows: column 0 / ncols-1 sit at the ends of the buffer.
+            const int which = (lane >> 2) & 1;
+            const int ecol = which ? (jbase + 64 < ncols - 1 ? jbase + 64 : ncols - 1) : jbase - 1;
+            const int erow = (which ? i00 - 63 : i00) + EX_CH * k + 4 * (lane & 3);
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                const float *src = pl[f] + (size_t)ecol * nrows;
+#pragma unroll
+                for (int e = 0; e < 4; e++) epre[f].v[e] = src[crow(erow + e)];
+            }
+        };
+        // The planes are column-major and contiguous and every staged column is >= 1, so a row index
+        // below 0 or above nrows-1 lands in a neighbouring column: a valid address whose value is never
+        // used (those rows belong to steps that relax nothing) -- as long as the access stays inside the
+        // plane.  The flat index grows with the column, so the last staged column of the last chunk
+        // bounds it.  Decided once per tile, so each path has a fixed number of loads in flight and the
+        // compiler's wait counts stay exact (a per-chunk branch made it drain everything).
+        const int jmax = jbase + 63 < ncols - 1 ? jbase + 63 : ncols - 1;
+        const bool tile_inside = (long)jmax * nrows + (i00 + EX_R + 4) < (long)nrows * ncols;
+        auto stash = [&](const f4u (&pre)[NP][4], const f4u (&epre)[NF], int buf) __attribute__((always_inline)) {
+            float *stage = smem + buf * L::BUF, *edge = stage + L::STAGE;
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = 16 * g + lcol;
+                    *reinterpret_cast<float4 *>(&stage[(p * 64 + col) * EX_STR + 4 * lrq]) =
+                        make_float4(pre[p][g].v[0], pre[p][g].v[1], pre[p][g].v[2], pre[p][g].v[3]);
+                }
+            if (lane < 8) {
+                const int which = (lane >> 2) & 1;
+#pragma unroll
+                for (int f = 0; f < NF; f++)
+                    *reinterpret_cast<float4 *>(&edge[(which * NF + f) * EX_CH + 4 * (lane & 3)]) =
+                        make_float4(epre[f].v[0], epre[f].v[1], epre[f].v[2], epre[f].v[3]);
+            }
+        };
+        // relaxed chunk k: LDS -> global, coalesced; only interior pixels are written
+        auto store_out = [&](int k) __attribute__((always_inline)) {
+            const float *outb = outb_base + (k & 1) * L::OUTB;
+            const int lo_row = i00 - 63 + EX_CH * k, hi_row = i00 + EX_CH * k + EX_CH - 1;
+            const bool all_valid = (lo_row >= 1) && (hi_row <= nrows - 2) && (jbase + 63 <= ncols - 2);
+#pragma unroll
+            for (int f = 0; f < NIT; f++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = 16 * g + lcol;
+                    const int jj = jbase + col;
+                    const int row = i00 - col + EX_CH * k + 4 * lrq;
+                    const float4 v = *reinterpret_cast<const float4 *>(&outb[(f * 64 + col) * EX_STR + 4 * lrq]);
+                    float *dst = it[f] + (size_t)(jj < ncols - 1 ? jj : ncols - 1) * nrows;
+                    if (all_valid) {
+                        f4u o;
+                        o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
+                        o.store(dst + row);
+                    } else if (jj <= ncols - 2) {
+                        if (row >= 1 && row <= nrows - 2) dst[row] = v.x;
+                        if (row + 1 >= 1 && row + 1 <= nrows - 2) dst[row + 1] = v.y;
+                        if (row + 2 >= 1 && row + 2 <= nrows - 2) dst[row + 2] = v.z;
+                        if (row + 3 >= 1 && row + 3 <= nrows - 2) dst[row + 3] = v.w;
+                    }
+                }
+        };
+        // schedule: chunk c is loaded two barriers before it is relaxed, stashed one barrier before, and
+        // written back one barrier after
+        // Two register sets (chunk k+2 in flight while chunk k+1 is stashed) when they fit the 512-register
+        // file; the 13-plane late-linearization model runs with one set (one chunk of look-ahead).
+        constexpr bool TWO_SETS = (NP <= 11);
+        auto run = [&](auto inside_tag) __attribute__((always_inline)) {
+            if constexpr (TWO_SETS) {
+                fetch_rows(0, preA, epreA, inside_tag);
+                stash(preA, epreA, 0);
+                fetch_rows(1, preB, epreB, inside_tag);
+                lds_barrier(); // #0: buffer 0 holds chunk 0
+                fetch_rows(2, preA, epreA, inside_tag);
+                stash(preB, epreB, 1);
+                lds_barrier(); // #1: buffer 1 holds chunk 1; chunk 0 has been relaxed
+                fetch_rows(3, preB, epreB, inside_tag);
+                stash(preA, epreA, 0);
+                store_out(0);
+                lds_barrier(); // #2
+                stash(preB, epreB, 1);
+                store_out(1);
+                lds_barrier(); // #3
+                store_out(2);
+                lds_barrier(); // #4
+                store_out(3);
+            } else {
+                fetch_rows(0, preA, epreA, inside_tag);
+                stash(preA, epreA, 0);
+                fetch_rows(1, preA, epreA, inside_tag);
+                lds_barrier(); // #0
+                stash(preA, epreA, 1);
+                fetch_rows(2, preA, epreA, inside_tag);
+                lds_barrier(); // #1
+                store_out(0);
+                stash(preA, epreA, 0);
+                fetch_rows(3, preA, epreA, inside_tag);
+                lds_barrier(); // #2
+                store_out(1);
+                stash(preA, epreA, 1);
+                lds_barrier(); // #3
+                store_out(2);
+                lds_barrier(); // #4
+                store_out(3);
+            }
+        };
+        if (tile_inside) run(std::true_type{});
+        else run(std::false_type{});
+        return;
+    }
+
+    // ================================== compute wave ===========================================
     const int j = jbase + lane;                   // this lane's column
     const bool col_ok = j <= ncols - 2;           // interior column: relaxed
     const int jc = j < ncols - 1 ? j : ncols - 1; // clamped (valid address, value unused)
     const size_t cb = (size_t)jc * nrows;
     const float om1 = 1.0f - omega;
     const bool first_sweep = (t == 0);
-    const int i00 = 1 + a * EX_R;                 // row of lane 0 at step 0
     const int i0 = i00 - lane;                    // row of this lane at step 0
-    auto crow = [&](int i) { return i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i); };
-
-    // loader geometry: instruction g covers columns 16g..16g+15 x 16 rows; this lane takes 4 consecutive
-    // rows (quad lrq) of column 16g+lcol.  Four consecutive lanes cover one column's 64 contiguous bytes,
-    // which costs the texture path fewer cache-line accesses per instruction than lane -> column
-    // (measured 6.1k vs 7.0k cycles per chunk fetch); the LDS stash is issue-bound either way.
-    const int lcol = lane >> 2, lrq = lane & 3;
-
-    // ---- chunk fetch: global -> registers (coalesced), registers -> LDS ------------------------
-    f4u pre[NP][4], epre[NF];
-    auto fetch_rows = [&](int k, auto inside_tag) {
-        constexpr bool INSIDE = decltype(inside_tag)::value;
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int col = 16 * g + lcol;
-                int jj = jbase + col;
-                jj = jj < ncols - 1 ? jj : ncols - 1;
-                // centre rows for coefficients, south rows (one further) for the neighbour fields
-                const int row = i00 - col + EX_CH * k + (p < NF ? 1 : 0) + 4 * lrq;
-                const float *src = pl[p] + (size_t)jj * nrows;
-                if (INSIDE) {
-                    pre[p][g].load(src + row);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) pre[p][g].v[e] = src[crow(row + e)];
-                }
-            }
-        }
-        // edge columns: lanes 0-3 fetch the west column of lane 0 (centre rows of lane 0), lanes 4-7 the
-        // east column of lane 63 (centre rows of lane 63); the other lanes repeat them (same addresses).
-        // Always element-wise with clamped rows: column 0 / ncols-1 sit at the ends of the buffer.
-        const int which = (lane >> 2) & 1;
-        const int ecol = which ? (jbase + 64 < ncols - 1 ? jbase + 64 : ncols - 1) : jbase - 1;
-        const int erow = (which ? i00 - 63 : i00) + EX_CH * k + 4 * (lane & 3);
-#pragma unroll
-        for (int f = 0; f < NF; f++) {
-            const float *src = pl[f] + (size_t)ecol * nrows;
-#pragma unroll
-            for (int e = 0; e < 4; e++) epre[f].v[e] = src[crow(erow + e)];
-        }
-    };
-    auto fetch = [&](int k) {
-        // The planes are column-major and contiguous, and every staged column is >= 1, so a row index
-        // below 0 or above nrows-1 simply lands in the neighbouring column: a valid address whose value is
-        // never used (those rows belong to steps that relax nothing).  The 16-byte path is therefore
-        // safe everywhere except where it could run past the END of the buffer: the bottom chunks of the
-        // strip that holds column ncols-1.  Only those take the element-wise, row-clamped path.
-        const bool last_strip = jbase + 63 >= ncols - 1;
-        const bool overflow = i00 + EX_CH * k + EX_CH > nrows - 1;
-        if (!(last_strip && overflow)) fetch_rows(k, std::true_type{});
-        else fetch_rows(k, std::false_type{});
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int p = 0; p < NP; p++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int col = 16 * g + lcol;
-                *reinterpret_cast<float4 *>(&stage[(p * 64 + col) * EX_STR + 4 * lrq]) =
-                    make_float4(pre[p][g].v[0], pre[p][g].v[1], pre[p][g].v[2], pre[p][g].v[3]);
-            }
-        if (lane < 8) {
-            const int which = (lane >> 2) & 1;
-#pragma unroll
-            for (int f = 0; f < NF; f++)
-                *reinterpret_cast<float4 *>(&edge[(which * NF + f) * EX_CH + 4 * (lane & 3)]) =
-                    make_float4(epre[f].v[0], epre[f].v[1], epre[f].v[2], epre[f].v[3]);
-        }
-    };
 
     // ---- per-lane state at step 0 (scattered loads, once per tile) --------------------------------
     float prev[NIT], cen[NIT], north0[NIT], west0[NIT], topb[NIT], rcen[NRO1], rnorth[NRO1];
@@ -222,19 +305,17 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
         rcen[f] = (NRO > 0) ? pl[(NRO > 0 ? NIT + f : 0)][cb + crow(i0)] : 0.0f;
         rnorth[f] = (NRO > 0) ? pl[(NRO > 0 ? NIT + f : 0)][cb + crow(i0 - 1)] : 0.0f;
     }
-
-    fetch(0);
     EX_STAMP(1);
-    stash();
+    lds_barrier(); // #0
     EX_STAMP(2);
 
     for (int k = 0; k < NCHUNK; k++) {
-        if (k + 1 < NCHUNK) fetch(k + 1); // in flight while this chunk is relaxed
+        const float *stage = smem + (k & 1) * L::BUF, *edge = stage + L::STAGE;
+        float *outb = outb_base + (k & 1) * L::OUTB;
         EX_STAMP(3 + 4 * k);
-
         // INTERIOR chunk: every lane relaxes an interior pixel at every step and none of them touches the
         // image border, so the activity masks and border substitutions below fold away (most chunks).
-        auto relax_chunk = [&](auto interior_tag) {
+        auto relax_chunk = [&](auto interior_tag) __attribute__((always_inline)) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
         for (int mq = 0; mq < EX_CH / 4; mq++) {
@@ -308,35 +389,9 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
             if (interior) relax_chunk(std::true_type{});
             else relax_chunk(std::false_type{});
         }
-
         EX_STAMP(4 + 4 * k);
-        // ---- relaxed chunk: LDS -> global, coalesced; only interior pixels are written -----------------
-        {
-            const int lo_row = i00 - 63 + EX_CH * k, hi_row = i00 + EX_CH * k + EX_CH - 1;
-            const bool all_valid = (lo_row >= 1) && (hi_row <= nrows - 2) && (jbase + 63 <= ncols - 2);
-#pragma unroll
-            for (int f = 0; f < NIT; f++)
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int col = 16 * g + lcol;
-                    const int jj = jbase + col;
-                    const int row = i00 - col + EX_CH * k + 4 * lrq;
-                    const float4 v = *reinterpret_cast<const float4 *>(&outb[(f * 64 + col) * EX_STR + 4 * lrq]);
-                    float *dst = it[f] + (size_t)(jj < ncols - 1 ? jj : ncols - 1) * nrows;
-                    if (all_valid) {
-                        f4u o;
-                        o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
-                        o.store(dst + row);
-                    } else if (jj <= ncols - 2) {
-                        if (row >= 1 && row <= nrows - 2) dst[row] = v.x;
-                        if (row + 1 >= 1 && row + 1 <= nrows - 2) dst[row + 1] = v.y;
-                        if (row + 2 >= 1 && row + 2 <= nrows - 2) dst[row + 2] = v.z;
-                        if (row + 3 >= 1 && row + 3 <= nrows - 2) dst[row + 3] = v.w;
-                    }
-                }
-        }
         EX_STAMP(5 + 4 * k);
-        if (k + 1 < NCHUNK) stash(); // all reads of this chunk are done (one wave, in-order LDS)
+        lds_barrier(); // #k+1: this buffer may be refilled, the next one is ready
         EX_STAMP(6 + 4 * k);
     }
 }

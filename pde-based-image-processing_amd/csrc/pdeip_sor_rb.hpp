@@ -122,6 +122,171 @@ __device__ __forceinline__ void rb_phase(float (&C)[Mdl::NIT][4], const float (&
     }
 }
 
+struct RbGeom {
+    int r, j0, j1, nrows, ncols, col0;
+    float omega;
+    bool store_lane;
+};
+
+// The column march of one unit.  DIR=+1 walks the owned columns [j0,j1) left to right, DIR=-1 right
+// to left; "previous" below means the column the march just left (c - DIR).  Per step: red update of
+// column c, black update of the previous column, store the previous column.
+template <class Mdl, bool VEC, bool FIRST, int DIR>
+__device__ __forceinline__ void rb_march(const SweepPlanes<Mdl> &P, float *dout0, float *dout1, const RbGeom &gm)
+{
+    constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NRO1 = at_least_one<NRO>::value, NCF = Mdl::NCF;
+    const int r = gm.r, j0 = gm.j0, j1 = gm.j1, nrows = gm.nrows, ncols = gm.ncols;
+    const float omega = gm.omega, om1 = 1.0f - gm.omega;
+
+    // register windows, in march order: prev-prev, prev, current, next
+    float Oprev[NIT][4], Oc[NIT][4], Onext[NIT][4];     // old iterate at c-DIR, c, c+DIR
+    float Rpp[NIT][4], Rp[NIT][4];                       // after red, at c-2DIR, c-DIR
+    float ROpp[NRO1][4], ROp[NRO1][4], ROc[NRO1][4], ROnext[NRO1][4];
+    float CFp[NCF][4], CFc[NCF][4];                      // coefficients at c-DIR, c
+
+    int c = (DIR > 0) ? j0 - 1 : j1;
+    const int nsteps = j1 - j0 + 2; // red on both halo columns, black on the owned ones
+#pragma unroll
+    for (int f = 0; f < NIT; f++) {
+        rb_load4<VEC>(Oprev[f], P.it_in[f], c - DIR, r, nrows, ncols);
+        rb_load4<VEC>(Oc[f], P.it_in[f], c, r, nrows, ncols);
+        rb_load4<VEC>(Onext[f], P.it_in[f], c + DIR, r, nrows, ncols);
+#pragma unroll
+        for (int e = 0; e < 4; e++) Rpp[f][e] = Rp[f][e] = 0.0f;
+    }
+#pragma unroll
+    for (int f = 0; f < NRO1; f++) {
+        if (NRO > 0) {
+            rb_load4<VEC>(ROp[f], P.ro[f], c - DIR, r, nrows, ncols);
+            rb_load4<VEC>(ROc[f], P.ro[f], c, r, nrows, ncols);
+            rb_load4<VEC>(ROnext[f], P.ro[f], c + DIR, r, nrows, ncols);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            ROpp[f][e] = 0.0f;
+            if (NRO == 0) ROp[f][e] = ROc[f][e] = ROnext[f][e] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < NCF; f++) {
+        rb_load4<VEC>(CFc[f], P.cf[f], c, r, nrows, ncols);
+#pragma unroll
+        for (int e = 0; e < 4; e++) CFp[f][e] = 0.0f;
+    }
+
+    for (int step = 0; step < nsteps; step++, c += DIR) {
+        // prefetch what the next step needs; consumed after the rotation below
+        float On[NIT][4], ROn[NRO1][4], CFn[NCF][4];
+#pragma unroll
+        for (int f = 0; f < NIT; f++) rb_load4<VEC>(On[f], P.it_in[f], c + 2 * DIR, r, nrows, ncols);
+#pragma unroll
+        for (int f = 0; f < NRO1; f++) {
+            if (NRO > 0) rb_load4<VEC>(ROn[f], P.ro[f], c + 2 * DIR, r, nrows, ncols);
+            else ROn[f][0] = ROn[f][1] = ROn[f][2] = ROn[f][3] = 0.0f;
+        }
+#pragma unroll
+        for (int f = 0; f < NCF; f++) rb_load4<VEC>(CFn[f], P.cf[f], c + DIR, r, nrows, ncols);
+
+        const int p = (c + gm.col0) & 1;
+
+        if (FIRST) { // column c becomes current: build its divisors, keep them for the later sweeps
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float k[NCF];
+#pragma unroll
+                for (int f = 0; f < NCF; f++) k[f] = CFc[f][e];
+                Mdl::derive(k);
+                CFc[Mdl::D0][e] = k[Mdl::D0];
+                CFc[Mdl::D1][e] = k[Mdl::D1];
+            }
+            if (gm.store_lane && c >= j0 && c < j1) {
+                rb_store4<VEC>(CFc[Mdl::D0], dout0, c, r, nrows);
+                rb_store4<VEC>(CFc[Mdl::D1], dout1, c, r, nrows);
+            }
+        }
+
+        // red half-sweep on column c from the old columns on both sides (west = c-1, east = c+1)
+        float Rc[NIT][4];
+#pragma unroll
+        for (int f = 0; f < NIT; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) Rc[f][e] = Oc[f][e];
+        if (c >= 1 && c <= ncols - 2) {
+            if (DIR > 0) {
+                if (p == 0) rb_phase<Mdl, 0>(Rc, Oprev, Onext, ROc, ROp, ROnext, CFc, r, nrows, omega, om1);
+                else        rb_phase<Mdl, 1>(Rc, Oprev, Onext, ROc, ROp, ROnext, CFc, r, nrows, omega, om1);
+            } else {
+                if (p == 0) rb_phase<Mdl, 0>(Rc, Onext, Oprev, ROc, ROnext, ROp, CFc, r, nrows, omega, om1);
+                else        rb_phase<Mdl, 1>(Rc, Onext, Oprev, ROc, ROnext, ROp, CFc, r, nrows, omega, om1);
+            }
+        }
+
+        // black half-sweep on the previous column cb = c-DIR from R(cb-1), R(cb), R(cb+1); then store it.
+        // The red pixels of cb are elements {1-p, 3-p}, so its black ones are {p, p+2}: the same
+        // element set as the red update of column c above.
+        const int cb = c - DIR;
+        if (cb >= j0 && cb < j1 && cb >= 1 && cb <= ncols - 2) {
+            float F[NIT][4];
+#pragma unroll
+            for (int f = 0; f < NIT; f++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) F[f][e] = Rp[f][e];
+            if (DIR > 0) {
+                if (p == 0) rb_phase<Mdl, 0>(F, Rpp, Rc, ROp, ROpp, ROc, CFp, r, nrows, omega, om1);
+                else        rb_phase<Mdl, 1>(F, Rpp, Rc, ROp, ROpp, ROc, CFp, r, nrows, omega, om1);
+            } else {
+                if (p == 0) rb_phase<Mdl, 0>(F, Rc, Rpp, ROp, ROc, ROpp, CFp, r, nrows, omega, om1);
+                else        rb_phase<Mdl, 1>(F, Rc, Rpp, ROp, ROc, ROpp, CFp, r, nrows, omega, om1);
+            }
+            // replicate into the border rows 0 and nrows-1 (rows first, opticalflowSolvers.c:161-170)
+#pragma unroll
+            for (int f = 0; f < NIT; f++) {
+                const float prev3 = VEC ? 0.0f : __shfl_up(F[f][3], 1);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int i = r + e;
+                    if (i == 0) F[f][e] = F[f][e == 3 ? 3 : e + 1];
+                    if (i == nrows - 1) F[f][e] = (e == 0) ? prev3 : F[f][e == 0 ? 0 : e - 1];
+                }
+                if (gm.store_lane) {
+                    rb_store4<VEC>(F[f], P.it_out[f], cb, r, nrows);
+                    // then columns (:172-179): column 0 copies column 1, the last copies ncols-2
+                    if (cb == 1) rb_store4<VEC>(F[f], P.it_out[f], 0, r, nrows);
+                    if (cb == ncols - 2) rb_store4<VEC>(F[f], P.it_out[f], ncols - 1, r, nrows);
+                }
+            }
+        }
+
+        // rotate the windows
+#pragma unroll
+        for (int f = 0; f < NIT; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                Rpp[f][e] = Rp[f][e];
+                Rp[f][e] = Rc[f][e];
+                Oprev[f][e] = Oc[f][e];
+                Oc[f][e] = Onext[f][e];
+                Onext[f][e] = On[f][e];
+            }
+#pragma unroll
+        for (int f = 0; f < NRO1; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                ROpp[f][e] = ROp[f][e];
+                ROp[f][e] = ROc[f][e];
+                ROc[f][e] = ROnext[f][e];
+                ROnext[f][e] = ROn[f][e];
+            }
+#pragma unroll
+        for (int f = 0; f < NCF; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                CFp[f][e] = CFc[f][e];
+                CFc[f][e] = CFn[f][e];
+            }
+    }
+}
+
 // FIRST: this is sweep 0 of a call.  The two derived coefficient planes (divisors) do not exist
 // yet: their slots in P.cf point at the raw planes (e.g. Du, Dv), every column is passed through
 // Mdl::derive() as it becomes current, and the owning unit stores the derived planes to
@@ -160,149 +325,24 @@ k_sor_rb(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, i
 #pragma unroll
     for (int f = 0; f < NCF; f++) P.cf[f] += fo;
 
-    const int a = unit % ntiles_r, b = unit / ntiles_r;
-    const int r = a * RB_OWN_ROWS - 4 + 4 * lane;
-    const int j0 = b * TJ;
-    const int j1 = (j0 + TJ < ncols) ? j0 + TJ : ncols;
-    const float om1 = 1.0f - omega;
-    const bool store_lane = (lane >= 1) && (lane <= 62);
-
-    // register windows (column index relative to the column c whose red update is due)
-    float Om[NIT][4], Oc[NIT][4], Op[NIT][4];    // old iterate, columns c-1, c, c+1
-    float Rmm[NIT][4], Rm[NIT][4];               // after red, columns c-2, c-1
-    float ROmm[NRO1][4], ROm[NRO1][4], ROc[NRO1][4], ROp[NRO1][4]; // read-only, c-2..c+1
-    float CFm[NCF][4], CFc[NCF][4];              // coefficients, columns c-1, c
-
-    int c = j0 - 1;
-#pragma unroll
-    for (int f = 0; f < NIT; f++) {
-        rb_load4<VEC>(Om[f], P.it_in[f], c - 1, r, nrows, ncols);
-        rb_load4<VEC>(Oc[f], P.it_in[f], c, r, nrows, ncols);
-        rb_load4<VEC>(Op[f], P.it_in[f], c + 1, r, nrows, ncols);
-#pragma unroll
-        for (int e = 0; e < 4; e++) Rmm[f][e] = Rm[f][e] = 0.0f;
-    }
-#pragma unroll
-    for (int f = 0; f < NRO1; f++) {
-        if (NRO > 0) {
-            rb_load4<VEC>(ROm[f], P.ro[f], c - 1, r, nrows, ncols);
-            rb_load4<VEC>(ROc[f], P.ro[f], c, r, nrows, ncols);
-            rb_load4<VEC>(ROp[f], P.ro[f], c + 1, r, nrows, ncols);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            ROmm[f][e] = 0.0f;
-            if (NRO == 0) ROm[f][e] = ROc[f][e] = ROp[f][e] = 0.0f;
-        }
-    }
-#pragma unroll
-    for (int f = 0; f < NCF; f++) {
-        rb_load4<VEC>(CFc[f], P.cf[f], c, r, nrows, ncols);
-#pragma unroll
-        for (int e = 0; e < 4; e++) CFm[f][e] = 0.0f;
-    }
-
-    for (; c <= j1; c++) {
-        // prefetch what the next step needs; consumed after the rotation below
-        float On[NIT][4], ROn[NRO1][4], CFn[NCF][4];
-#pragma unroll
-        for (int f = 0; f < NIT; f++) rb_load4<VEC>(On[f], P.it_in[f], c + 2, r, nrows, ncols);
-#pragma unroll
-        for (int f = 0; f < NRO1; f++) {
-            if (NRO > 0) rb_load4<VEC>(ROn[f], P.ro[f], c + 2, r, nrows, ncols);
-            else ROn[f][0] = ROn[f][1] = ROn[f][2] = ROn[f][3] = 0.0f;
-        }
-#pragma unroll
-        for (int f = 0; f < NCF; f++) rb_load4<VEC>(CFn[f], P.cf[f], c + 1, r, nrows, ncols);
-
-        const int p = (c + col0) & 1;
-
-        if (FIRST) { // column c becomes current: build its divisors, keep them for the later sweeps
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float k[NCF];
-#pragma unroll
-                for (int f = 0; f < NCF; f++) k[f] = CFc[f][e];
-                Mdl::derive(k);
-                CFc[Mdl::D0][e] = k[Mdl::D0];
-                CFc[Mdl::D1][e] = k[Mdl::D1];
-            }
-            if (store_lane && c >= j0 && c < j1) {
-                rb_store4<VEC>(CFc[Mdl::D0], dout0, c, r, nrows);
-                rb_store4<VEC>(CFc[Mdl::D1], dout1, c, r, nrows);
-            }
-        }
-
-        // red half-sweep on column c: R(c) from O(c-1), O(c), O(c+1)
-        float Rc[NIT][4];
-#pragma unroll
-        for (int f = 0; f < NIT; f++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) Rc[f][e] = Oc[f][e];
-        if (c >= 1 && c <= ncols - 2) {
-            if (p == 0) rb_phase<Mdl, 0>(Rc, Om, Op, ROc, ROm, ROp, CFc, r, nrows, omega, om1);
-            else        rb_phase<Mdl, 1>(Rc, Om, Op, ROc, ROm, ROp, CFc, r, nrows, omega, om1);
-        }
-
-        // black half-sweep on column c-1: F(c-1) from R(c-2), R(c-1), R(c); then store it.
-        // The red pixels of column c-1 are elements {1-p, 3-p}, so its black ones are {p, p+2}:
-        // the same element set as the red update of column c above.
-        const int cb = c - 1;
-        if (cb >= j0 && cb >= 1 && cb <= ncols - 2) {
-            float F[NIT][4];
-#pragma unroll
-            for (int f = 0; f < NIT; f++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) F[f][e] = Rm[f][e];
-            if (p == 0) rb_phase<Mdl, 0>(F, Rmm, Rc, ROm, ROmm, ROc, CFm, r, nrows, omega, om1);
-            else        rb_phase<Mdl, 1>(F, Rmm, Rc, ROm, ROmm, ROc, CFm, r, nrows, omega, om1);
-            // replicate into the border rows 0 and nrows-1 (rows first, opticalflowSolvers.c:161-170)
-#pragma unroll
-            for (int f = 0; f < NIT; f++) {
-                const float prev3 = VEC ? 0.0f : __shfl_up(F[f][3], 1);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int i = r + e;
-                    if (i == 0) F[f][e] = F[f][e == 3 ? 3 : e + 1];
-                    if (i == nrows - 1) F[f][e] = (e == 0) ? prev3 : F[f][e == 0 ? 0 : e - 1];
-                }
-                if (store_lane) {
-                    rb_store4<VEC>(F[f], P.it_out[f], cb, r, nrows);
-                    // then columns (:172-179): column 0 copies column 1, the last copies ncols-2
-                    if (cb == 1) rb_store4<VEC>(F[f], P.it_out[f], 0, r, nrows);
-                    if (cb == ncols - 2) rb_store4<VEC>(F[f], P.it_out[f], ncols - 1, r, nrows);
-                }
-            }
-        }
-
-        // rotate the windows
-#pragma unroll
-        for (int f = 0; f < NIT; f++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                Rmm[f][e] = Rm[f][e];
-                Rm[f][e] = Rc[f][e];
-                Om[f][e] = Oc[f][e];
-                Oc[f][e] = Op[f][e];
-                Op[f][e] = On[f][e];
-            }
-#pragma unroll
-        for (int f = 0; f < NRO1; f++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                ROmm[f][e] = ROm[f][e];
-                ROm[f][e] = ROc[f][e];
-                ROc[f][e] = ROp[f][e];
-                ROp[f][e] = ROn[f][e];
-            }
-#pragma unroll
-        for (int f = 0; f < NCF; f++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                CFm[f][e] = CFc[f][e];
-                CFc[f][e] = CFn[f][e];
-            }
-    }
+    // strips fastest: the four waves of a workgroup (and neighbouring workgroups of one XCD) relax
+    // adjacent strips of the same row tile at the same time
+    const int nstrips = nunits / ntiles_r;
+    const int a = unit / nstrips, b = unit % nstrips;
+    RbGeom gm;
+    gm.r = a * RB_OWN_ROWS - 4 + 4 * lane;
+    gm.j0 = b * TJ;
+    gm.j1 = (gm.j0 + TJ < ncols) ? gm.j0 + TJ : ncols;
+    gm.nrows = nrows;
+    gm.ncols = ncols;
+    gm.col0 = col0;
+    gm.omega = omega;
+    gm.store_lane = (lane >= 1) && (lane <= 62);
+    // Alternate the marching direction from strip to strip: strips 2k and 2k+1 finish at their common
+    // boundary together and strips 2k+1 and 2k+2 start at theirs together, so the halo columns both
+    // sides need are touched at about the same time and the second toucher hits L1/L2 instead of HBM.
+    if (b & 1) rb_march<Mdl, VEC, FIRST, -1>(P, dout0, dout1, gm);
+    else rb_march<Mdl, VEC, FIRST, +1>(P, dout0, dout1, gm);
 }
 
 } // namespace pdeip
