@@ -88,6 +88,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("PDEIP_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = 0  # rehearsal: every rank shares GPU 0
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -96,7 +98,11 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("PDEIP_DIST_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("pde-based-image-processing_amd")
     dev = importlib.import_module("pde-based-image-processing_amd.device")
@@ -125,7 +131,7 @@ def main():
         ms, nl = capi.profile_read()
         capi.profile_enable(False)
         if world > 1:
-            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, ms, nl

@@ -437,23 +437,57 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     g.last_launches = 0;
     if (iter <= 0) return PDEIP_OK;
-    const size_t n = (size_t)nrows * ncols;
+    const size_t n = (size_t)nrows * ncols, nf = n * (size_t)nframes;
     float *bt, *inv, *scratch = nullptr;
-    RC(ws_get(WS_AUX0, n * nframes * sizeof(float), &bt));
-    RC(ws_get(WS_AUX1, n * nframes * sizeof(float), &inv));
-    hipLaunchKernelGGL(k_pde8_divisors, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, bt, inv, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, nrows, ncols, n);
-    g.last_launches++;
-    Pde8Planes P{};
-    P.x = X;
-    const float *cf[ModelPde8::NCF] = {bt, inv, wW, wNW, wN, wNE, wE, wSE, wS, wSW};
-    for (int f = 0; f < ModelPde8::NCF; f++) P.cf[f] = cf[f];
-    if (mode == PDEIP_MODE_EXACT_ORDER)
+    RC(ws_get(WS_AUX0, nf * sizeof(float), &bt));
+    RC(ws_get(WS_AUX1, nf * sizeof(float), &inv));
+    if (mode == PDEIP_MODE_EXACT_ORDER) {
+        hipLaunchKernelGGL(k_pde8_divisors, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, bt, inv, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, nrows, ncols, n);
+        g.last_launches++;
+        Pde8Planes P{};
+        P.x = X;
+        const float *cf[ModelPde8::NCF] = {bt, inv, wW, wNW, wN, wNE, wE, wSE, wS, wSW};
+        for (int f = 0; f < ModelPde8::NCF; f++) P.cf[f] = cf[f];
         RC(ws_get(WS_PING, pde8_exact_scratch_floats(nrows, ncols, nframes, iter) * sizeof(float), &scratch));
+        SweepTimer timer(s);
+        const int nl = pde8_run_exact(s, P, scratch, nrows, ncols, nframes, iter, omega);
+        timer.stop(nl);
+        g.last_launches += nl;
+        HIPCHK(hipGetLastError());
+        return PDEIP_OK;
+    }
+    // four-colour: one fused launch per sweep, ping-pong with a scratch copy; sweep 0 builds B_temp/INV_TRACE
+    RC(ws_get(WS_PING, nf * sizeof(float), &scratch));
+    Pde8SweepPlanes P{};
+    const float *cf[ModelPde8::NCF] = {B, TRACE, wW, wNW, wN, wNE, wE, wSE, wS, wSW}; // raw planes in the derived slots
+    bool vec = (nrows % 4 == 0) && aligned16(X) && aligned16(scratch) && aligned16(bt) && aligned16(inv);
+    for (int f = 0; f < ModelPde8::NCF; f++) {
+        P.cf[f] = cf[f];
+        vec = vec && aligned16(cf[f]);
+    }
+    int TJ = g.rb_tj > 0 ? g.rb_tj : env_int("PDEIP_RB_TJ", 12);
+    if (TJ < 2) TJ = 2;
+    const int ntiles_r = (nrows + RB_OWN_ROWS - 1) / RB_OWN_ROWS;
+    const int nunits = ntiles_r * ((ncols + TJ - 1) / TJ);
+    const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);
+    const dim3 block(64 * RB_WAVES_PER_BLOCK);
     SweepTimer timer(s);
-    const int nl = (mode == PDEIP_MODE_EXACT_ORDER) ? pde8_run_exact(s, P, scratch, nrows, ncols, nframes, iter, omega)
-                                                    : pde8_run_colour(s, P, nrows, ncols, nframes, iter, omega, col0);
-    timer.stop(nl);
-    g.last_launches += nl;
+    for (int it = 0; it < iter; it++) {
+        P.x_in = (it & 1) ? scratch : X;
+        P.x_out = (it & 1) ? X : scratch;
+        if (it == 0) {
+            if (vec) hipLaunchKernelGGL((k_pde8_colour<true, true>), grid, block, 0, s, P, bt, inv, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+            else hipLaunchKernelGGL((k_pde8_colour<false, true>), grid, block, 0, s, P, bt, inv, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+            P.cf[ModelPde8::cB] = bt;
+            P.cf[ModelPde8::cInv] = inv;
+        } else if (vec)
+            hipLaunchKernelGGL((k_pde8_colour<true, false>), grid, block, 0, s, P, nullptr, nullptr, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+        else
+            hipLaunchKernelGGL((k_pde8_colour<false, false>), grid, block, 0, s, P, nullptr, nullptr, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+        g.last_launches++;
+    }
+    timer.stop(iter);
+    if (iter & 1) HIPCHK(hipMemcpyAsync(X, scratch, nf * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

@@ -18,6 +18,7 @@
 #pragma once
 #include "pdeip_models.hpp"
 #include "pdeip_sor_exact.hpp"
+#include "pdeip_sor_rb.hpp"
 
 namespace pdeip {
 
@@ -27,46 +28,173 @@ struct Pde8Planes {
 };
 
 // ---------------------------------------------------------------------------------------------
-// four-colour ordering
+// four-colour ordering: one fused launch per sweep (register marching, like pdeip_sor_rb.hpp)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_pde8_colour(Pde8Planes P, int nrows, int ncols, int colour, float omega, int col0, size_t frame_stride)
+// colour = (i&1) | ((j+col0)&1)<<1.  An even column is finished by colours 0 (even rows) and 1 (odd
+// rows), which read only OLD odd columns; an odd column is then finished by colours 2 and 3, which
+// read the FINISHED even columns on both sides.  So the march is the same two-stage pipeline as the
+// red-black kernel: stage 1 on column c (colours 0,1 if c is even), stage 2 on column c-1 (colours 2,3
+// if it is odd), store column c-1.  Lane l holds rows r..r+3 (r a multiple of 4: even rows are
+// elements {0,2}); the 9-point taps at the lane edges come from the adjacent lane by shuffle.  Three
+// rows of vertical and two columns of horizontal halo are recomputed per unit.
+
+// Relax elements {E0, E0+2} of column C using the columns W and E on either side.
+template <int E0>
+__device__ __forceinline__ void p8_phase(float (&C)[4], const float (&W)[4], const float (&E)[4],
+                                         const float (&cf)[ModelPde8::NCF][4], int r, int nrows, float omega, float om1)
 {
-    // thread -> one pixel of this colour: rows i = 1 + (colour&1 ^ 1 ...) handled via parity
-    const int pi = colour & 1, pj = (colour >> 1) & 1;
-    // first interior row with i&1 == pi, first interior column with (j+col0)&1 == pj
-    const int ifirst = (pi == 1) ? 1 : 2;
-    const int jfirst = (((1 + col0) & 1) == pj) ? 1 : 2;
-    const int i = ifirst + 2 * (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int j = jfirst + 2 * (int)blockIdx.y;
-    if (i > nrows - 2 || j > ncols - 2) return;
-    const size_t fo = (size_t)blockIdx.z * frame_stride;
-    float *x = P.x + fo;
-    const size_t pos = (size_t)j * nrows + i, wp = pos - nrows, ep = pos + nrows;
-    float k[ModelPde8::NCF];
+    const float ce = (E0 == 0) ? __shfl_up(C[3], 1) : __shfl_down(C[0], 1);
+    const float we = (E0 == 0) ? __shfl_up(W[3], 1) : __shfl_down(W[0], 1);
+    const float ee = (E0 == 0) ? __shfl_up(E[3], 1) : __shfl_down(E[0], 1);
 #pragma unroll
-    for (int f = 0; f < ModelPde8::NCF; f++) k[f] = P.cf[f][fo + pos];
-    x[pos] = ModelPde8::update(x[pos], x[wp], x[ep], x[pos - 1], x[pos + 1], x[wp - 1], x[ep - 1], x[wp + 1],
-                               x[ep + 1], k, omega, 1.0f - omega);
+    for (int e = E0; e < 4; e += 2) {
+        const int i = r + e;
+        if (i >= 1 && i <= nrows - 2) {
+            const int em = e == 0 ? 0 : e - 1, ep = e == 3 ? 3 : e + 1;
+            const float xN = (e == 0) ? ce : C[em], xS = (e == 3) ? ce : C[ep];
+            const float xNW = (e == 0) ? we : W[em], xSW = (e == 3) ? we : W[ep];
+            const float xNE = (e == 0) ? ee : E[em], xSE = (e == 3) ? ee : E[ep];
+            float k[ModelPde8::NCF];
+#pragma unroll
+            for (int f = 0; f < ModelPde8::NCF; f++) k[f] = cf[f][e];
+            C[e] = ModelPde8::update(C[e], W[e], E[e], xN, xS, xNW, xNE, xSW, xSE, k, omega, om1);
+        }
+    }
 }
 
-inline int pde8_run_colour(hipStream_t s, Pde8Planes P, int nrows, int ncols, int nframes, int iter,
-                           float omega, int col0)
+// pdeSolvers.c:217-237: the slots of B_temp / INV_TRACE hold B / TRACE before this
+__device__ __forceinline__ void p8_derive(float (&k)[ModelPde8::NCF])
 {
-    const size_t n = (size_t)nrows * ncols;
-    const int hi = (nrows + 1) / 2, hj = (ncols + 1) / 2;
-    const dim3 grid((unsigned)((hi + 255) / 256), (unsigned)hj, (unsigned)nframes);
-    const int nb = 2 * ncols + 2 * (nrows - 2);
-    int launches = 0;
-    for (int it = 0; it < iter; it++) {
-        for (int c = 0; c < 4; c++) {
-            hipLaunchKernelGGL(k_pde8_colour, grid, dim3(256), 0, s, P, nrows, ncols, c, omega, col0, n);
-            launches++;
-        }
-        hipLaunchKernelGGL(k_fill_borders, dim3((nb + 255) / 256, nframes, 1), dim3(256), 0, s, P.x, P.x, 1, nrows, ncols, n);
-        launches++;
+    const float tr = k[ModelPde8::cInv];
+    float t = k[ModelPde8::cWE] + k[ModelPde8::cWW];
+    t += k[ModelPde8::cWS] + k[ModelPde8::cWN];
+    t += k[ModelPde8::cWSW] + k[ModelPde8::cWNW];
+    t += k[ModelPde8::cWSE] + k[ModelPde8::cWNE];
+    const bool ok = !is_nan(tr);
+    k[ModelPde8::cInv] = ok ? 1.0f / tr : 1.0f / t;
+    k[ModelPde8::cB] = ok ? k[ModelPde8::cB] : 0.0f;
+}
+
+struct Pde8SweepPlanes {
+    const float *x_in;
+    float *x_out;
+    const float *cf[ModelPde8::NCF];
+};
+
+template <bool VEC, bool FIRST>
+__global__ void __launch_bounds__(64 * RB_WAVES_PER_BLOCK)
+k_pde8_colour(Pde8SweepPlanes P, float *dout0, float *dout1, int nrows, int ncols, int TJ, int ntiles_r,
+              int nunits, float omega, int col0, size_t frame_stride)
+{
+    constexpr int NCF = ModelPde8::NCF;
+    const int lane = threadIdx.x & 63;
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, per = nb >> 3; // XCD-aware unit order (speed only)
+        if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
     }
-    return launches;
+    const int unit = bid * RB_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (unit >= nunits) return;
+    const size_t fo = (size_t)blockIdx.y * frame_stride;
+    P.x_in += fo;
+    P.x_out += fo;
+#pragma unroll
+    for (int f = 0; f < NCF; f++) P.cf[f] += fo;
+    if (FIRST) {
+        dout0 += fo;
+        dout1 += fo;
+    }
+    const int nstrips = nunits / ntiles_r;
+    const int a = unit / nstrips, b = unit % nstrips;
+    const int r = a * RB_OWN_ROWS - 4 + 4 * lane;
+    const int j0 = b * TJ, j1 = (j0 + TJ < ncols) ? j0 + TJ : ncols;
+    const float om1 = 1.0f - omega;
+    const bool store_lane = (lane >= 1) && (lane <= 62);
+
+    float Om[4], Oc[4], Op[4];   // old X at columns c-1, c, c+1
+    float Rmm[4], Rm[4];         // after stage 1, columns c-2, c-1
+    float CFm[NCF][4], CFc[NCF][4];
+    int c = j0 - 1;
+    rb_load4<VEC>(Om, P.x_in, c - 1, r, nrows, ncols);
+    rb_load4<VEC>(Oc, P.x_in, c, r, nrows, ncols);
+    rb_load4<VEC>(Op, P.x_in, c + 1, r, nrows, ncols);
+#pragma unroll
+    for (int e = 0; e < 4; e++) Rmm[e] = Rm[e] = 0.0f;
+#pragma unroll
+    for (int f = 0; f < NCF; f++) {
+        rb_load4<VEC>(CFc[f], P.cf[f], c, r, nrows, ncols);
+#pragma unroll
+        for (int e = 0; e < 4; e++) CFm[f][e] = 0.0f;
+    }
+    for (; c <= j1; c++) {
+        float On[4], CFn[NCF][4];
+        rb_load4<VEC>(On, P.x_in, c + 2, r, nrows, ncols);
+#pragma unroll
+        for (int f = 0; f < NCF; f++) rb_load4<VEC>(CFn[f], P.cf[f], c + 1, r, nrows, ncols);
+
+        if (FIRST) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float k[NCF];
+#pragma unroll
+                for (int f = 0; f < NCF; f++) k[f] = CFc[f][e];
+                p8_derive(k);
+                CFc[ModelPde8::cB][e] = k[ModelPde8::cB];
+                CFc[ModelPde8::cInv][e] = k[ModelPde8::cInv];
+            }
+            if (store_lane && c >= j0 && c < j1) {
+                rb_store4<VEC>(CFc[ModelPde8::cB], dout0, c, r, nrows);
+                rb_store4<VEC>(CFc[ModelPde8::cInv], dout1, c, r, nrows);
+            }
+        }
+        const bool c_even = ((c + col0) & 1) == 0;
+        // stage 1 on column c: colours 0 then 1 (even columns only), from the old columns on both sides
+        float Rc[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) Rc[e] = Oc[e];
+        if (c_even && c >= 1 && c <= ncols - 2) {
+            p8_phase<0>(Rc, Om, Op, CFc, r, nrows, omega, om1);
+            p8_phase<1>(Rc, Om, Op, CFc, r, nrows, omega, om1);
+        }
+        // stage 2 on column c-1: colours 2 then 3 (odd columns only), from the finished even columns
+        const int cb = c - 1;
+        if (cb >= j0 && cb >= 1 && cb <= ncols - 2) {
+            float F[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) F[e] = Rm[e];
+            if (c_even) { // then c-1 is odd
+                p8_phase<0>(F, Rmm, Rc, CFm, r, nrows, omega, om1);
+                p8_phase<1>(F, Rmm, Rc, CFm, r, nrows, omega, om1);
+            }
+            const float prev3 = VEC ? 0.0f : __shfl_up(F[3], 1);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { // border rows replicate (pdeSolvers.c:249-255)
+                const int i = r + e;
+                if (i == 0) F[e] = F[e == 3 ? 3 : e + 1];
+                if (i == nrows - 1) F[e] = (e == 0) ? prev3 : F[e == 0 ? 0 : e - 1];
+            }
+            if (store_lane) {
+                rb_store4<VEC>(F, P.x_out, cb, r, nrows);
+                if (cb == 1) rb_store4<VEC>(F, P.x_out, 0, r, nrows);             // then columns (:256-262)
+                if (cb == ncols - 2) rb_store4<VEC>(F, P.x_out, ncols - 1, r, nrows);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            Rmm[e] = Rm[e];
+            Rm[e] = Rc[e];
+            Om[e] = Oc[e];
+            Oc[e] = Op[e];
+            Op[e] = On[e];
+        }
+#pragma unroll
+        for (int f = 0; f < NCF; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                CFm[f][e] = CFc[f][e];
+                CFc[f][e] = CFn[f][e];
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

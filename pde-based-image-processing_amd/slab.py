@@ -69,18 +69,28 @@ class SlabDomain:
         """Refresh the halo columns of every local 2-D plane in `fields` from the neighbours' owned columns."""
         if self.world == 1:
             return
-        H, ops, keep = self.halo, [], []
+        H, ops, staged = self.halo, [], []
+        # gloo moves host memory only: a rehearsal of the multi-rank path on CUDA tensors over gloo stages
+        # the halo columns through the host (never the case with the nccl/RCCL backend)
+        via_host = fields[0].is_cuda and dist.get_backend(self.group) == "gloo"
+        own0, own1 = self.c0 - self.lo, self.c1 - self.lo
         for t in fields:
-            own0, own1 = self.c0 - self.lo, self.c1 - self.lo
+            pairs = []
             if self.left is not None:
-                ops.append(dist.P2POp(dist.isend, t[own0:own0 + H], self.left, self.group))
-                ops.append(dist.P2POp(dist.irecv, t[own0 - H:own0], self.left, self.group))
+                pairs.append((t[own0:own0 + H], t[own0 - H:own0], self.left))
             if self.right is not None:
-                ops.append(dist.P2POp(dist.isend, t[own1 - H:own1], self.right, self.group))
-                ops.append(dist.P2POp(dist.irecv, t[own1:own1 + H], self.right, self.group))
-            keep.append(t)
+                pairs.append((t[own1 - H:own1], t[own1:own1 + H], self.right))
+            for src, dst, peer in pairs:
+                if via_host:
+                    hsrc, hdst = src.cpu(), torch.empty(dst.shape, dtype=dst.dtype)
+                    staged.append((dst, hdst))
+                    src, dst = hsrc, hdst
+                ops.append(dist.P2POp(dist.isend, src, peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, dst, peer, self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        for dst, hdst in staged:
+            dst.copy_(hdst)
 
     def gather_owned(self, local, dst=0):
         """Rank `dst` gets the assembled [ncols, nrows] plane (others get None)."""
