@@ -211,31 +211,57 @@ inline size_t pde8_exact_scratch_floats(int nrows, int ncols, int nframes, int i
     return pde8_side_stride(nrows, ncols) * (size_t)nframes * (size_t)(iter > 0 ? iter : 1);
 }
 
-__global__ void __launch_bounds__(64)
+struct Pde8Layout {
+    static constexpr int NCF = ModelPde8::NCF;
+    static constexpr int CST = NCF * 64 * EX_STR;  // coefficient chunk: [plane][column][20] (16 rows used)
+    static constexpr int XST = 65 * EX_STR;        // X chunk: 64 own columns + the east edge column, 20 rows each
+    static constexpr int WED = EX_STR;             // west edge column (new values), 20 rows
+    static constexpr int BUF = CST + XST + WED;
+    static constexpr int OUTB = 64 * EX_STR;
+    static constexpr size_t LDS_BYTES = (size_t)(2 * BUF + 2 * OUTB) * sizeof(float);
+};
+
+// One workgroup = one tile (a,b,t) = two waves (mover + compute), four chunks of 16 steps; the same
+// structure as k_sor_exact (pdeip_sor_exact.hpp) with a skew of two rows per lane.  The X chunk of a
+// column holds 20 rows (its 16 centre rows + 4 of look-ahead), so the south tap and the three east
+// taps (the neighbour lane's rows +1,+2,+3) are plain LDS reads of staged sweep t-1 values; the three
+// west taps come from the neighbour lane's last three results through one DPP shift per step.
+// Border cells hold the previous sweep's replicate: in sweeps t>0 the mover substitutes them from the
+// ring side array while staging (tiles that touch the border take an element-wise path), and the
+// compute wave records this sweep's ring.
+__global__ void __launch_bounds__(128)
 k_pde8_exact(Pde8Planes P, float *side, int nrows, int ncols, int A, int B, int T, int m, float omega,
              size_t frame_stride)
 {
-    const int lane = threadIdx.x;
+    using L = Pde8Layout;
+    constexpr int NCF = ModelPde8::NCF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *outb_base = smem + 2 * L::BUF;
+
+    const int lane = threadIdx.x & 63;
+    const bool mover = (threadIdx.x >> 6) == 1;
     const int b = blockIdx.x % B, t = blockIdx.x / B;
     const int a = m - P8_G * b - P8_H * t;
     if (a < 0 || a >= A) return;
     const size_t fo = (size_t)blockIdx.y * frame_stride;
     float *x = P.x + fo;
+    const float *cfp[NCF];
+#pragma unroll
+    for (int f = 0; f < NCF; f++) cfp[f] = P.cf[f] + fo;
     const size_t sstride = pde8_side_stride(nrows, ncols);
     // border ring after sweep t-1 (read) and after sweep t (written): top[ncols] bot[ncols] left[nrows] right[nrows]
     float *ring_w = side + ((size_t)blockIdx.y * T + t) * sstride;
     const float *ring_r = (t > 0) ? ring_w - sstride : nullptr;
 
-    const int j = 1 + 64 * b + lane;
-    const bool col_in = j <= ncols - 1, col_ok = j <= ncols - 2;
-    const size_t cb = (size_t)j * nrows;
-    const float om1 = 1.0f - omega;
-    const int i0 = 1 + a * P8_R - P8_SKEW * lane;
-
-    // value of cell (ii,jj) as the reference's sweep t sees a cell that sweep t has not (yet) relaxed:
-    // border cells hold the replicate of sweep t-1 (the caller's cell in sweep 0)
-    auto old_at = [&](int ii, int jj) -> float {
-        if (ii < 0 || ii > nrows - 1 || jj < 0 || jj > ncols - 1) return 0.0f;
+    const int jbase = 1 + 64 * b;
+    const int i00 = 1 + a * P8_R;
+    auto crow = [&](int i) { return i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i); };
+    auto ccol = [&](int jj) { return jj < 0 ? 0 : (jj > ncols - 1 ? ncols - 1 : jj); };
+    // value of cell (ii,jj) as sweep t sees a cell it has not relaxed: border cells hold the replicate of
+    // sweep t-1 (the caller's cell in sweep 0).  Out-of-image coordinates are clamped (value unused).
+    auto cell = [&](int ii, int jj) __attribute__((always_inline)) -> float {
+        ii = crow(ii);
+        jj = ccol(jj);
         if (ring_r != nullptr) {
             if (ii == 0) return ring_r[jj];
             if (ii == nrows - 1) return ring_r[ncols + jj];
@@ -244,60 +270,224 @@ k_pde8_exact(Pde8Planes P, float *side, int nrows, int ncols, int A, int B, int 
         }
         return x[(size_t)jj * nrows + ii];
     };
-    auto is_border = [&](int ii, int jj) -> bool { return ii <= 0 || ii >= nrows - 1 || jj <= 0 || jj >= ncols - 1; };
+    const int lcol = lane >> 2, lrq = lane & 3;
 
-    // own column look-ahead queue of old values: rows i, i+1, i+2, i+3
-    float o0 = col_in ? old_at(i0, j) : 0.0f, o1 = col_in ? old_at(i0 + 1, j) : 0.0f, o2 = col_in ? old_at(i0 + 2, j) : 0.0f;
-    // west column shift register (new values): rows i-1, i (i+1 is fetched per step)
-    float nw = 0.0f, w = 0.0f, prev = 0.0f;
-    if (col_ok) {
-        nw = old_at(i0 - 1, j - 1); // memory holds sweep-t values there already, or the border rule applies
-        w = old_at(i0, j - 1);
+    if (mover) {
+        // ================================ mover wave ===========================================
+        f4u cA[NCF][4], cB[NCF][4], xA[6], xB[6];
+        // does the tile's X traffic touch border cells (ring substitution, t>0) or could a 16-byte access
+        // leave the plane?  Decided once per tile (static load counts per path).
+        const bool xborder = (i00 - 126 <= 0) || (i00 + P8_R + 4 >= nrows - 1) || (jbase - 1 == 0) || (jbase + 64 >= ncols - 1);
+        const int jmax = jbase + 64 < ncols - 1 ? jbase + 64 : ncols - 1;
+        const bool inside_plane = (long)jmax * nrows + (i00 + P8_R + 8) < (long)nrows * ncols && (jbase - 1) * (long)nrows + i00 - 1 >= 0;
+        const bool xfast = inside_plane && !(t > 0 && xborder);
+        // path 2: everything 16-byte; path 1: coefficients 16-byte, X element-wise with ring substitution
+        // (border tiles of sweeps t>0); path 0: everything element-wise and row-clamped (end of the plane)
+        // replace the border cells among rows row..row+3 of column jj by the previous sweep's ring values
+        auto patch = [&](f4u &v, int row, int jj) __attribute__((always_inline)) {
+            const bool colb = (jj == 0) || (jj == ncols - 1);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int ii = row + e;
+                if (ii >= 0 && ii <= nrows - 1 && jj >= 0 && jj <= ncols - 1 && (colb || ii == 0 || ii == nrows - 1)) v.v[e] = cell(ii, jj);
+            }
+        };
+        auto fetch = [&](int k, f4u (&cpre)[NCF][4], f4u (&xpre)[6], auto path_tag) __attribute__((always_inline)) {
+            constexpr bool CFAST = decltype(path_tag)::value >= 1, FAST = decltype(path_tag)::value >= 2;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 16 * g + lcol;
+                const int jj = ccol(jbase + col);
+                const int row = i00 - P8_SKEW * col + EX_CH * k + 4 * lrq;
+#pragma unroll
+                for (int f = 0; f < NCF; f++) {
+                    const float *src = cfp[f] + (size_t)jj * nrows;
+                    if (CFAST) cpre[f][g].load(src + row);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) cpre[f][g].v[e] = src[crow(row + e)];
+                    }
+                }
+                if (CFAST) {
+                    xpre[g].load(x + (size_t)jj * nrows + row);
+                    if (!FAST) patch(xpre[g], row, jbase + col);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) xpre[g].v[e] = cell(row + e, jbase + col);
+                }
+            }
+            { // fifth quad (rows +16..+19) of every own column: lane -> column
+                const int row = i00 - P8_SKEW * lane + EX_CH * k + 16;
+                if (CFAST) {
+                    xpre[4].load(x + (size_t)ccol(jbase + lane) * nrows + row);
+                    if (!FAST) patch(xpre[4], row, jbase + lane);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) xpre[4].v[e] = cell(row + e, jbase + lane);
+                }
+            }
+            { // lanes 0-4: east edge column (as lane 64); lanes 5-9: west edge column, rows i00-1 ...; others repeat
+                const int w = lane % 10;
+                const bool west = w >= 5;
+                const int jj = west ? jbase - 1 : jbase + 64;
+                const int row = (west ? i00 - 1 + 4 * (w - 5) : i00 - P8_SKEW * 64 + 4 * w) + EX_CH * k;
+                if (CFAST) {
+                    xpre[5].load(x + (size_t)ccol(jj) * nrows + row);
+                    if (!FAST) patch(xpre[5], row, jj);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) xpre[5].v[e] = cell(row + e, jj);
+                }
+            }
+        };
+        auto stash = [&](const f4u (&cpre)[NCF][4], const f4u (&xpre)[6], int buf) __attribute__((always_inline)) {
+            float *cst = smem + buf * L::BUF, *xst = cst + L::CST, *wed = xst + L::XST;
+            auto put = [&](float *dst, const f4u &v) { *reinterpret_cast<float4 *>(dst) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]); };
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 16 * g + lcol;
+#pragma unroll
+                for (int f = 0; f < NCF; f++) put(&cst[(f * 64 + col) * EX_STR + 4 * lrq], cpre[f][g]);
+                put(&xst[col * EX_STR + 4 * lrq], xpre[g]);
+            }
+            put(&xst[lane * EX_STR + 16], xpre[4]);
+            if (lane < 5) put(&xst[64 * EX_STR + 4 * lane], xpre[5]);
+            else if (lane < 10) put(&wed[4 * (lane - 5)], xpre[5]);
+        };
+        auto store_out = [&](int k) __attribute__((always_inline)) {
+            const float *outb = outb_base + (k & 1) * L::OUTB;
+            const int lo_row = i00 - 126 + EX_CH * k, hi_row = i00 + EX_CH * k + EX_CH - 1;
+            const bool all_valid = (lo_row >= 1) && (hi_row <= nrows - 2) && (jbase + 63 <= ncols - 2);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 16 * g + lcol;
+                const int jj = jbase + col;
+                const int row = i00 - P8_SKEW * col + EX_CH * k + 4 * lrq;
+                const float4 v = *reinterpret_cast<const float4 *>(&outb[col * EX_STR + 4 * lrq]);
+                float *dst = x + (size_t)ccol(jj) * nrows;
+                if (all_valid) {
+                    f4u o;
+                    o.v[0] = v.x; o.v[1] = v.y; o.v[2] = v.z; o.v[3] = v.w;
+                    o.store(dst + row);
+                } else if (jj <= ncols - 2) {
+                    if (row >= 1 && row <= nrows - 2) dst[row] = v.x;
+                    if (row + 1 >= 1 && row + 1 <= nrows - 2) dst[row + 1] = v.y;
+                    if (row + 2 >= 1 && row + 2 <= nrows - 2) dst[row + 2] = v.z;
+                    if (row + 3 >= 1 && row + 3 <= nrows - 2) dst[row + 3] = v.w;
+                }
+            }
+        };
+        auto run = [&](auto fast_tag) __attribute__((always_inline)) {
+            fetch(0, cA, xA, fast_tag);
+            stash(cA, xA, 0);
+            fetch(1, cB, xB, fast_tag);
+            lds_barrier(); // #0
+            fetch(2, cA, xA, fast_tag);
+            stash(cB, xB, 1);
+            lds_barrier(); // #1
+            fetch(3, cB, xB, fast_tag);
+            stash(cA, xA, 0);
+            store_out(0);
+            lds_barrier(); // #2
+            stash(cB, xB, 1);
+            store_out(1);
+            lds_barrier(); // #3
+            store_out(2);
+            lds_barrier(); // #4
+            store_out(3);
+        };
+        if (xfast) run(std::integral_constant<int, 2>{});
+        else if (inside_plane) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 0>{});
+        return;
     }
 
-    for (int q = 0; q < P8_R; q++) {
-        const int i = i0 + q;
-        const bool row_ok = (i >= 1) && (i <= nrows - 2);
-        const bool active = col_ok && row_ok;
-        const float o3 = col_in ? old_at(i + 3, j) : 0.0f;
+    // ================================== compute wave ===========================================
+    const int j = jbase + lane;
+    const bool col_ok = j <= ncols - 2;
+    const float om1 = 1.0f - omega;
+    const int i0 = i00 - P8_SKEW * lane;
+    // state at step 0: values relaxed by earlier launches (tile a-1 / strip b-1) or border cells
+    float prev = 0.0f;
+    float n0 = cell(i0 - 1, j), nw = cell(i0 - 1, j - 1), w = cell(i0, j - 1), sw0 = cell(i0 + 1, j - 1);
+    const float topb = cell(0, j), topbW = cell(0, j - 1), botbW = cell(nrows - 1, j - 1);
+    lds_barrier(); // #0
 
-        // east column (old): lane l+1 is two rows higher, its queue rows +1,+2,+3 are my rows i-1,i,i+1
-        float ne = __shfl_down(o1, 1), e = __shfl_down(o2, 1), se = __shfl_down(o3, 1);
-        if (lane == 63) {
-            ne = old_at(i - 1, j + 1);
-            e = old_at(i, j + 1);
-            se = old_at(i + 1, j + 1);
-        }
-        // south-west (new): lane l-1 relaxed (i+1, j-1) one step ago
-        float sw = __shfl_up(prev, 1);
-        if (lane == 0 || q == 0 || is_border(i + 1, j - 1)) sw = col_ok ? old_at(i + 1, j - 1) : 0.0f;
-
-        if (active) {
-            float n = (q == 0 || i == 1) ? old_at(i - 1, j) : prev;
-            float k[ModelPde8::NCF];
+    for (int k = 0; k < P8_R / EX_CH; k++) {
+        const float *cst = smem + (k & 1) * L::BUF, *xst = cst + L::CST, *wed = xst + L::XST;
+        float *outb = outb_base + (k & 1) * L::OUTB;
+        auto relax_chunk = [&](auto interior_tag) __attribute__((always_inline)) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
-            for (int f = 0; f < ModelPde8::NCF; f++) k[f] = P.cf[f][fo + cb + i];
-            const float v = ModelPde8::update(o0, w, e, n, o1, nw, ne, sw, se, k, omega, om1);
-            x[cb + i] = v;
-            prev = v;
-            // border ring after this sweep: nearest-interior replicate (pdeSolvers.c:249-262)
-            float *top = ring_w, *bot = ring_w + ncols, *left = ring_w + 2 * ncols, *right = left + nrows;
-            if (i == 1) {
-                top[j] = v;
-                if (j == 1) { top[0] = v; left[0] = v; }
-                if (j == ncols - 2) { top[ncols - 1] = v; right[0] = v; }
+            for (int mq = 0; mq < EX_CH / 4; mq++) {
+                float4 ck[NCF], res;
+                float xo[8], xe[8], we[8];
+#pragma unroll
+                for (int f = 0; f < NCF; f++) ck[f] = *reinterpret_cast<const float4 *>(&cst[(f * 64 + lane) * EX_STR + 4 * mq]);
+                {
+                    const float4 a0 = *reinterpret_cast<const float4 *>(&xst[lane * EX_STR + 4 * mq]);
+                    const float4 a1 = *reinterpret_cast<const float4 *>(&xst[lane * EX_STR + 4 * mq + 4]);
+                    const float4 b0 = *reinterpret_cast<const float4 *>(&xst[(lane + 1) * EX_STR + 4 * mq]);
+                    const float4 b1 = *reinterpret_cast<const float4 *>(&xst[(lane + 1) * EX_STR + 4 * mq + 4]);
+                    const float4 c0 = *reinterpret_cast<const float4 *>(&wed[4 * mq]);
+                    const float4 c1 = *reinterpret_cast<const float4 *>(&wed[4 * mq + 4]);
+                    xo[0] = a0.x; xo[1] = a0.y; xo[2] = a0.z; xo[3] = a0.w; xo[4] = a1.x; xo[5] = a1.y; xo[6] = a1.z; xo[7] = a1.w;
+                    xe[0] = b0.x; xe[1] = b0.y; xe[2] = b0.z; xe[3] = b0.w; xe[4] = b1.x; xe[5] = b1.y; xe[6] = b1.z; xe[7] = b1.w;
+                    we[0] = c0.x; we[1] = c0.y; we[2] = c0.z; we[3] = c0.w; we[4] = c1.x; we[5] = c1.y; we[6] = c1.z; we[7] = c1.w;
+                }
+#pragma unroll
+                for (int xq = 0; xq < 4; xq++) {
+                    const int q = EX_CH * k + 4 * mq + xq;
+                    const int i = i0 + q;
+                    const bool active = INTERIOR || (col_ok && (i >= 1) && (i <= nrows - 2));
+                    auto el = [&](const float4 &v) { return xq == 0 ? v.x : (xq == 1 ? v.y : (xq == 2 ? v.z : v.w)); };
+                    // south-west (new): lane l-1 relaxed (i+1, j-1) one step ago; lane 0 reads the west edge column
+                    float sw = dpp_from_lower_lane(prev, we[xq + 2]);
+                    if (q == 0) {
+                        if (lane != 0) sw = sw0;
+                        else { nw = we[0]; w = we[1]; }
+                    }
+                    if (!INTERIOR && lane != 0) { // the tap is a border cell of the top/bottom ring
+                        if (i + 1 == 0) sw = topbW;
+                        if (i + 1 == nrows - 1) sw = botbW;
+                    }
+                    float nn = (q == 0) ? n0 : prev;
+                    if (!INTERIOR && i == 1) nn = topb;
+                    float kk[NCF];
+#pragma unroll
+                    for (int f = 0; f < NCF; f++) kk[f] = el(ck[f]);
+                    // update(xc, xW, xE, xN, xS, xNW, xNE, xSW, xSE)
+                    const float v = ModelPde8::update(xo[xq], w, xe[xq + 2], nn, xo[xq + 1], nw, xe[xq + 1], sw, xe[xq + 3], kk, omega, om1);
+                    if (active) prev = v;
+                    if (xq == 0) res.x = v; else if (xq == 1) res.y = v; else if (xq == 2) res.z = v; else res.w = v;
+                    if (!INTERIOR && active) { // border ring after this sweep: nearest-interior replicate (pdeSolvers.c:249-262)
+                        float *top = ring_w, *bot = ring_w + ncols, *left = ring_w + 2 * ncols, *right = left + nrows;
+                        if (i == 1) {
+                            top[j] = v;
+                            if (j == 1) { top[0] = v; left[0] = v; }
+                            if (j == ncols - 2) { top[ncols - 1] = v; right[0] = v; }
+                        }
+                        if (i == nrows - 2) {
+                            bot[j] = v;
+                            if (j == 1) { bot[0] = v; left[nrows - 1] = v; }
+                            if (j == ncols - 2) { bot[ncols - 1] = v; right[nrows - 1] = v; }
+                        }
+                        if (j == 1) left[i] = v;
+                        if (j == ncols - 2) right[i] = v;
+                    }
+                    nw = w;
+                    w = sw;
+                }
+                *reinterpret_cast<float4 *>(&outb[lane * EX_STR + 4 * mq]) = res;
             }
-            if (i == nrows - 2) {
-                bot[j] = v;
-                if (j == 1) { bot[0] = v; left[nrows - 1] = v; }
-                if (j == ncols - 2) { bot[ncols - 1] = v; right[nrows - 1] = v; }
-            }
-            if (j == 1) left[i] = v;
-            if (j == ncols - 2) right[i] = v;
+        };
+        {
+            const int lo_row = i00 - 126 + EX_CH * k, hi_row = i00 + EX_CH * k + EX_CH - 1;
+            const bool interior = (lo_row >= 2) && (hi_row <= nrows - 3) && (jbase >= 2) && (jbase + 63 <= ncols - 3);
+            if (interior) relax_chunk(std::true_type{});
+            else relax_chunk(std::false_type{});
         }
-        // advance one row
-        o0 = o1; o1 = o2; o2 = o3;
-        nw = w; w = sw;
+        lds_barrier(); // #k+1
     }
 }
 
@@ -309,9 +499,15 @@ inline int pde8_run_exact(hipStream_t s, Pde8Planes P, float *side, int nrows, i
     const int B = (ncols - 2 + 63) / 64;
     const int last_m = (A - 1) + P8_G * (B - 1) + P8_H * (iter - 1);
     const dim3 grid((unsigned)(B * iter), (unsigned)nframes);
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pde8_exact), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)Pde8Layout::LDS_BYTES);
+        lds_opt_in = true;
+    }
     int launches = 0;
     for (int m = 0; m <= last_m; m++) {
-        hipLaunchKernelGGL(k_pde8_exact, grid, dim3(64), 0, s, P, side, nrows, ncols, A, B, iter, m, omega, n);
+        hipLaunchKernelGGL(k_pde8_exact, grid, dim3(128), Pde8Layout::LDS_BYTES, s, P, side, nrows, ncols, A, B, iter, m, omega, n);
         launches++;
     }
     const int nb = 2 * ncols + 2 * (nrows - 2);
