@@ -138,6 +138,18 @@ int env_int(const char *name, int dflt)
     return (s && *s) ? atoi(s) : dflt;
 }
 
+// Columns per red-black unit.  Narrow strips mean more waves in flight but more halo re-reads
+// ((TJ+2)/TJ coefficient, (TJ+4)/TJ iterate columns).  12 is the measured optimum at 4K (2880 units)
+// and at 1080p (10-12 equal, 6-8 slower); a strip stride that is a multiple of a large power of two
+// aliases on HBM channels (TJ=16 at nrows=2160 is 15 % slower than 12).  PDEIP_RB_TJ overrides.
+int pick_rb_tj(int nrows, int ncols)
+{
+    (void)nrows;
+    (void)ncols;
+    const int forced = g.rb_tj > 0 ? g.rb_tj : env_int("PDEIP_RB_TJ", 0);
+    return forced > 0 ? (forced < 2 ? 2 : forced) : 12;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sweep drivers (5-point models)
 // ------------------------------------------------------------------------------------------------
@@ -204,8 +216,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     vec = vec && aligned16(aux0) && aligned16(aux1);
     for (int f = 0; f < Mdl::NRO; f++) vec = vec && aligned16(P.ro[f]);
 
-    int TJ = g.rb_tj > 0 ? g.rb_tj : env_int("PDEIP_RB_TJ", 12);
-    if (TJ < 2) TJ = 2;
+    const int TJ = pick_rb_tj(nrows, ncols);
     const int ntiles_r = (nrows + RB_OWN_ROWS - 1) / RB_OWN_ROWS;
     const int nstrips = (ncols + TJ - 1) / TJ;
     const int nunits = ntiles_r * nstrips;
@@ -465,8 +476,7 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
         P.cf[f] = cf[f];
         vec = vec && aligned16(cf[f]);
     }
-    int TJ = g.rb_tj > 0 ? g.rb_tj : env_int("PDEIP_RB_TJ", 12);
-    if (TJ < 2) TJ = 2;
+    const int TJ = pick_rb_tj(nrows, ncols);
     const int ntiles_r = (nrows + RB_OWN_ROWS - 1) / RB_OWN_ROWS;
     const int nunits = ntiles_r * ((ncols + TJ - 1) / TJ);
     const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);

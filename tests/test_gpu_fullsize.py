@@ -1,0 +1,85 @@
+"""GPU parity at the BASELINE.json config sizes (C1..C5 shapes), bit for bit against the oracle, in both
+orderings -- the oracle finishes a few 4K sweeps in seconds, so no size-independent proxy is needed.
+Plus size-independent properties at full size: frames are independent, a second call continues the
+iteration exactly (iter=2 then 2 == iter=4), and the exact order on the GPU equals itself across tilings."""
+import importlib
+
+import numpy as np
+import pytest
+
+import problems as pb
+
+pytestmark = pytest.mark.gpu
+MODES = [(0, 0), (1, 1)]
+
+
+def _check(got, want, what):
+    got = got if isinstance(got, tuple) else (got,)
+    want = want if isinstance(want, tuple) else (want,)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert pb.bit_equal(g, w), "%s output %d: %s" % (what, k, pb.describe_mismatch(g, w))
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+def test_c1_horn_schunck_388x584_iter20(pdeip, oracle, mode, order):
+    pdeip.mex_api.set_mode(mode)
+    p = pb.elin4(701, 388, 584)
+    _check(pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(20), np.float32(1.9), np.float32(1), nargout=4),
+           oracle.Oflow_sor_elin4_2d(*p.values(), 20, 1.9, nargout=4, order=order), "C1 elin4")
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+def test_c2_late_linearization_1080x1920(pdeip, oracle, mode, order):
+    pdeip.mex_api.set_mode(mode)
+    p = pb.llin4(702, 1080, 1920, nan_frac=0.01)
+    _check(pdeip.mex_api.Oflow_sor_llin4_2d(*p.values(), np.float32(4), np.float32(1.9), np.float32(1), nargout=4),
+           oracle.Oflow_sor_llin4_2d(*p.values(), 4, 1.9, nargout=4, order=order), "C2 llin4")
+    w = pb.warp(703, 1080, 1920, nframes=6, special=True)
+    _check(pdeip.mex_api.BilinInterp_2d(w["Iin"], w["X"], w["Y"]), oracle.BilinInterp_2d(w["Iin"], w["X"], w["Y"]), "C2 warp C=6")
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+def test_c3_tv8_2160x3840(pdeip, oracle, mode, order):
+    pdeip.mex_api.set_mode(mode)
+    p = pb.pde8(704, 2160, 3840, nan_frac=0.001)
+    _check(pdeip.mex_api.PDEsolver8(*p.values(), np.float32(4), np.float32(1.75), np.float32(1)),
+           oracle.PDEsolver8(*p.values(), 4, 1.75, order=order), "C3 pde8")
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+def test_c4_elin_fmg_smoother_2160x3840(pdeip, oracle, mode, order):
+    pdeip.mex_api.set_mode(mode)
+    p = pb.elin4(705, 2160, 3840)
+    _check(pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(4), np.float32(1.9), np.float32(1), nargout=4),
+           oracle.Oflow_sor_elin4_2d(*p.values(), 4, 1.9, nargout=4, order=order), "C4 elin4 + residuals")
+    args = [p[k] for k in ("U", "V", "M", "Du", "Dv", "wW", "wN", "wE", "wS")]
+    _check(pdeip.mex_api.Oflow_lhs_elin4_2d(*args), oracle.Oflow_lhs_elin4_2d(*args), "C4 lhs")
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+def test_c5_disparity_1988x2880(pdeip, oracle, mode, order):
+    pdeip.mex_api.set_mode(mode)
+    p = pb.disp4(706, 1988, 2880, nan_frac=0.01)
+    _check(pdeip.mex_api.Disp_sor_llin4_2d(*p.values(), np.float32(4), np.float32(1.9), np.float32(1)),
+           oracle.Disp_sor_llin4_2d(*p.values(), 4, 1.9, order=order), "C5 disp")
+    d = pb.diffweights(707, 1988, 2880)
+    _check(pdeip.mex_api.DdiffWeights(d["D"], np.float32(1e-5)), oracle.DdiffWeights(d["D"], 1e-5), "C5 diffweights")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_properties_at_4k(pdeip, mode):
+    """No oracle: iter=2 twice == iter=4 once (the call is a pure continuation); frames are independent."""
+    pdeip.mex_api.set_mode(mode)
+    api = pdeip.mex_api
+    p = pb.elin4(708, 2160, 3840)
+    coef = [p[k] for k in ("M", "Cu", "Cv", "Du", "Dv", "wW", "wN", "wE", "wS")]
+    one = api.Oflow_sor_elin4_2d(p["U"], p["V"], *coef, np.float32(4), np.float32(1.9), np.float32(1))
+    half = api.Oflow_sor_elin4_2d(p["U"], p["V"], *coef, np.float32(2), np.float32(1.9), np.float32(1))
+    two = api.Oflow_sor_elin4_2d(half[0], half[1], *coef, np.float32(2), np.float32(1.9), np.float32(1))
+    _check(two, one, "iter 2+2 vs 4")
+    q = pb.pde4(709, 1080, 1920, nframes=3)
+    X = api.PDEsolver4(*q.values(), np.float32(3), np.float32(1.75), np.float32(1))
+    for k in range(3):
+        Xk = api.PDEsolver4(*[np.asfortranarray(v[:, :, k]) for v in q.values()], np.float32(3), np.float32(1.75), np.float32(1))
+        assert pb.bit_equal(X[:, :, k], Xk), "frame %d" % k
+    pdeip.mex_api.set_mode(0)
