@@ -163,6 +163,17 @@ int pdeip_diffweights6(const float *D, int nrows, int ncols, int nframes, float 
 int pdeip_warp_bilinear(const float *Iin, const float *X, const float *Y, int nrows, int ncols,
                         int nframes, float *Iout);
 
+/* [Idt,Idx,Idy] = FstDerivatives5(It0,It1)
+ * replaces mex/source/FstDerivatives5.c:50-145 -> fstSimoncelli_c (library/imageDerivatives.c:309).
+ * Every plane is [nrows x ncols x nframes] (frames independent); nrows, ncols >= 4. */
+int pdeip_fst_derivatives5(const float *It0, const float *It1, int nrows, int ncols, int nframes,
+                           float *Idt, float *Idx, float *Idy);
+
+/* [Idxt,Idyt,Idxx,Idyy,Idxy] = SndDerivatives5(It0,It1)
+ * replaces mex/source/SndDerivatives5.c:51-174 -> sndSimoncelli_c (imageDerivatives.c:391). */
+int pdeip_snd_derivatives5(const float *It0, const float *It1, int nrows, int ncols, int nframes,
+                           float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy);
+
 /* ---- device-pointer entry points ---------------------------------------------------------
  * Same arithmetic on buffers already resident in HBM; asynchronous on `stream`.  Solvers work
  * in place on the iterate and take the ordering `mode` explicitly.  iter<=0 is a no-op here
@@ -210,6 +221,11 @@ int pdeip_diffweights6_dev(void *stream, const float *D, int nrows, int ncols, i
                            float eps, float *wW, float *wN, float *wE, float *wS);
 int pdeip_warp_bilinear_dev(void *stream, const float *Iin, const float *X, const float *Y,
                             int nrows, int ncols, int nframes, float *Iout);
+int pdeip_fst_derivatives5_dev(void *stream, const float *It0, const float *It1, int nrows, int ncols,
+                               int nframes, float *Idt, float *Idx, float *Idy);
+int pdeip_snd_derivatives5_dev(void *stream, const float *It0, const float *It1, int nrows, int ncols,
+                               int nframes, float *Idxt, float *Idyt, float *Idxx, float *Idyy,
+                               float *Idxy);
 
 #ifdef __cplusplus
 }

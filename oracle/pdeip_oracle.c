@@ -765,3 +765,103 @@ void orc_warp_bilinear(float *Iout, const float *Iin, const float *X, const floa
             }
         }
 }
+
+/* ---- Simoncelli derivatives (next row f1) -------------------------------------------------------- */
+
+static const float SIM_SMOOTH[5] = {0.037659f, 0.249724f, 0.439911f, 0.249724f, 0.037659f};  /* FstDerivatives5.c:59 */
+static const float SIM_D1[5] = {-0.104550f, -0.292315f, 0.0f, 0.292315f, 0.104550f};          /* :60 */
+static const float SIM_D2[5] = {0.232905f, 0.002668f, -0.471147f, 0.002668f, 0.232905f};      /* SndDerivatives5.c:67 */
+static const float SIM_DT[2] = {0.50f, -0.50f};                                               /* :61 / :68 */
+
+static int clampi(int x, int hi) { return x < 0 ? 0 : (x > hi ? hi : x); }
+
+/* VerticalConvWO5 (imageDerivatives.c:66-119): 5-tap correlation along the rows of each column, the two
+ * rows past either end replicate the end row; five products summed left to right. */
+static void conv_vertical5(float *out, const float *in, const float *op, int nrows, int ncols)
+{
+    int i, j, k;
+    for (j = 0; j < ncols; j++)
+        for (i = 0; i < nrows; i++) {
+            const float *c = in + (size_t)j * nrows;
+            float t[5], r;
+            for (k = 0; k < 5; k++) t[k] = c[clampi(i - 2 + k, nrows - 1)] * op[k];
+            r = t[0] + t[1];
+            r = r + t[2];
+            r = r + t[3];
+            r = r + t[4];
+            out[(size_t)j * nrows + i] = r;
+        }
+}
+
+/* HorizontalConvWO5 (imageDerivatives.c:125-211): the same along the columns of each row. */
+static void conv_horizontal5(float *out, const float *in, const float *op, int nrows, int ncols)
+{
+    int i, j, k;
+    for (i = 0; i < nrows; i++)
+        for (j = 0; j < ncols; j++) {
+            float t[5], r;
+            for (k = 0; k < 5; k++) t[k] = in[(size_t)clampi(j - 2 + k, ncols - 1) * nrows + i] * op[k];
+            r = t[0] + t[1];
+            r = r + t[2];
+            r = r + t[3];
+            r = r + t[4];
+            out[(size_t)j * nrows + i] = r;
+        }
+}
+
+/* TemporalConvWO2 (imageDerivatives.c:44-60) */
+static void conv_temporal2(float *out, const float *a, const float *b, const float *op, size_t n)
+{
+    size_t p;
+    for (p = 0; p < n; p++) out[p] = a[p] * op[0] + b[p] * op[1];
+}
+
+void orc_fst_derivatives5(float *Idt, float *Idx, float *Idy, const float *It0, const float *It1,
+                          int nrows, int ncols, int nframes)
+{
+    size_t n = (size_t)nrows * ncols;
+    float *temp = (float *)malloc(n * sizeof(float));
+    int k;
+    if (!temp) return;
+    for (k = 0; k < nframes; k++) { /* imageDerivatives.c:369-385 */
+        size_t o = (size_t)k * n;
+        conv_temporal2(Idt + o, It0 + o, It1 + o, SIM_DT, n);
+        conv_vertical5(temp, It1 + o, SIM_SMOOTH, nrows, ncols);
+        conv_horizontal5(Idx + o, temp, SIM_D1, nrows, ncols);
+        conv_horizontal5(temp, It1 + o, SIM_SMOOTH, nrows, ncols);
+        conv_vertical5(Idy + o, temp, SIM_D1, nrows, ncols);
+    }
+    free(temp);
+}
+
+void orc_snd_derivatives5(float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy,
+                          const float *It0, const float *It1, int nrows, int ncols, int nframes)
+{
+    size_t n = (size_t)nrows * ncols;
+    float *t1 = (float *)malloc(n * sizeof(float)), *t2 = (float *)malloc(n * sizeof(float));
+    int k;
+    if (!t1 || !t2) { free(t1); free(t2); return; }
+    for (k = 0; k < nframes; k++) { /* imageDerivatives.c:454-480 */
+        size_t o = (size_t)k * n;
+        conv_vertical5(t2, It0 + o, SIM_SMOOTH, nrows, ncols);
+        conv_horizontal5(t1, t2, SIM_D1, nrows, ncols);
+        conv_vertical5(Idxt + o, It1 + o, SIM_SMOOTH, nrows, ncols);
+        conv_horizontal5(t2, Idxt + o, SIM_D1, nrows, ncols);
+        conv_temporal2(Idxt + o, t1, t2, SIM_DT, n);
+
+        conv_horizontal5(t2, It0 + o, SIM_SMOOTH, nrows, ncols);
+        conv_vertical5(t1, t2, SIM_D1, nrows, ncols);
+        conv_horizontal5(Idyt + o, It1 + o, SIM_SMOOTH, nrows, ncols);
+        conv_vertical5(t2, Idyt + o, SIM_D1, nrows, ncols);
+        conv_temporal2(Idyt + o, t1, t2, SIM_DT, n);
+
+        conv_vertical5(t1, It1 + o, SIM_SMOOTH, nrows, ncols);
+        conv_horizontal5(Idxx + o, t1, SIM_D2, nrows, ncols);
+        conv_horizontal5(t1, It1 + o, SIM_SMOOTH, nrows, ncols);
+        conv_vertical5(Idyy + o, t1, SIM_D2, nrows, ncols);
+        conv_horizontal5(t1, It1 + o, SIM_D1, nrows, ncols);
+        conv_vertical5(Idxy + o, t1, SIM_D1, nrows, ncols);
+    }
+    free(t1);
+    free(t2);
+}

@@ -104,6 +104,15 @@ void orc_diffweights6(float *wW, float *wN, float *wE, float *wS, const float *D
 void orc_warp_bilinear(float *Iout, const float *Iin, const float *X, const float *Y, int nrows,
                        int ncols, int nframes);
 
+/* imageDerivatives.c:309-388 (fstSimoncelli_c, size 5) with the filters of FstDerivatives5.c:59-61.
+ * All planes [nrows x ncols x nframes]; frames are independent. */
+void orc_fst_derivatives5(float *Idt, float *Idx, float *Idy, const float *It0, const float *It1,
+                          int nrows, int ncols, int nframes);
+
+/* imageDerivatives.c:391-482 (sndSimoncelli_c) with the filters of SndDerivatives5.c:65-68. */
+void orc_snd_derivatives5(float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy,
+                          const float *It0, const float *It1, int nrows, int ncols, int nframes);
+
 #ifdef __cplusplus
 }
 #endif

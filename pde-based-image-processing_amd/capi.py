@@ -48,6 +48,8 @@ SIGNATURES = {
     "pdeip_pde_sor8": _sig(11, [_I, _I, _I, _I, _F, _I, _P]),
     "pdeip_diffweights6": [_P, _I, _I, _I, _F, _P, _P, _P, _P],
     "pdeip_warp_bilinear": [_P, _P, _P, _I, _I, _I, _P],
+    "pdeip_fst_derivatives5": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "pdeip_snd_derivatives5": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     # device-pointer entry points (first argument: hipStream_t)
     "pdeip_oflow_sor_elin4_dev": _sig(1 + 11, [_I, _I, _I, _F, _I, _I]),
     "pdeip_oflow_sor_llin4_dev": _sig(1 + 13, [_I, _I, _I, _F, _I, _I]),
@@ -60,6 +62,8 @@ SIGNATURES = {
     "pdeip_oflow_lhs_llin4_dev": _sig(1 + 13, [_I, _I, _I]),
     "pdeip_diffweights6_dev": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _P],
     "pdeip_warp_bilinear_dev": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "pdeip_fst_derivatives5_dev": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "pdeip_snd_derivatives5_dev": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     # library state
     "pdeip_set_mode": [_I],
     "pdeip_get_mode": [],

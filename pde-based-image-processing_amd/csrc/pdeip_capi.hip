@@ -575,6 +575,33 @@ extern "C" int pdeip_warp_bilinear_dev(void *stream, const float *Iin, const flo
     return PDEIP_OK;
 }
 
+static int check_deriv_dims(const char *who, int nrows, int ncols, int nframes)
+{
+    RC(check_dims(who, nrows, ncols, nframes));
+    if (nrows < 4 || ncols < 4) return set_err(PDEIP_ERR_ARG, "%s: the 5-tap filters need at least 4x4 pixels (got %dx%d)", who, nrows, ncols);
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_fst_derivatives5_dev(void *stream, const float *It0, const float *It1, int nrows, int ncols,
+                                          int nframes, float *Idt, float *Idx, float *Idy)
+{
+    RC(check_deriv_dims("pdeip_fst_derivatives5_dev", nrows, ncols, nframes));
+    hipLaunchKernelGGL(k_fst_derivatives5, pixel_grid(nrows, ncols, nframes), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       Idt, Idx, Idy, It0, It1, nrows, ncols, (size_t)nrows * ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_snd_derivatives5_dev(void *stream, const float *It0, const float *It1, int nrows, int ncols,
+                                          int nframes, float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy)
+{
+    RC(check_deriv_dims("pdeip_snd_derivatives5_dev", nrows, ncols, nframes));
+    hipLaunchKernelGGL(k_snd_derivatives5, pixel_grid(nrows, ncols, nframes), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       Idxt, Idyt, Idxx, Idyy, Idxy, It0, It1, nrows, ncols, (size_t)nrows * ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-pointer drop-in entry points (gateway semantics)
 // ------------------------------------------------------------------------------------------------
@@ -843,5 +870,43 @@ extern "C" int pdeip_warp_bilinear(const float *Iin, const float *X, const float
     RC(upload(dI, Iin, nf)); RC(upload(dX, X, n)); RC(upload(dY, Y, n));
     RC(pdeip_warp_bilinear_dev(nullptr, dI, dX, dY, nrows, ncols, nframes, dO));
     RC(download(Iout, dO, nf));
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_fst_derivatives5(const float *It0, const float *It1, int nrows, int ncols, int nframes,
+                                      float *Idt, float *Idx, float *Idy)
+{
+    const char *who = "FstDerivatives5";
+    NONNULL(who, It0); NONNULL(who, It1); NONNULL(who, Idt); NONNULL(who, Idx); NONNULL(who, Idy);
+    RC(check_deriv_dims(who, nrows, ncols, nframes));
+    RC(use_device());
+    const size_t nf = (size_t)nrows * ncols * nframes;
+    Arena ar;
+    RC(ar.init(pad4(nf) * 5));
+    float *d0 = ar.take(nf), *d1 = ar.take(nf), *o0 = ar.take(nf), *o1 = ar.take(nf), *o2 = ar.take(nf);
+    RC(upload(d0, It0, nf)); RC(upload(d1, It1, nf));
+    RC(pdeip_fst_derivatives5_dev(nullptr, d0, d1, nrows, ncols, nframes, o0, o1, o2));
+    RC(download(Idt, o0, nf)); RC(download(Idx, o1, nf)); RC(download(Idy, o2, nf));
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_snd_derivatives5(const float *It0, const float *It1, int nrows, int ncols, int nframes,
+                                      float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy)
+{
+    const char *who = "SndDerivatives5";
+    NONNULL(who, It0); NONNULL(who, It1); NONNULL(who, Idxt); NONNULL(who, Idyt); NONNULL(who, Idxx); NONNULL(who, Idyy);
+    NONNULL(who, Idxy);
+    RC(check_deriv_dims(who, nrows, ncols, nframes));
+    RC(use_device());
+    const size_t nf = (size_t)nrows * ncols * nframes;
+    Arena ar;
+    RC(ar.init(pad4(nf) * 7));
+    float *d0 = ar.take(nf), *d1 = ar.take(nf);
+    float *o[5];
+    for (int k = 0; k < 5; k++) o[k] = ar.take(nf);
+    RC(upload(d0, It0, nf)); RC(upload(d1, It1, nf));
+    RC(pdeip_snd_derivatives5_dev(nullptr, d0, d1, nrows, ncols, nframes, o[0], o[1], o[2], o[3], o[4]));
+    float *h[5] = {Idxt, Idyt, Idxx, Idyy, Idxy};
+    for (int k = 0; k < 5; k++) RC(download(h[k], o[k], nf));
     return PDEIP_OK;
 }

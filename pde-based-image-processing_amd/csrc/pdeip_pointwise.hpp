@@ -257,4 +257,83 @@ __global__ void k_warp_bilinear(float *Iout, const float *Iin, const float *X, c
     }
 }
 
+// ---- Simoncelli derivatives: fstSimoncelli_c / sndSimoncelli_c (imageDerivatives.c:309-482) --------
+// The reference runs separable 5-tap correlations through float temporaries (replicate ends, five
+// products summed left to right).  Here each output pixel re-evaluates the five temporaries it needs
+// from the 5x5 neighbourhood with exactly the same operations, so the results are bit-identical and no
+// temporary plane touches HBM (the 25 taps of neighbouring threads overlap in L1/L2).
+
+__constant__ float SIM_SMOOTH[5] = {0.037659f, 0.249724f, 0.439911f, 0.249724f, 0.037659f}; // FstDerivatives5.c:59
+__constant__ float SIM_D1[5] = {-0.104550f, -0.292315f, 0.0f, 0.292315f, 0.104550f};         // :60
+__constant__ float SIM_D2[5] = {0.232905f, 0.002668f, -0.471147f, 0.002668f, 0.232905f};     // SndDerivatives5.c:67
+
+__device__ __forceinline__ float sum5(const float (&t)[5])
+{
+    float r = t[0] + t[1];
+    r = r + t[2];
+    r = r + t[3];
+    r = r + t[4];
+    return r;
+}
+// VerticalConvWO5 at (i, j): taps along the rows of column j (imageDerivatives.c:66-119)
+__device__ __forceinline__ float v5_at(const float *in, const float *op, int i, int j, int nrows)
+{
+    const float *c = in + (size_t)j * nrows;
+    float t[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) t[k] = c[clampi(i - 2 + k, 0, nrows - 1)] * op[k];
+    return sum5(t);
+}
+// HorizontalConvWO5 at (i, j): taps along the columns of row i (:125-211)
+__device__ __forceinline__ float h5_at(const float *in, const float *op, int i, int j, int nrows, int ncols)
+{
+    float t[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) t[k] = in[(size_t)clampi(j - 2 + k, 0, ncols - 1) * nrows + i] * op[k];
+    return sum5(t);
+}
+// H5(op2) of the temporary V5(op1)(in), and V5(op2) of the temporary H5(op1)(in)
+__device__ __forceinline__ float h5_of_v5(const float *in, const float *op1, const float *op2, int i, int j, int nrows, int ncols)
+{
+    float t[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) t[k] = v5_at(in, op1, i, clampi(j - 2 + k, 0, ncols - 1), nrows) * op2[k];
+    return sum5(t);
+}
+__device__ __forceinline__ float v5_of_h5(const float *in, const float *op1, const float *op2, int i, int j, int nrows, int ncols)
+{
+    float t[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) t[k] = h5_at(in, op1, clampi(i - 2 + k, 0, nrows - 1), j, nrows, ncols) * op2[k];
+    return sum5(t);
+}
+
+__global__ void k_fst_derivatives5(float *Idt, float *Idx, float *Idy, const float *It0, const float *It1,
+                                   int nrows, int ncols, size_t frame_stride)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t fo = (size_t)blockIdx.z * frame_stride;
+    const float *a = It0 + fo, *b = It1 + fo;
+    Idt[fo + pos] = a[pos] * 0.50f + b[pos] * -0.50f;                         // TemporalConvWO2 (:44-60)
+    Idx[fo + pos] = h5_of_v5(b, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);      // :376-378
+    Idy[fo + pos] = v5_of_h5(b, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);      // :380-382
+}
+
+__global__ void k_snd_derivatives5(float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy,
+                                   const float *It0, const float *It1, int nrows, int ncols, size_t frame_stride)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t fo = (size_t)blockIdx.z * frame_stride;
+    const float *a = It0 + fo, *b = It1 + fo;
+    float t1 = h5_of_v5(a, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);           // :459-463
+    float t2 = h5_of_v5(b, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);
+    Idxt[fo + pos] = t1 * 0.50f + t2 * -0.50f;
+    t1 = v5_of_h5(a, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);                 // :465-469
+    t2 = v5_of_h5(b, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);
+    Idyt[fo + pos] = t1 * 0.50f + t2 * -0.50f;
+    Idxx[fo + pos] = h5_of_v5(b, SIM_SMOOTH, SIM_D2, i, j, nrows, ncols);     // :472-473
+    Idyy[fo + pos] = v5_of_h5(b, SIM_SMOOTH, SIM_D2, i, j, nrows, ncols);     // :476-477
+    Idxy[fo + pos] = v5_of_h5(b, SIM_D1, SIM_D1, i, j, nrows, ncols);         // :480-481
+}
+
 } // namespace pdeip

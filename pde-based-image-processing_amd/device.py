@@ -108,3 +108,15 @@ def warp_bilinear(Iin, X, Y, Iout):
     _chk(Iin, X, Y, Iout)
     nrows, ncols, F = _dims(Iin)
     capi.call("pdeip_warp_bilinear_dev", _stream(), *_p(Iin, X, Y), nrows, ncols, F, Iout.data_ptr())
+
+
+def fst_derivatives5(It0, It1, Idt, Idx, Idy):
+    _chk(It0, It1, Idt, Idx, Idy)
+    nrows, ncols, F = _dims(It0)
+    capi.call("pdeip_fst_derivatives5_dev", _stream(), *_p(It0, It1), nrows, ncols, F, *_p(Idt, Idx, Idy))
+
+
+def snd_derivatives5(It0, It1, Idxt, Idyt, Idxx, Idyy, Idxy):
+    _chk(It0, It1, Idxt, Idyt, Idxx, Idyy, Idxy)
+    nrows, ncols, F = _dims(It0)
+    capi.call("pdeip_snd_derivatives5_dev", _stream(), *_p(It0, It1), nrows, ncols, F, *_p(Idxt, Idyt, Idxx, Idyy, Idxy))

@@ -11,7 +11,7 @@ All arithmetic happens in libpdeip.so on the GPU; this file only checks, packs a
 
 Reference: Oflow_sor_elin4_2d.c, Oflow_sor_llin4_2d.c, Oflow_sor_llin8_2d.c, Oflow_lhs_elin4_2d.c,
 Oflow_lhs_llin4_2d.c, Disp_sor_llin4_2d.c, PDEsolver4.c, PDEsolver8.c, DdiffWeights.c,
-BilinInterp_2d.c (all under mex/source/).
+BilinInterp_2d.c, FstDerivatives5.c, SndDerivatives5.c (all under mex/source/).
 """
 import numpy as np
 
@@ -217,6 +217,30 @@ def BilinInterp_2d(Iin, X, Y, nargout=1):
     nrows, ncols = Iin.shape[:2]
     _run("pdeip_warp_bilinear", _ptr(Iin), _ptr(X), _ptr(Y), nrows, ncols, _frames(Iin), _ptr(out))
     return out
+
+
+def _derivatives(who, fn, It0, It1, nout, nargout, msg):
+    if nargout < nout:
+        raise MexError(capi.PDEIP_ERR_ARG, msg)
+    It0, It1 = _single("It0", who, It0), _single("It1", who, It1)
+    if It0.shape != It1.shape:
+        raise MexError(capi.PDEIP_ERR_ARG, "%s: 'It1' is %s but 'It0' is %s" % (who, It1.shape, It0.shape))
+    outs = [_out_like(It0) for _ in range(nout)]
+    nrows, ncols = It0.shape[:2]
+    _run(fn, _ptr(It0), _ptr(It1), nrows, ncols, _frames(It0), *[_ptr(o) for o in outs])
+    return tuple(outs)
+
+
+def FstDerivatives5(It0, It1, nargout=3):
+    """[Idt,Idx,Idy] = FstDerivatives5(It0,It1)  -- mex/source/FstDerivatives5.c:50-145."""
+    return _derivatives("fstDerivatives", "pdeip_fst_derivatives5", It0, It1, 3, nargout,
+                        "fstDerivatives: insufficient number of outputs...outputs from this function are 'Idt', 'Idx' and 'Idy'.")
+
+
+def SndDerivatives5(It0, It1, nargout=5):
+    """[Idxt,Idyt,Idxx,Idyy,Idxy] = SndDerivatives5(It0,It1)  -- mex/source/SndDerivatives5.c:51-174."""
+    return _derivatives("sndDerivatives", "pdeip_snd_derivatives5", It0, It1, 5, nargout,
+                        "sndDerivatives: insufficient number of outputs.")
 
 
 def set_mode(mode):

@@ -38,6 +38,9 @@ CASES = [
     ("diffweights_frames", "DdiffWeights", lambda: dict(pb.diffweights(162, 33, 29, nframes=3), eps=np.float32(1e-3)), dict()),
     ("warp_a", "BilinInterp_2d", lambda: pb.warp(171, 24, 40), dict()),
     ("warp_frames", "BilinInterp_2d", lambda: pb.warp(172, 33, 29, nframes=4, max_disp=8.0), dict()),
+    ("fstderiv_a", "FstDerivatives5", lambda: pb.image_pair(191, 24, 40), dict()),
+    ("fstderiv_frames_small", "FstDerivatives5", lambda: pb.image_pair(192, 4, 7, nframes=3), dict()),
+    ("sndderiv_a", "SndDerivatives5", lambda: pb.image_pair(193, 33, 29, nframes=2), dict()),
 ]
 LHS_CASES = [
     ("lhs_elin4_frames", "oflow_lhs_elin4", lambda: pb.elin4(181, 33, 29, nframes=3, nan_frac=0.05, nan_mode="D"),

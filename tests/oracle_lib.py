@@ -32,6 +32,8 @@ _SIGS = {
     "orc_pde_sor8": [_P] * 11 + [_I, _I, _I, _I, _F, _I],
     "orc_diffweights6": [_P] * 5 + [_I, _I, _I, _F],
     "orc_warp_bilinear": [_P] * 4 + [_I, _I, _I],
+    "orc_fst_derivatives5": [_P] * 5 + [_I, _I, _I],
+    "orc_snd_derivatives5": [_P] * 7 + [_I, _I, _I],
 }
 _lib = None
 
@@ -232,3 +234,19 @@ def Oflow_lhs_elin4_2d(U, V, M, Du, Dv, wW, wN, wE, wS):
 
 def Oflow_lhs_llin4_2d(U, V, dU, dV, M, Du, Dv, wW, wN, wE, wS):
     return oflow_lhs_llin4(U, V, dU, dV, M, Du, Dv, wW, wN, wE, wS)
+
+
+def FstDerivatives5(It0, It1):
+    """[Idt, Idx, Idy] = FstDerivatives5(It0, It1)  (FstDerivatives5.c + fstSimoncelli_c)"""
+    It0, It1 = F(It0), F(It1)
+    outs = [np.zeros_like(It0) for _ in range(3)]
+    lib().orc_fst_derivatives5(*[_p(o) for o in outs], _p(It0), _p(It1), It0.shape[0], It0.shape[1], _frames(It0))
+    return tuple(outs)
+
+
+def SndDerivatives5(It0, It1):
+    """[Idxt, Idyt, Idxx, Idyy, Idxy] = SndDerivatives5(It0, It1)  (SndDerivatives5.c + sndSimoncelli_c)"""
+    It0, It1 = F(It0), F(It1)
+    outs = [np.zeros_like(It0) for _ in range(5)]
+    lib().orc_snd_derivatives5(*[_p(o) for o in outs], _p(It0), _p(It1), It0.shape[0], It0.shape[1], _frames(It0))
+    return tuple(outs)

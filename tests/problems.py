@@ -131,6 +131,15 @@ def warp(seed, nrows, ncols, nframes=1, max_disp=3.0, special=True):
     return dict(Iin=Iin, X=_f(X), Y=_f(Y))
 
 
+def image_pair(seed, nrows, ncols, nframes=1):
+    """Two frames of a smooth-ish random texture (inputs of the Simoncelli derivative gateways)."""
+    rng = np.random.default_rng(seed)
+    shape = (nrows, ncols) if nframes == 1 else (nrows, ncols, nframes)
+    It0 = _plane(rng, shape, 0, 1)
+    It1 = _f(It0 + rng.uniform(-0.1, 0.1, size=shape))
+    return dict(It0=It0, It1=It1)
+
+
 def bit_equal(a, b):
     """Bitwise equality of float32 arrays, except that any NaN equals any NaN."""
     a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)

@@ -17,7 +17,7 @@ def test_header_declares_the_boundary():
     syms = declared_symbols()
     for gateway in ("pdeip_oflow_sor_elin4", "pdeip_oflow_sor_llin4", "pdeip_oflow_sor_llin8", "pdeip_oflow_lhs_elin4",
                     "pdeip_oflow_lhs_llin4", "pdeip_disp_sor_llin4", "pdeip_pde_sor4", "pdeip_pde_sor8",
-                    "pdeip_diffweights6", "pdeip_warp_bilinear"):
+                    "pdeip_diffweights6", "pdeip_warp_bilinear", "pdeip_fst_derivatives5", "pdeip_snd_derivatives5"):
         assert gateway in syms and (gateway + "_dev" in syms or gateway.endswith(("llin8", "lhs_elin4", "lhs_llin4"))), gateway
 
 

@@ -138,6 +138,13 @@ def test_warp(pdeip, oracle, shape, F):
           "warp %s F=%d" % (shape, F))
 
 
+@pytest.mark.parametrize("shape,F", [((32, 48), 1), ((97, 131), 3), ((4, 4), 2), ((5, 300), 1), ((260, 7), 1), ((388, 584), 2)])
+def test_simoncelli_derivatives(pdeip, oracle, shape, F):
+    p = pb.image_pair(85, *shape, nframes=F)
+    check(pdeip.mex_api.FstDerivatives5(p["It0"], p["It1"]), oracle.FstDerivatives5(p["It0"], p["It1"]), "fst %s F=%d" % (shape, F))
+    check(pdeip.mex_api.SndDerivatives5(p["It0"], p["It1"]), oracle.SndDerivatives5(p["It0"], p["It1"]), "snd %s F=%d" % (shape, F))
+
+
 def test_solver_errors(pdeip):
     p = pb.elin4(91, 16, 16)
     with pytest.raises(pdeip.mex_api.MexError, match="no such solver"):

@@ -70,10 +70,10 @@ def call(lib, nlhs, args):
     return (lib.mock_last_error().decode() if rc else None), outs
 
 
-def test_all_ten_gateways_have_a_stub():
+def test_all_gateways_have_a_stub():
     assert STUBS == sorted(["Oflow_sor_elin4_2d", "Oflow_sor_llin4_2d", "Oflow_sor_llin8_2d", "Oflow_lhs_elin4_2d",
                             "Oflow_lhs_llin4_2d", "Disp_sor_llin4_2d", "PDEsolver4", "PDEsolver8", "DdiffWeights",
-                            "BilinInterp_2d"])
+                            "BilinInterp_2d", "FstDerivatives5", "SndDerivatives5"])
 
 
 @pytest.mark.parametrize("name", STUBS)
@@ -123,3 +123,12 @@ def test_stubs_run_like_matlab_would_call_them(pdeip, oracle):
     assert err is None and pb.bit_equal(outs[0], oracle.BilinInterp_2d(w_["Iin"], w_["X"], w_["Y"]))
     err, _ = call(build_stub("Oflow_sor_elin4_2d", pdeip), 2, list(p.values()) + [np.float32(4), np.float32(1.9), np.float32(2)])
     assert "alternating line relaxation" in err
+    ip = pb.image_pair(7, 21, 26, nframes=2)
+    err, outs = call(build_stub("FstDerivatives5", pdeip), 3, [ip["It0"], ip["It1"]])
+    assert err is None
+    for g, w in zip(outs, oracle.FstDerivatives5(ip["It0"], ip["It1"])):
+        assert pb.bit_equal(g, w)
+    err, outs = call(build_stub("SndDerivatives5", pdeip), 5, [ip["It0"], ip["It1"]])
+    assert err is None
+    for g, w in zip(outs, oracle.SndDerivatives5(ip["It0"], ip["It1"])):
+        assert pb.bit_equal(g, w)

@@ -205,3 +205,35 @@ def test_diffweights_closed_forms(oracle):
         tW, tN = np.maximum(tW, tw), np.maximum(tN, tn)
     assert np.allclose(wW[:, 1:], 1 / np.sqrt(tW[:, 1:] + eps), rtol=2e-5)
     assert np.allclose(wN[1:, :], 1 / np.sqrt(tN[1:, :] + eps), rtol=2e-5)
+
+
+def test_simoncelli_derivatives_closed_forms(oracle):
+    """Ramp image: first derivatives = slope x filter gains away from the border; second derivatives and
+    temporal terms vanish; a constant image has zero spatial derivatives everywhere (replicate border)."""
+    nrows, ncols = 11, 14
+    jj, ii = np.meshgrid(np.arange(ncols, dtype=np.float64), np.arange(nrows, dtype=np.float64))
+    ramp = (2.0 * jj + 3.0 * ii).astype(np.float32)
+    S = np.array([0.037659, 0.249724, 0.439911, 0.249724, 0.037659])
+    D1 = np.array([-0.104550, -0.292315, 0.0, 0.292315, 0.104550])
+    gain = S.sum() * (D1 * np.arange(-2, 3)).sum()
+    Idt, Idx, Idy = oracle.FstDerivatives5(ramp, ramp)
+    assert not Idt.any()
+    assert np.allclose(Idx[2:-2, 2:-2], 2.0 * gain, rtol=1e-5) and np.allclose(Idy[2:-2, 2:-2], 3.0 * gain, rtol=1e-5)
+    Idt, _, _ = oracle.FstDerivatives5(ramp, ramp + np.float32(1))
+    assert np.allclose(Idt, -0.5)                                   # 0.5*It0 - 0.5*It1
+    Idxt, Idyt, Idxx, Idyy, Idxy = oracle.SndDerivatives5(ramp, ramp)
+    for a in (Idxt, Idyt):
+        assert np.abs(a).max() == 0.0
+    assert np.abs(Idxx[2:-2, 2:-2]).max() < 1e-3 and np.abs(Idyy[2:-2, 2:-2]).max() < 1e-3
+    assert np.allclose(Idxy[2:-2, 2:-2], 0.0, atol=1e-4)
+    const = np.full((nrows, ncols), 0.7, dtype=np.float32)
+    _, Idx, Idy = oracle.FstDerivatives5(const, const)
+    assert np.abs(Idx).max() < 1e-6 and np.abs(Idy).max() < 1e-6
+    # against scipy's correlate1d with replicate borders (float64), the definition in prose
+    import scipy.ndimage as ndi
+    p = pb.image_pair(351, 16, 13)
+    _, Idx, Idy = oracle.FstDerivatives5(p["It0"], p["It1"])
+    I1 = p["It1"].astype(np.float64)
+    want_x = ndi.correlate1d(ndi.correlate1d(I1, S, axis=0, mode="nearest"), D1, axis=1, mode="nearest")
+    want_y = ndi.correlate1d(ndi.correlate1d(I1, S, axis=1, mode="nearest"), D1, axis=0, mode="nearest")
+    assert np.allclose(Idx, want_x, atol=2e-6) and np.allclose(Idy, want_y, atol=2e-6)
