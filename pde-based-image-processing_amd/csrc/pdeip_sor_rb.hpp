@@ -28,12 +28,16 @@ namespace pdeip {
 
 constexpr int RB_OWN_ROWS = 248; // 62 storing lanes x 4 rows
 constexpr int RB_WAVES_PER_BLOCK = 4;
+#ifndef PDEIP_RB_NT
+#define PDEIP_RB_NT 0 /* measured at 4K: non-temporal coefficient loads are ~5 % slower than default-policy loads */
+#endif
+constexpr bool RB_NT_COEF = PDEIP_RB_NT != 0;
 
 // Loads rows r..r+3 of column c.  Always issued, never branched on: a bounds check around a load
 // makes the compiler wait for it inside the branch, which serialises the thirteen loads of a step.
 // Out-of-image lanes/columns read a clamped (valid) address instead; their values are never used
 // for a stored result (they only feed border cells, which are not relaxed).
-template <bool VEC>
+template <bool VEC, bool NT = false>
 __device__ __forceinline__ void rb_load4(float (&d)[4], const float *__restrict__ p, int c, int r,
                                          int nrows, int ncols)
 {
@@ -41,7 +45,11 @@ __device__ __forceinline__ void rb_load4(float (&d)[4], const float *__restrict_
     const float *q = p + (size_t)cc * nrows;
     if (VEC) {
         const int rr = r < 0 ? 0 : (r > nrows - 4 ? nrows - 4 : r);
-        const float4 t = *reinterpret_cast<const float4 *>(q + rr);
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        // NT: coefficient planes are streamed exactly once per sweep -- non-temporal loads keep them from
+        // displacing the iterate columns that neighbouring units re-read
+        const v4f t = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(q + rr))
+                         : *reinterpret_cast<const v4f *>(q + rr);
         d[0] = t.x;
         d[1] = t.y;
         d[2] = t.z;
@@ -185,7 +193,7 @@ __device__ __forceinline__ void rb_march(const SweepPlanes<Mdl> &P, float *dout0
             else ROn[f][0] = ROn[f][1] = ROn[f][2] = ROn[f][3] = 0.0f;
         }
 #pragma unroll
-        for (int f = 0; f < NCF; f++) rb_load4<VEC>(CFn[f], P.cf[f], c + DIR, r, nrows, ncols);
+        for (int f = 0; f < NCF; f++) rb_load4<VEC, RB_NT_COEF>(CFn[f], P.cf[f], c + DIR, r, nrows, ncols);
 
         const int p = (c + gm.col0) & 1;
 
