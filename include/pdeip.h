@@ -65,6 +65,9 @@ int pdeip_set_device(int device_id);
 int pdeip_release(void);
 /* Number of kernel launches the last *_dev solver call enqueued (diagnostic). */
 int pdeip_last_launch_count(void);
+/* Waits for the device and reports PDEIP_ERR_DEVICE if a bounded dependency wait of the persistent
+ * exact-order kernel (PDEIP_EXACT_PERSIST=1) timed out during the preceding calls. */
+int pdeip_persist_error(void);
 /* Sweep-kernel timing for bench.py's roofline figure.  While enabled, every *_dev solver call
  * brackets its back-to-back sweep launches (not its prologue) with a pair of HIP events on the
  * call's stream.  pdeip_profile_read() waits for the recorded events, returns the summed elapsed

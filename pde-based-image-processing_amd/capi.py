@@ -70,6 +70,7 @@ SIGNATURES = {
     "pdeip_set_device": [_I],
     "pdeip_release": [],
     "pdeip_last_launch_count": [],
+    "pdeip_persist_error": [],
     "pdeip_profile_enable": [_I],
     "pdeip_profile_read": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
 }

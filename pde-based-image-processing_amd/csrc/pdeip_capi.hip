@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
@@ -24,15 +25,16 @@ using namespace pdeip;
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_NSLOT };
+enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_CTL, WS_ORDER, WS_NSLOT };
 
 struct Context {
     int device = 0;
     int mode = PDEIP_MODE_EXACT_ORDER;
     int last_launches = 0;
     char err[512] = "";
-    void *ws[WS_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
-    size_t ws_bytes[WS_NSLOT] = {0, 0, 0, 0};
+    void *ws[WS_NSLOT] = {};
+    size_t ws_bytes[WS_NSLOT] = {};
+    int order_B = 0, order_T = 0; // shape of the cached persistent-kernel schedule table
     int rb_tj = 0; // columns per red-black unit (0 = default)
     // sweep-kernel timing (pdeip_profile_*)
     bool profile = false;
@@ -180,6 +182,54 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         const int B = (ncols - 2 + 63) / 64;
         const int last_m = (A - 1) + 2 * (B - 1) + 3 * (iter - 1);
         for (int f = 0; f < NIT; f++) P.it_in[f] = P.it_out[f];
+        // Launch-per-front or persistent?  Measured at 4K: equal at iter=4 (each strip has to trail its west
+        // neighbour by 64 rows plus the hand-off latency either way), persistent 1.4x faster at iter=20 (no
+        // per-front cold start, sweeps overlap more tightly).  PDEIP_EXACT_PERSIST = 0 never, 1 always, unset: auto.
+        const int persist_pref = env_int("PDEIP_EXACT_PERSIST", -1);
+        const bool persist = (persist_pref == 1) || (persist_pref < 0 && iter >= 8);
+        if (persist && B <= 0xffff && iter <= 0x7fff && n * sizeof(float) < 0xffffffffull) {
+            // ---- persistent form: one launch, progress counters instead of one launch per front ----
+            const int NC = (nrows - 2 + 63 + EX_CH - 1) / EX_CH;
+            float *ctl_f = nullptr, *order_f = nullptr;
+            const size_t nprog = (size_t)nframes * iter * B;
+            RC(ws_get(WS_CTL, (4 + nprog) * sizeof(unsigned), &ctl_f));
+            RC(ws_get(WS_ORDER, (size_t)B * iter * sizeof(int), &order_f));
+            if (g.order_B != B || g.order_T != iter) { // (b,t) in an order where every dependency comes earlier
+                std::vector<int> ord;
+                ord.reserve((size_t)B * iter);
+                for (int key = 0; key <= (B - 1) + 2 * (iter - 1); key++)
+                    for (int t = 0; t < iter; t++) {
+                        const int b = key - 2 * t;
+                        if (b >= 0 && b < B) ord.push_back(b | (t << 16));
+                    }
+                HIPCHK(hipMemcpyAsync(order_f, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, s));
+                HIPCHK(hipStreamSynchronize(s)); // `ord` is about to go out of scope
+                g.order_B = B;
+                g.order_T = iter;
+            }
+            HIPCHK(hipMemsetAsync(ctl_f, 0, (4 + nprog) * sizeof(unsigned), s));
+            PersistCtl ctl;
+            ctl.ticket = reinterpret_cast<unsigned *>(ctl_f);
+            ctl.abort_flag = ctl.ticket + 1;
+            ctl.progress = ctl.ticket + 4;
+            ctl.order = reinterpret_cast<const int *>(order_f);
+            constexpr size_t plds = ExactLayout<Mdl>::LDS_BYTES + 16;
+            static bool plds_opt_in = false;
+            if (!plds_opt_in) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sor_exact_persist<Mdl>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+                plds_opt_in = true;
+            }
+            SweepTimer timer(s);
+            hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(B * iter * nframes)), dim3(128), plds, s, P, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
+            timer.stop(1);
+            g.last_launches++;
+            const int nb = 2 * ncols + 2 * (nrows - 2);
+            hipLaunchKernelGGL(k_fill_borders, dim3((nb + 255) / 256, nframes, NIT), dim3(256), 0, s,
+                               P.it_out[0], P.it_out[NIT - 1], NIT, nrows, ncols, n);
+            g.last_launches++;
+            HIPCHK(hipGetLastError());
+            return PDEIP_OK;
+        }
         const dim3 grid((unsigned)(B * iter), (unsigned)nframes);
         constexpr size_t lds = ExactLayout<Mdl>::LDS_BYTES;
         static bool lds_opt_in = false; // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
@@ -326,6 +376,15 @@ extern "C" int pdeip_release(void)
     return PDEIP_OK;
 }
 extern "C" int pdeip_last_launch_count(void) { return g.last_launches; }
+extern "C" int pdeip_persist_error(void)
+{ // waits for the device, then reports whether a bounded spin of the persistent kernel timed out
+    if (!g.ws[WS_CTL]) return PDEIP_OK;
+    unsigned words[2] = {0, 0};
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(words, g.ws[WS_CTL], sizeof words, hipMemcpyDeviceToHost));
+    if (words[1] != 0) return set_err(PDEIP_ERR_DEVICE, "persistent exact-order kernel: a dependency wait timed out (results are invalid)");
+    return PDEIP_OK;
+}
 #ifdef PDEIP_EXACT_STAMPS
 extern "C" int pdeip_debug_read_stamps(unsigned long long *out)
 {

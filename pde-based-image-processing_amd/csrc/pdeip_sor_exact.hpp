@@ -396,6 +396,346 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
     }
 }
 
+// =================================================================================================
+// Persistent form: one launch per call.  A workgroup owns one (strip b, sweep t) and walks down the
+// strip chunk by chunk (same mover/compute pair and LDS layout as k_sor_exact, no tile boundaries, no
+// cold start); the launch-per-front ordering is replaced by progress counters:
+//   chunk c of (b,t) needs   progress[b-1][t]   >= c+5   (west column relaxed, and its readers done)
+//                            progress[b][t-1]   >= c+2   (own columns' south rows of sweep t-1)
+//                            progress[b+1][t-1] >= c-2   (east column of sweep t-1)
+// (rows relaxed by lane 63 trail lane 0 by 63 rows = 4 chunks, hence the +5).  The same three
+// conditions cover the write-after-read hazards.
+// Hand-off (cdna_hip_programming.md Guideline 16, recipe R1): the iterate is stored write-through
+// (buffer_store ... sc1) by the mover wave only, which drains (s_waitcnt vmcnt(0)) and then publishes
+// the counter with one relaxed agent-scope atomic store; a consumer's mover polls relaxed and reads
+// the iterate with sc1 buffer loads only.  Buffer addressing also gives free bounds clamping, so
+// there is no element-wise slow path here.
+// Liveness: workgroups take a ticket at start and tickets are mapped to (b,t) in an order in which
+// every dependency has a smaller ticket, so whatever the dispatch order a running workgroup only ever
+// waits for workgroups that are running or finished.  Every spin is bounded; a timeout raises the
+// abort word, after which all waits fall through and the grid drains (the host reports the error).
+struct PersistCtl {
+    unsigned *ticket;    // [1]
+    unsigned *abort_flag; // [1]
+    unsigned *progress;  // [nframes][T][B] chunks completed and visible
+    const int *order;    // [B*T] packed b | (t << 16), dependency-respecting order
+};
+
+// Wave-wide wait: lane k polls counter ptrs[k] (k < 3) until it reaches need[k]; the three polls are ONE
+// load instruction per round (one write-through latency instead of three).  Bounded: a timeout raises
+// the abort word and every later wait falls through.
+__device__ __forceinline__ void persist_wait3(const unsigned *my_ptr, unsigned my_need, unsigned *abort_flag)
+{
+    const bool polls = (my_ptr != nullptr) && (my_need != 0);
+    bool ok = !polls || (__hip_atomic_load(my_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= my_need);
+    if (__all(ok)) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+    for (;;) {
+        __builtin_amdgcn_s_sleep(4);
+        if (!ok) ok = __hip_atomic_load(my_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= my_need;
+        if (__all(ok)) return;
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) { // 0.5 s: something is wrong; drain the grid
+            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+}
+
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+
+template <class Mdl>
+__global__ void __launch_bounds__(128)
+k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, int B, int T, int NC, int nframes,
+                    float omega, size_t frame_stride)
+{
+    using L = ExactLayout<Mdl>;
+    constexpr int NIT = L::NIT, NRO = L::NRO, NRO1 = at_least_one<NRO>::value, NF = L::NF, NCF = L::NCF, NP = L::NP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *outb_base = smem + 2 * L::BUF;
+    // the ticket word lives at the END of the dynamic region: a static __shared__ would sit in front of it
+    // and knock the 16-byte alignment of every ds_read_b128 (cdna_hip_programming.md Guideline 17)
+    unsigned *s_ticket = reinterpret_cast<unsigned *>(smem + 2 * L::BUF + 2 * L::OUTB);
+
+    const int lane = threadIdx.x & 63;
+    const bool mover = (threadIdx.x >> 6) == 1;
+    if (threadIdx.x == 0) *s_ticket = atomicAdd(ctl.ticket, 1u);
+    __syncthreads();
+    const unsigned tk = *s_ticket;
+    const int frame = (int)(tk % (unsigned)nframes);
+    const int packed = ctl.order[tk / (unsigned)nframes];
+    const int b = packed & 0xffff, t = packed >> 16;
+    const size_t fo = (size_t)frame * frame_stride;
+    unsigned *prog_mine = ctl.progress + ((size_t)frame * T + t) * B + b;
+    const unsigned *prog_west = (b > 0) ? prog_mine - 1 : nullptr;
+    const unsigned *prog_prev = (t > 0) ? prog_mine - B : nullptr;
+    const unsigned *prog_east = (t > 0 && b + 1 < B) ? prog_mine - B + 1 : nullptr;
+
+    // every plane through a buffer descriptor (range-checked: an out-of-plane row reads 0 / writes nothing);
+    // iterate fields with aux = 16 (sc1), coefficients and read-only fields with the default policy
+    __amdgpu_buffer_rsrc_t rs[NP];
+    const unsigned plane_bytes = (unsigned)((size_t)nrows * ncols * sizeof(float));
+#pragma unroll
+    for (int f = 0; f < NIT; f++) rs[f] = __builtin_amdgcn_make_buffer_rsrc(P.it_out[f] + fo, 0, plane_bytes, 0x00020000);
+#pragma unroll
+    for (int f = 0; f < NRO; f++) rs[NIT + f] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.ro[f]) + fo, 0, plane_bytes, 0x00020000);
+#pragma unroll
+    for (int f = 0; f < NCF; f++) rs[NF + f] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.cf[f]) + fo, 0, plane_bytes, 0x00020000);
+
+    const int jbase = 1 + 64 * b;
+    auto crow = [&](int i) { return i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i); };
+    auto boff = [&](int jj, int row) { return (unsigned)(((long)jj * nrows + row) * 4); }; // byte offset; >= 0 for jj >= 1
+    const int lcol = lane >> 2, lrq = lane & 3;
+    auto as_f4u = [](v4u_t v, f4u &o) {
+        o.v[0] = __uint_as_float(v.x); o.v[1] = __uint_as_float(v.y); o.v[2] = __uint_as_float(v.z); o.v[3] = __uint_as_float(v.w);
+    };
+
+    if (mover) {
+        // ================================ mover wave ==========================================
+        f4u preA[NP][4], preB[(NP <= 11) ? NP : 1][4], epreA[NF], epreB[NF];
+        constexpr bool TWO_SETS = (NP <= 11);
+        // lane 0 watches the west strip, lane 1 this strip's previous sweep, lane 2 the east strip's previous sweep
+        const unsigned *my_ptr = lane == 0 ? prog_west : (lane == 1 ? prog_prev : (lane == 2 ? prog_east : nullptr));
+        auto wait_deps = [&](int c) __attribute__((always_inline)) {
+            const int need = lane == 0 ? c + 5 : (lane == 1 ? c + 2 : c - 2);
+            persist_wait3(my_ptr, (unsigned)(need < 0 ? 0 : (need < NC ? need : NC)), ctl.abort_flag);
+        };
+        auto fetch = [&](int c, f4u (&pre)[NP][4], f4u (&epre)[NF]) __attribute__((always_inline)) {
+            const int i00 = 1 + EX_CH * c;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = 16 * g + lcol;
+                    int jj = jbase + col;
+                    jj = jj < ncols - 1 ? jj : ncols - 1;
+                    const int row = i00 - col + (p < NF ? 1 : 0) + 4 * lrq;
+                    const v4u_t v = (p < NIT) ? __builtin_amdgcn_raw_buffer_load_b128(rs[p], boff(jj, row), 0, 16)
+                                              : __builtin_amdgcn_raw_buffer_load_b128(rs[p], boff(jj, row), 0, 0);
+                    as_f4u(v, pre[p][g]);
+                }
+            }
+            const int which = (lane >> 2) & 1;
+            const int ecol = which ? (jbase + 64 < ncols - 1 ? jbase + 64 : ncols - 1) : jbase - 1;
+            const int erow = (which ? i00 - 63 : i00) + 4 * (lane & 3);
+#pragma unroll
+            for (int f = 0; f < NF; f++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const unsigned u = (f < NIT) ? __builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(ecol, crow(erow + e)), 0, 16)
+                                                 : __builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(ecol, crow(erow + e)), 0, 0);
+                    epre[f].v[e] = __uint_as_float(u);
+                }
+        };
+        auto stash = [&](const f4u (&pre)[NP][4], const f4u (&epre)[NF], int buf) __attribute__((always_inline)) {
+            float *stage = smem + buf * L::BUF, *edge = stage + L::STAGE;
+#pragma unroll
+            for (int p = 0; p < NP; p++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = 16 * g + lcol;
+                    *reinterpret_cast<float4 *>(&stage[(p * 64 + col) * EX_STR + 4 * lrq]) =
+                        make_float4(pre[p][g].v[0], pre[p][g].v[1], pre[p][g].v[2], pre[p][g].v[3]);
+                }
+            if (lane < 8) {
+                const int which = (lane >> 2) & 1;
+#pragma unroll
+                for (int f = 0; f < NF; f++)
+                    *reinterpret_cast<float4 *>(&edge[(which * NF + f) * EX_CH + 4 * (lane & 3)]) =
+                        make_float4(epre[f].v[0], epre[f].v[1], epre[f].v[2], epre[f].v[3]);
+            }
+        };
+        // relaxed chunk c: LDS -> global, write-through (sc1)
+        auto store_out = [&](int c) __attribute__((always_inline)) {
+            const float *outb = outb_base + (c & 1) * L::OUTB;
+            const int i00 = 1 + EX_CH * c;
+            const int lo_row = i00 - 63, hi_row = i00 + EX_CH - 1;
+            const bool all_valid = (lo_row >= 1) && (hi_row <= nrows - 2) && (jbase + 63 <= ncols - 2);
+#pragma unroll
+            for (int f = 0; f < NIT; f++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = 16 * g + lcol;
+                    const int jj = jbase + col;
+                    const int row = i00 - col + 4 * lrq;
+                    const float4 v = *reinterpret_cast<const float4 *>(&outb[(f * 64 + col) * EX_STR + 4 * lrq]);
+                    if (all_valid) {
+                        v4u_t u;
+                        u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+                        __builtin_amdgcn_raw_buffer_store_b128(u, rs[f], boff(jj, row), 0, 16);
+                    } else if (jj <= ncols - 2) {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (row + e >= 1 && row + e <= nrows - 2)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[e]), rs[f], boff(jj, row + e), 0, 16);
+                    }
+                }
+        };
+        // publish progress = c+1 once every store of this wave has left (recipe R1: drain, then the flag).
+        // `younger_loads` = vector loads issued AFTER those stores (the prefetch of a later chunk): vmcnt
+        // retires in order, so waiting until only that many operations remain drains the stores without
+        // waiting for the prefetch.  (vmcnt encodes 0..63.)
+        constexpr int FETCH_LOADS = NP * 4 + NF * 4;
+        auto publish = [&](int c, bool younger_loads) __attribute__((always_inline)) {
+            if (younger_loads && FETCH_LOADS <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FETCH_LOADS <= 63 ? FETCH_LOADS : 0) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(prog_mine, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        // chunk c is fetched two barriers before it is relaxed, stashed one barrier before, written back one after.
+        // Per step: stash the chunk that landed, issue the write-back stores, wait for the dependencies of the
+        // chunk two ahead and issue its loads, then publish behind vmcnt(#loads).
+        wait_deps(0);
+        fetch(0, preA, epreA);
+        stash(preA, epreA, 0);
+        if (NC > 1) {
+            wait_deps(1);
+            if constexpr (TWO_SETS) fetch(1, preB, epreB);
+            else fetch(1, preA, epreA);
+        }
+        lds_barrier(); // chunk 0 is in buffer 0
+        for (int c = 0; c < NC; c += 2) {
+            // ---- while chunk c (buffer 0) is relaxed ----
+            if constexpr (TWO_SETS) {
+                if (c + 1 < NC) stash(preB, epreB, 1);
+                if (c >= 1) store_out(c - 1);
+                const bool pf = c + 2 < NC;
+                if (pf) { wait_deps(c + 2); fetch(c + 2, preA, epreA); }
+                if (c >= 1) publish(c - 1, pf);
+            } else {
+                if (c + 1 < NC) stash(preA, epreA, 1);
+                if (c >= 1) store_out(c - 1);
+                const bool pf = c + 2 < NC;
+                if (pf) { wait_deps(c + 2); fetch(c + 2, preA, epreA); }
+                if (c >= 1) publish(c - 1, pf);
+            }
+            lds_barrier();
+            if (c + 1 >= NC) break;
+            // ---- while chunk c+1 (buffer 1) is relaxed ----
+            if constexpr (TWO_SETS) {
+                if (c + 2 < NC) stash(preA, epreA, 0);
+                store_out(c);
+                const bool pf = c + 3 < NC;
+                if (pf) { wait_deps(c + 3); fetch(c + 3, preB, epreB); }
+                publish(c, pf);
+            } else {
+                if (c + 2 < NC) stash(preA, epreA, 0);
+                store_out(c);
+                const bool pf = c + 3 < NC;
+                if (pf) { wait_deps(c + 3); fetch(c + 3, preA, epreA); }
+                publish(c, pf);
+            }
+            lds_barrier();
+        }
+        store_out(NC - 1);
+        publish(NC - 1, false);
+        return;
+    }
+
+    // ================================== compute wave ===========================================
+    const int j = jbase + lane;
+    const bool col_ok = j <= ncols - 2;
+    const int jc = j < ncols - 1 ? j : ncols - 1;
+    const float om1 = 1.0f - omega;
+    const bool first_sweep = (t == 0);
+    const int i0 = 1 - lane; // row of this lane at step 0 of chunk 0
+
+    lds_barrier(); // the mover has passed the dependency waits of chunks 0 and 1
+    // state at step 0 (rows <= 1): sc1 loads, after the waits above
+    float prev[NIT], cen[NIT], north0[NIT], west0[NIT], topb[NIT], rcen[NRO1], rnorth[NRO1];
+#pragma unroll
+    for (int f = 0; f < NIT; f++) {
+        cen[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc, crow(i0)), 0, 16));
+        north0[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc, crow(i0 - 1)), 0, 16));
+        west0[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc - 1, crow(i0)), 0, 16));
+        topb[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc, 0), 0, 16));
+        prev[f] = 0.0f;
+    }
+#pragma unroll
+    for (int f = 0; f < NRO1; f++) {
+        rcen[f] = (NRO > 0) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[(NRO > 0 ? NIT + f : 0)], boff(jc, crow(i0)), 0, 0)) : 0.0f;
+        rnorth[f] = (NRO > 0) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[(NRO > 0 ? NIT + f : 0)], boff(jc, crow(i0 - 1)), 0, 0)) : 0.0f;
+    }
+
+    for (int k = 0; k < NC; k++) {
+        const float *stage = smem + (k & 1) * L::BUF, *edge = stage + L::STAGE;
+        float *outb = outb_base + (k & 1) * L::OUTB;
+        const int i00 = 1 + EX_CH * k;
+        auto relax_chunk = [&](auto interior_tag) __attribute__((always_inline)) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+        for (int mq = 0; mq < EX_CH / 4; mq++) {
+            float4 ck[NCF], s4[NF], e4[NF], res[NIT];
+#pragma unroll
+            for (int f = 0; f < NCF; f++) ck[f] = *reinterpret_cast<const float4 *>(&stage[((NF + f) * 64 + lane) * EX_STR + 4 * mq]);
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                s4[f] = *reinterpret_cast<const float4 *>(&stage[(f * 64 + lane) * EX_STR + 4 * mq]);
+                e4[f] = *reinterpret_cast<const float4 *>(&edge[((lane == 63 ? 1 : 0) * NF + f) * EX_CH + 4 * mq]);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int q = EX_CH * k + 4 * mq + x;
+                const int i = i0 + q;
+                const bool row_ok = INTERIOR || ((i >= 1) && (i <= nrows - 2));
+                const bool active = INTERIOR || (col_ok && row_ok);
+                auto el = [&](const float4 &v) { return x == 0 ? v.x : (x == 1 ? v.y : (x == 2 ? v.z : v.w)); };
+                float c[NIT], w[NIT], e[NIT], n[NIT], s[NIT], kk[NCF];
+                float rsouth[NRO1], reast[NRO1], rwest[NRO1];
+#pragma unroll
+                for (int f = 0; f < NIT; f++) {
+                    const float sraw = el(s4[f]);
+                    const float eraw = dpp_from_upper_lane(sraw, el(e4[f]));
+                    float wnew = dpp_from_lower_lane(prev[f], el(e4[f]));
+                    if (q == 0 && lane != 0) wnew = west0[f];
+                    float nv = (q == 0) ? north0[f] : prev[f];
+                    if (!INTERIOR && i == 1) nv = first_sweep ? topb[f] : cen[f];
+                    c[f] = cen[f];
+                    n[f] = nv;
+                    s[f] = (!INTERIOR && i + 1 == nrows - 1 && !first_sweep) ? cen[f] : sraw;
+                    e[f] = (!INTERIOR && j + 1 == ncols - 1 && !first_sweep) ? cen[f] : eraw;
+                    w[f] = (!INTERIOR && j - 1 == 0 && !first_sweep) ? cen[f] : wnew;
+                    cen[f] = sraw;
+                }
+#pragma unroll
+                for (int f = 0; f < NRO1; f++) {
+                    if (NRO > 0) {
+                        rsouth[f] = el(s4[(NRO > 0 ? NIT + f : 0)]);
+                        reast[f] = dpp_from_upper_lane(rsouth[f], el(e4[(NRO > 0 ? NIT + f : 0)]));
+                        rwest[f] = dpp_from_lower_lane(rnorth[f], el(e4[(NRO > 0 ? NIT + f : 0)]));
+                    } else {
+                        rsouth[f] = reast[f] = rwest[f] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < NCF; f++) kk[f] = el(ck[f]);
+                Mdl::update(c, w, e, n, s, rcen, rwest, reast, rnorth, rsouth, kk, omega, om1);
+#pragma unroll
+                for (int f = 0; f < NIT; f++) {
+                    if (active) prev[f] = c[f];
+                    const float r = c[f];
+                    if (x == 0) res[f].x = r; else if (x == 1) res[f].y = r; else if (x == 2) res[f].z = r; else res[f].w = r;
+                }
+#pragma unroll
+                for (int f = 0; f < NRO1; f++) {
+                    rnorth[f] = rcen[f];
+                    rcen[f] = rsouth[f];
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < NIT; f++) *reinterpret_cast<float4 *>(&outb[(f * 64 + lane) * EX_STR + 4 * mq]) = res[f];
+        }
+        };
+        {
+            const int lo_row = i00 - 63, hi_row = i00 + EX_CH - 1;
+            const bool interior = (lo_row >= 2) && (hi_row <= nrows - 3) && (jbase >= 2) && (jbase + 63 <= ncols - 3);
+            if (interior) relax_chunk(std::true_type{});
+            else relax_chunk(std::false_type{});
+        }
+        lds_barrier();
+    }
+}
+
 // Final border replicate of the iterate (rows first, then columns; opticalflowSolvers.c:161-179):
 // border cell <- nearest interior pixel.  Reads interior cells only, writes border cells only.
 __global__ void k_fill_borders(float *p0, float *p1, int nfields, int nrows, int ncols,

@@ -1,0 +1,68 @@
+"""GPU: the persistent exact-order kernel (one launch, progress counters, write-through hand-off) against the
+oracle, bit for bit, forced on with PDEIP_EXACT_PERSIST=1 -- small/odd/large frames, NaN-laced data, every
+5-point model, multi-frame -- and its abort word stays clear.  Also the automatic policy (iter >= 8)."""
+import os
+
+import numpy as np
+import pytest
+
+import problems as pb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def persist_on():
+    old = os.environ.get("PDEIP_EXACT_PERSIST")
+    os.environ["PDEIP_EXACT_PERSIST"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("PDEIP_EXACT_PERSIST", None)
+    else:
+        os.environ["PDEIP_EXACT_PERSIST"] = old
+
+
+def _ok(pdeip):
+    assert pdeip.capi.load().pdeip_persist_error() == 0, pdeip.capi.last_error()
+
+
+@pytest.mark.parametrize("shape", [(32, 48), (97, 131), (64, 200), (131, 70), (3, 3), (5, 300), (260, 7), (388, 584), (1080, 1920)])
+def test_persistent_elin4(pdeip, oracle, persist_on, shape):
+    pdeip.mex_api.set_mode(0)
+    for it in (1, 4, 9):
+        p = pb.elin4(811, *shape, nan_frac=0.01)
+        got = pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(it), np.float32(1.9), np.float32(1))
+        assert pdeip.capi.load().pdeip_last_launch_count() <= 3  # derive + one persistent launch + border fill
+        _ok(pdeip)
+        want = oracle.Oflow_sor_elin4_2d(*p.values(), it, 1.9)
+        for g, w in zip(got, want):
+            assert pb.bit_equal(g, w), "elin4 %s it=%d: %s" % (shape, it, pb.describe_mismatch(g, w))
+
+
+@pytest.mark.parametrize("shape", [(97, 131), (388, 584), (70, 1000)])
+def test_persistent_other_models(pdeip, oracle, persist_on, shape):
+    api = pdeip.mex_api
+    api.set_mode(0)
+    q = pb.llin4(821, *shape, nan_frac=0.02)
+    for g, w in zip(api.Oflow_sor_llin4_2d(*q.values(), np.float32(5), np.float32(1.9), np.float32(1)), oracle.Oflow_sor_llin4_2d(*q.values(), 5, 1.9)):
+        assert pb.bit_equal(g, w)
+    d = pb.disp4(822, *shape, nan_frac=0.02)
+    assert pb.bit_equal(api.Disp_sor_llin4_2d(*d.values(), np.float32(6), np.float32(1.9), np.float32(1)), oracle.Disp_sor_llin4_2d(*d.values(), 6, 1.9))
+    e = pb.pde4(823, *shape, nframes=3, nan_frac=0.02)
+    assert pb.bit_equal(api.PDEsolver4(*e.values(), np.float32(5), np.float32(1.75), np.float32(1)), oracle.PDEsolver4(*e.values(), 5, 1.75))
+    _ok(pdeip)
+
+
+def test_auto_policy_uses_persistent_for_long_calls(pdeip, oracle):
+    """Without the override, iter >= 8 takes the persistent kernel (few launches), iter < 8 one launch per front."""
+    os.environ.pop("PDEIP_EXACT_PERSIST", None)
+    pdeip.mex_api.set_mode(0)
+    p = pb.elin4(831, 388, 584)
+    lib = pdeip.capi.load()
+    got = pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(20), np.float32(1.9), np.float32(1))
+    assert lib.pdeip_last_launch_count() <= 3
+    _ok(pdeip)
+    for g, w in zip(got, oracle.Oflow_sor_elin4_2d(*p.values(), 20, 1.9)):
+        assert pb.bit_equal(g, w)
+    pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(4), np.float32(1.9), np.float32(1))
+    assert lib.pdeip_last_launch_count() > 10
