@@ -188,6 +188,15 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e_bytes / e_launch_s / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": None, "launch_us": round(e_launch_s * 1e6, 2)},
         }
+        # the same frame with iter=20 per call (the Horn-Schunck driver's setting): the persistent kernel
+        def step_exact20():
+            dev.oflow_sor_elin4(Ue, Ve, *coef_full, 20, OMEGA, capi.MODE_EXACT_ORDER)
+
+        l_steps = max(3, args.steps // 40)
+        ldt, _, _ = timed(step_exact20, l_steps, 1)
+        out["exact_order"]["iter20_per_call"] = {"value": round(l_steps * 20 / ldt, 2), "unit": "iterations/s",
+                                                 "ms_per_call": round(ldt / l_steps * 1e3, 4), "kernel": "k_sor_exact_persist<ModelElin4>"}
+        capi.call("pdeip_persist_error")
         # ---- CPU baseline + parity of the first call -----------------------------------------------
         if args.cpu_calls > 0:
             cpu_rate, first = cpu_baseline(U0, V0, coef_full, args.cpu_calls)

@@ -35,6 +35,7 @@ struct Context {
     void *ws[WS_NSLOT] = {};
     size_t ws_bytes[WS_NSLOT] = {};
     int order_B = 0, order_T = 0; // shape of the cached persistent-kernel schedule table
+    bool persist_used = false;    // a persistent launch happened since the last pdeip_persist_error()
     int rb_tj = 0; // columns per red-black unit (0 = default)
     // sweep-kernel timing (pdeip_profile_*)
     bool profile = false;
@@ -219,6 +220,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sor_exact_persist<Mdl>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
                 plds_opt_in = true;
             }
+            g.persist_used = true;
             SweepTimer timer(s);
             hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(B * iter * nframes)), dim3(128), plds, s, P, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
             timer.stop(1);
@@ -378,7 +380,8 @@ extern "C" int pdeip_release(void)
 extern "C" int pdeip_last_launch_count(void) { return g.last_launches; }
 extern "C" int pdeip_persist_error(void)
 { // waits for the device, then reports whether a bounded spin of the persistent kernel timed out
-    if (!g.ws[WS_CTL]) return PDEIP_OK;
+    if (!g.ws[WS_CTL] || !g.persist_used) return PDEIP_OK;
+    g.persist_used = false;
     unsigned words[2] = {0, 0};
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(words, g.ws[WS_CTL], sizeof words, hipMemcpyDeviceToHost));
@@ -704,6 +707,7 @@ static int oflow_sor_host(const char *who, bool llin, bool fill_residuals, const
             RC(pdeip_oflow_sor_elin4_dev(nullptr, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
         RC(download(o0, do0, n));
         RC(download(o1, do1, n));
+        RC(pdeip_persist_error());
     } else { // outputs stay as mxCreateNumericArray made them: zero
         memset(o0, 0, n * sizeof(float));
         memset(o1, 0, n * sizeof(float));
@@ -829,6 +833,7 @@ extern "C" int pdeip_disp_sor_llin4(const float *U, const float *dU, const float
     RC(upload(dwW, wW, n)); RC(upload(dwN, wN, n)); RC(upload(dwE, wE, n)); RC(upload(dwS, wS, n));
     RC(pdeip_disp_sor_llin4_dev(nullptr, dUin, ddU, dCu, dDu, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
     RC(download(dU_out, ddU, n));
+    RC(pdeip_persist_error());
     return PDEIP_OK;
 }
 
@@ -857,6 +862,7 @@ extern "C" int pdeip_pde_sor4(const float *X, const float *TRACE, const float *B
     RC(upload(dwW, wW, nf)); RC(upload(dwN, wN, nf)); RC(upload(dwE, wE, nf)); RC(upload(dwS, wS, nf));
     RC(pdeip_pde_sor4_dev(nullptr, dX, dT, dB, dwW, dwN, dwE, dwS, nrows, ncols, nframes, iter, omega, g.mode, 0));
     RC(download(X_out, dX, nf));
+    RC(pdeip_persist_error());
     return PDEIP_OK;
 }
 
