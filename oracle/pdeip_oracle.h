@@ -113,6 +113,40 @@ void orc_fst_derivatives5(float *Idt, float *Idx, float *Idy, const float *It0, 
 void orc_snd_derivatives5(float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy,
                           const float *It0, const float *It1, int nrows, int ncols, int nframes);
 
+/* ---- alternating line relaxation, solver = 2 of the gateways (pdeip_oracle_alr.c) ---------------------
+ * `order`: ORC_ORDER_LEX = the reference's line order; ORC_ORDER_COLOUR = zebra (even lines, then odd
+ * lines) with the same per-line arithmetic. */
+
+/* opticalflowSolvers.c:196-262 (GS_ALR_SOR_elin4_2d) + line solvers :1763-2410; U,V in place. */
+void orc_oflow_alr_elin4(float *U, float *V, const float *M, const float *Cu, const float *Cv, const float *Du,
+                         const float *Dv, const float *wW, const float *wN, const float *wE, const float *wS,
+                         int nrows, int ncols, int iter, float omega, int order);
+
+/* opticalflowSolvers.c:690-759 (GS_ALR_SOR_llin4_2d) + :2415-3100; dU,dV in place. */
+void orc_oflow_alr_llin4(const float *U, const float *V, float *dU, float *dV, const float *M, const float *Cu,
+                         const float *Cv, const float *Du, const float *Dv, const float *wW, const float *wN,
+                         const float *wE, const float *wS, int nrows, int ncols, int iter, float omega, int order);
+
+/* opticalflowSolvers.c:1677-1750 (GS_ALR_SOR_llin8_2d) + :3104-3914: the only place the diagonal weights act. */
+void orc_oflow_alr_llin8(const float *U, const float *V, float *dU, float *dV, const float *M, const float *Cu,
+                         const float *Cv, const float *Du, const float *Dv, const float *wW, const float *wNW,
+                         const float *wN, const float *wNE, const float *wE, const float *wSE, const float *wS,
+                         const float *wSW, int nrows, int ncols, int iter, float omega, int order);
+
+/* disparitySolvers.c:154-211 (GS_ALR_SOR_llin4_2d) + :1376-2029. */
+void orc_disp_alr_llin4(const float *U, float *dU, const float *Cu, const float *Du, const float *wW,
+                        const float *wN, const float *wE, const float *wS, int nrows, int ncols, int iter,
+                        float omega, int order);
+
+/* pdeSolvers.c:277-335 (GS_ALR_SOR_4_2d) + :409-1131. */
+void orc_pde_alr4(float *X, const float *TRACE, const float *B, const float *wW, const float *wN, const float *wE,
+                  const float *wS, int nrows, int ncols, int nframes, int iter, float omega, int order);
+
+/* pdeSolvers.c:344-402 (GS_ALR_SOR_8_2d) + :1132-1393: ONE iteration whatever `iter` says, interior lines only. */
+void orc_pde_alr8(float *X, const float *TRACE, const float *B, const float *wW, const float *wNW, const float *wN,
+                  const float *wNE, const float *wE, const float *wSE, const float *wS, const float *wSW, int nrows,
+                  int ncols, int nframes, int iter, float omega, int order);
+
 #ifdef __cplusplus
 }
 #endif

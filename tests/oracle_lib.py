@@ -34,12 +34,18 @@ _SIGS = {
     "orc_warp_bilinear": [_P] * 4 + [_I, _I, _I],
     "orc_fst_derivatives5": [_P] * 5 + [_I, _I, _I],
     "orc_snd_derivatives5": [_P] * 7 + [_I, _I, _I],
+    "orc_oflow_alr_elin4": [_P] * 11 + [_I, _I, _I, _F, _I],
+    "orc_oflow_alr_llin4": [_P] * 13 + [_I, _I, _I, _F, _I],
+    "orc_oflow_alr_llin8": [_P] * 17 + [_I, _I, _I, _F, _I],
+    "orc_disp_alr_llin4": [_P] * 8 + [_I, _I, _I, _F, _I],
+    "orc_pde_alr4": [_P] * 7 + [_I, _I, _I, _I, _F, _I],
+    "orc_pde_alr8": [_P] * 11 + [_I, _I, _I, _I, _F, _I],
 }
 _lib = None
 
 
 def build(force=False):
-    src = [os.path.join(ORACLE_DIR, f) for f in ("pdeip_oracle.c", "pdeip_oracle.h", "Makefile")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("pdeip_oracle.c", "pdeip_oracle_alr.c", "pdeip_oracle.h", "Makefile")]
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
     if stale:
         subprocess.run(["make", "-C", ORACLE_DIR, "-B", "liboracle.so"], check=True, stdout=subprocess.DEVNULL)
@@ -159,13 +165,60 @@ def warp_bilinear(Iin, X, Y):
     return out
 
 
+# ---- alternating line relaxation (solver = 2), library level ----------------------------------------
+
+def oflow_alr_elin4(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, omega, order=LEX):
+    U, V = F(U), F(V)
+    ins = [F(a) for a in (M, Cu, Cv, Du, Dv, wW, wN, wE, wS)]
+    lib().orc_oflow_alr_elin4(_p(U), _p(V), *[_p(a) for a in ins], U.shape[0], U.shape[1], int(it), float(omega), order)
+    return U, V
+
+
+def oflow_alr_llin4(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, omega, order=LEX):
+    U, V, dU, dV = F(U), F(V), F(dU), F(dV)
+    ins = [F(a) for a in (M, Cu, Cv, Du, Dv, wW, wN, wE, wS)]
+    lib().orc_oflow_alr_llin4(_p(U), _p(V), _p(dU), _p(dV), *[_p(a) for a in ins], U.shape[0], U.shape[1], int(it),
+                              float(omega), order)
+    return dU, dV
+
+
+def oflow_alr_llin8(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wNW, wN, wNE, wE, wSE, wS, wSW, it, omega, order=LEX):
+    U, V, dU, dV = F(U), F(V), F(dU), F(dV)
+    ins = [F(a) for a in (M, Cu, Cv, Du, Dv, wW, wNW, wN, wNE, wE, wSE, wS, wSW)]
+    lib().orc_oflow_alr_llin8(_p(U), _p(V), _p(dU), _p(dV), *[_p(a) for a in ins], U.shape[0], U.shape[1], int(it),
+                              float(omega), order)
+    return dU, dV
+
+
+def disp_alr_llin4(U, dU, Cu, Du, wW, wN, wE, wS, it, omega, order=LEX):
+    U, dU = F(U), F(dU)
+    ins = [F(a) for a in (Cu, Du, wW, wN, wE, wS)]
+    lib().orc_disp_alr_llin4(_p(U), _p(dU), *[_p(a) for a in ins], U.shape[0], U.shape[1], int(it), float(omega), order)
+    return dU
+
+
+def pde_alr4(X, TRACE, B, wW, wN, wE, wS, it, omega, order=LEX):
+    X = F(X)
+    ins = [F(a) for a in (TRACE, B, wW, wN, wE, wS)]
+    lib().orc_pde_alr4(_p(X), *[_p(a) for a in ins], X.shape[0], X.shape[1], _frames(X), int(it), float(omega), order)
+    return X
+
+
+def pde_alr8(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, it, omega, order=LEX):
+    X = F(X)
+    ins = [F(a) for a in (TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW)]
+    lib().orc_pde_alr8(_p(X), *[_p(a) for a in ins], X.shape[0], X.shape[1], _frames(X), int(it), float(omega), order)
+    return X
+
+
 # ---- gateway-level wrappers (mexFunction semantics) ---------------------------------------------------
 
 def Oflow_sor_elin4_2d(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, omega, solver=1, nargout=2, order=LEX):
-    assert solver == 1
+    assert solver in (1, 2)
     if it > 0:  # Oflow_sor_elin4_2d.c:341-346
         M0, Cu0, Cv0, Du0, Dv0 = [a[..., 0] if np.ndim(a) == 3 else a for a in (M, Cu, Cv, Du, Dv)]
-        Uo, Vo = oflow_sor_elin4(U, V, M0, Cu0, Cv0, Du0, Dv0, wW, wN, wE, wS, it, omega, order)
+        fn = oflow_sor_elin4 if solver == 1 else oflow_alr_elin4
+        Uo, Vo = fn(U, V, M0, Cu0, Cv0, Du0, Dv0, wW, wN, wE, wS, it, omega, order)
     else:
         Uo, Vo = np.zeros_like(F(U)), np.zeros_like(F(V))
     if nargout >= 4:  # residuals of the input iterate (:349-350)
@@ -175,10 +228,11 @@ def Oflow_sor_elin4_2d(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, omega, solve
 
 def Oflow_sor_llin4_2d(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, omega, solver=1, nargout=2, order=LEX,
                        fill_residuals=True):
-    assert solver == 1
+    assert solver in (1, 2)
     if it > 0:  # Oflow_sor_llin4_2d.c:376-381
         M0, Cu0, Cv0, Du0, Dv0 = [a[..., 0] if np.ndim(a) == 3 else a for a in (M, Cu, Cv, Du, Dv)]
-        o0, o1 = oflow_sor_llin4(U, V, dU, dV, M0, Cu0, Cv0, Du0, Dv0, wW, wN, wE, wS, it, omega, order)
+        fn = oflow_sor_llin4 if solver == 1 else oflow_alr_llin4
+        o0, o1 = fn(U, V, dU, dV, M0, Cu0, Cv0, Du0, Dv0, wW, wN, wE, wS, it, omega, order)
     else:
         o0, o1 = np.zeros_like(F(dU)), np.zeros_like(F(dV))
     if nargout >= 4:
@@ -190,25 +244,36 @@ def Oflow_sor_llin4_2d(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, omeg
 
 def Oflow_sor_llin8_2d(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wNW, wN, wNE, wE, wSE, wS, wSW, it, omega, solver=1,
                        nargout=2, order=LEX):
-    # diagonal weights unused by the point solver; residual outputs never filled (Oflow_sor_llin8_2d.c:466-488)
+    # residual outputs never filled (Oflow_sor_llin8_2d.c:466-488)
+    if solver == 2:  # the line solvers are the only place the diagonal weights act
+        if it > 0:
+            M0, Cu0, Cv0, Du0, Dv0 = [a[..., 0] if np.ndim(a) == 3 else a for a in (M, Cu, Cv, Du, Dv)]
+            o0, o1 = oflow_alr_llin8(U, V, dU, dV, M0, Cu0, Cv0, Du0, Dv0, wW, wNW, wN, wNE, wE, wSE, wS, wSW, it, omega, order)
+        else:
+            o0, o1 = np.zeros_like(F(dU)), np.zeros_like(F(dV))
+        return (o0, o1) if nargout < 4 else (o0, o1, np.zeros_like(F(M)), np.zeros_like(F(M)))
+    # diagonal weights unused by the point solver
     return Oflow_sor_llin4_2d(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, omega, solver, nargout, order,
                               fill_residuals=False)
 
 
 def Disp_sor_llin4_2d(U, dU, Cu, Du, wW, wN, wE, wS, it, omega, solver=1, nargout=1, order=LEX):
-    assert solver == 1
-    out = disp_sor_llin4(U, dU, Cu, Du, wW, wN, wE, wS, it, omega, order) if it > 0 else np.zeros_like(F(dU))
+    assert solver in (1, 2)
+    fn = disp_sor_llin4 if solver == 1 else disp_alr_llin4
+    out = fn(U, dU, Cu, Du, wW, wN, wE, wS, it, omega, order) if it > 0 else np.zeros_like(F(dU))
     return out if nargout < 2 else (out, np.zeros_like(F(U)))  # RU allocated, never computed
 
 
 def PDEsolver4(X, TRACE, B, wW, wN, wE, wS, it, omega, solver=1, order=LEX):
-    assert solver == 1
-    return pde_sor4(X, TRACE, B, wW, wN, wE, wS, max(int(it), 0), omega, order)
+    assert solver in (1, 2)
+    fn = pde_sor4 if solver == 1 else pde_alr4
+    return fn(X, TRACE, B, wW, wN, wE, wS, max(int(it), 0), omega, order)
 
 
 def PDEsolver8(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, it, omega, solver=1, order=LEX):
-    assert solver == 1
-    return pde_sor8(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, max(int(it), 0), omega, order)
+    assert solver in (1, 2)
+    fn = pde_sor8 if solver == 1 else pde_alr8  # ALR-8 runs exactly one iteration whatever `it` is (pdeSolvers.c:362)
+    return fn(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, max(int(it), 0), omega, order)
 
 
 def DdiffWeights(D, eps):
