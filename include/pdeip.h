@@ -44,7 +44,8 @@ extern "C" {
 #define PDEIP_OK 0
 #define PDEIP_ERR_ARG 1         /* null pointer, nrows/ncols < 3, nframes < 1 */
 #define PDEIP_ERR_SOLVER 2      /* "no such solver" (gateway default: branch) */
-#define PDEIP_ERR_UNSUPPORTED 3 /* solver 2 (alternating line relaxation) has no device path yet */
+#define PDEIP_ERR_UNSUPPORTED 3 /* valid request outside what the device path covers (e.g. an exact-order ALR line
+                                    longer than 10000 pixels) */
 #define PDEIP_ERR_DEVICE 4      /* HIP runtime error / no gfx950 device */
 #define PDEIP_ERR_NOMEM 5
 
@@ -203,6 +204,35 @@ int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, const float *
                        const float *wNW, const float *wN, const float *wNE, const float *wE,
                        const float *wSE, const float *wS, const float *wSW, int nrows, int ncols,
                        int nframes, int iter, float omega, int mode, int col0);
+/* Alternating line relaxation, solver = 2 of the gateways (GS_ALR_SOR_*: opticalflowSolvers.c:196,690,1677;
+ * disparitySolvers.c:154; pdeSolvers.c:277,344).  Iterate planes in place.
+ *   mode PDEIP_MODE_EXACT_ORDER: the reference's line order, bit-identical, inherently serial (one
+ *        workgroup per frame; a line must fit in LDS: at most 10000 pixels per line).
+ *   mode PDEIP_MODE_RED_BLACK:   zebra order (even lines, then odd lines), lines solved concurrently.
+ * pdeip_pde_alr8_dev runs ONE iteration whatever `iter` is, like the reference (pdeSolvers.c:362). */
+int pdeip_oflow_alr_elin4_dev(void *stream, float *U, float *V, const float *M, const float *Cu,
+                              const float *Cv, const float *Du, const float *Dv, const float *wW,
+                              const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                              int iter, float omega, int mode);
+int pdeip_oflow_alr_llin4_dev(void *stream, const float *U, const float *V, float *dU, float *dV,
+                              const float *M, const float *Cu, const float *Cv, const float *Du,
+                              const float *Dv, const float *wW, const float *wN, const float *wE,
+                              const float *wS, int nrows, int ncols, int iter, float omega, int mode);
+int pdeip_oflow_alr_llin8_dev(void *stream, const float *U, const float *V, float *dU, float *dV,
+                              const float *M, const float *Cu, const float *Cv, const float *Du,
+                              const float *Dv, const float *wW, const float *wNW, const float *wN,
+                              const float *wNE, const float *wE, const float *wSE, const float *wS,
+                              const float *wSW, int nrows, int ncols, int iter, float omega, int mode);
+int pdeip_disp_alr_llin4_dev(void *stream, const float *U, float *dU, const float *Cu, const float *Du,
+                             const float *wW, const float *wN, const float *wE, const float *wS,
+                             int nrows, int ncols, int iter, float omega, int mode);
+int pdeip_pde_alr4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
+                       const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                       int nframes, int iter, float omega, int mode);
+int pdeip_pde_alr8_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
+                       const float *wNW, const float *wN, const float *wNE, const float *wE,
+                       const float *wSE, const float *wS, const float *wSW, int nrows, int ncols,
+                       int nframes, int iter, float omega, int mode);
 int pdeip_oflow_res_elin4_dev(void *stream, float *RU, float *RV, const float *U, const float *V,
                               const float *M, const float *Cu, const float *Cv, const float *Du,
                               const float *Dv, const float *wW, const float *wN, const float *wE,

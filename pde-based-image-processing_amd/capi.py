@@ -56,6 +56,12 @@ SIGNATURES = {
     "pdeip_disp_sor_llin4_dev": _sig(1 + 8, [_I, _I, _I, _F, _I, _I]),
     "pdeip_pde_sor4_dev": _sig(1 + 7, [_I, _I, _I, _I, _F, _I, _I]),
     "pdeip_pde_sor8_dev": _sig(1 + 11, [_I, _I, _I, _I, _F, _I, _I]),
+    "pdeip_oflow_alr_elin4_dev": _sig(1 + 11, [_I, _I, _I, _F, _I]),
+    "pdeip_oflow_alr_llin4_dev": _sig(1 + 13, [_I, _I, _I, _F, _I]),
+    "pdeip_oflow_alr_llin8_dev": _sig(1 + 17, [_I, _I, _I, _F, _I]),
+    "pdeip_disp_alr_llin4_dev": _sig(1 + 8, [_I, _I, _I, _F, _I]),
+    "pdeip_pde_alr4_dev": _sig(1 + 7, [_I, _I, _I, _I, _F, _I]),
+    "pdeip_pde_alr8_dev": _sig(1 + 11, [_I, _I, _I, _I, _F, _I]),
     "pdeip_oflow_res_elin4_dev": _sig(1 + 13, [_I, _I, _I]),
     "pdeip_oflow_lhs_elin4_dev": _sig(1 + 11, [_I, _I, _I]),
     "pdeip_oflow_res_llin4_dev": _sig(1 + 15, [_I, _I, _I]),

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <vector>
 
+#include "pdeip_alr.hpp"
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
 #include "pdeip_sor_exact.hpp"
@@ -126,10 +127,7 @@ int check_mode(const char *who, int mode)
 // The gateways' solver switch (e.g. Oflow_sor_elin4_2d.c:328-338).
 int check_solver(const char *who, int solver)
 {
-    if (solver == PDEIP_SOLVER_SOR) return PDEIP_OK;
-    if (solver == PDEIP_SOLVER_ALR)
-        return set_err(PDEIP_ERR_UNSUPPORTED,
-                       "%s: solver 2 (alternating line relaxation) has no device implementation; use solver 1", who);
+    if (solver == PDEIP_SOLVER_SOR || solver == PDEIP_SOLVER_ALR) return PDEIP_OK;
     return set_err(PDEIP_ERR_SOLVER, "%s: no such solver", who);
 }
 
@@ -564,6 +562,176 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
     return PDEIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// alternating line relaxation (solver 2): pdeip_alr.hpp
+// ------------------------------------------------------------------------------------------------
+constexpr int ALR_LEX_MAX_LINE = 10000; // one float4 per line element in LDS (160 KB per workgroup)
+
+// One direction of one field: all lines, in the reference's order (EXACT_ORDER) or zebra (RED_BLACK).
+template <class Mdl>
+static int alr_pass(const char *who, hipStream_t s, const typename Mdl::Ctx &q, float *x, int nrows, int ncols,
+                    int nframes, bool vertical, float omega, int mode)
+{
+    const int lo = Mdl::INTERIOR_LINES ? 1 : 0;
+    const int hi = (vertical ? ncols : nrows) - 1 - lo;
+    const int n = vertical ? nrows : ncols;
+    const size_t fs = (size_t)nrows * ncols;
+    if (mode == PDEIP_MODE_EXACT_ORDER) {
+        if (n > ALR_LEX_MAX_LINE)
+            return set_err(PDEIP_ERR_UNSUPPORTED, "%s: exact-order line relaxation holds one line in LDS: at most %d pixels per line (got %d)",
+                           who, ALR_LEX_MAX_LINE, n);
+        const size_t lds = (size_t)n * sizeof(float4);
+        static size_t lds_set = 0;
+        if (lds > 64 * 1024 && lds > lds_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_alr_lex<Mdl>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set = lds;
+        }
+        hipLaunchKernelGGL(k_alr_lex<Mdl>, dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), lds, s, q, x, nrows, ncols, fs,
+                           vertical ? 1 : 0, lo, hi, omega);
+        g.last_launches++;
+    } else {
+        float *cp, *dp;
+        RC(ws_get(WS_AUX0, fs * nframes * sizeof(float), &cp));
+        RC(ws_get(WS_AUX1, fs * nframes * sizeof(float), &dp));
+        for (int colour = 0; colour < 2; colour++) {
+            const int first = lo + (((lo & 1) != colour) ? 1 : 0);
+            if (first > hi) continue;
+            const int count = (hi - first) / 2 + 1;
+            hipLaunchKernelGGL(k_alr_zebra<Mdl>, dim3((unsigned)((count + 63) / 64), (unsigned)nframes), dim3(64), 0, s, q, x, cp, dp,
+                               nrows, ncols, fs, vertical ? 1 : 0, lo, hi, colour, omega);
+            g.last_launches++;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_alr_elin4_dev(void *stream, float *U, float *V, const float *M, const float *Cu,
+                                         const float *Cv, const float *Du, const float *Dv, const float *wW,
+                                         const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                                         int iter, float omega, int mode)
+{
+    const char *who = "pdeip_oflow_alr_elin4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    g.last_launches = 0;
+    const AlrElin4::Ctx qu{U, V, M, Cu, Du, wW, wN, wE, wS}, qv{V, U, M, Cv, Dv, wW, wN, wE, wS};
+    SweepTimer timer(s);
+    for (int it = 0; it < iter; it++) { // opticalflowSolvers.c:231-258: columns U then V, rows V then U
+        RC(alr_pass<AlrElin4>(who, s, qu, U, nrows, ncols, 1, true, omega, mode));
+        RC(alr_pass<AlrElin4>(who, s, qv, V, nrows, ncols, 1, true, omega, mode));
+        RC(alr_pass<AlrElin4>(who, s, qv, V, nrows, ncols, 1, false, omega, mode));
+        RC(alr_pass<AlrElin4>(who, s, qu, U, nrows, ncols, 1, false, omega, mode));
+    }
+    timer.stop(iter > 0 ? iter : 1);
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_alr_llin4_dev(void *stream, const float *U, const float *V, float *dU, float *dV,
+                                         const float *M, const float *Cu, const float *Cv, const float *Du,
+                                         const float *Dv, const float *wW, const float *wN, const float *wE,
+                                         const float *wS, int nrows, int ncols, int iter, float omega, int mode)
+{
+    const char *who = "pdeip_oflow_alr_llin4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    g.last_launches = 0;
+    const AlrLlin4::Ctx qu{U, dU, dV, M, Cu, Du, wW, wN, wE, wS}, qv{V, dV, dU, M, Cv, Dv, wW, wN, wE, wS};
+    SweepTimer timer(s);
+    for (int it = 0; it < iter; it++) { // :728-755
+        RC(alr_pass<AlrLlin4>(who, s, qu, dU, nrows, ncols, 1, true, omega, mode));
+        RC(alr_pass<AlrLlin4>(who, s, qv, dV, nrows, ncols, 1, true, omega, mode));
+        RC(alr_pass<AlrLlin4>(who, s, qv, dV, nrows, ncols, 1, false, omega, mode));
+        RC(alr_pass<AlrLlin4>(who, s, qu, dU, nrows, ncols, 1, false, omega, mode));
+    }
+    timer.stop(iter > 0 ? iter : 1);
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_alr_llin8_dev(void *stream, const float *U, const float *V, float *dU, float *dV,
+                                         const float *M, const float *Cu, const float *Cv, const float *Du,
+                                         const float *Dv, const float *wW, const float *wNW, const float *wN,
+                                         const float *wNE, const float *wE, const float *wSE, const float *wS,
+                                         const float *wSW, int nrows, int ncols, int iter, float omega, int mode)
+{
+    const char *who = "pdeip_oflow_alr_llin8_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    g.last_launches = 0;
+    const AlrLlin8::Ctx qu{U, dU, dV, M, Cu, Du, {wN, wS, wE, wW, wNW, wNE, wSW, wSE}};
+    const AlrLlin8::Ctx qv{V, dV, dU, M, Cv, Dv, {wN, wS, wE, wW, wNW, wNE, wSW, wSE}};
+    SweepTimer timer(s);
+    for (int it = 0; it < iter; it++) { // :1718-1746
+        RC(alr_pass<AlrLlin8>(who, s, qu, dU, nrows, ncols, 1, true, omega, mode));
+        RC(alr_pass<AlrLlin8>(who, s, qv, dV, nrows, ncols, 1, true, omega, mode));
+        RC(alr_pass<AlrLlin8>(who, s, qv, dV, nrows, ncols, 1, false, omega, mode));
+        RC(alr_pass<AlrLlin8>(who, s, qu, dU, nrows, ncols, 1, false, omega, mode));
+    }
+    timer.stop(iter > 0 ? iter : 1);
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_disp_alr_llin4_dev(void *stream, const float *U, float *dU, const float *Cu, const float *Du,
+                                        const float *wW, const float *wN, const float *wE, const float *wS,
+                                        int nrows, int ncols, int iter, float omega, int mode)
+{
+    const char *who = "pdeip_disp_alr_llin4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    g.last_launches = 0;
+    const AlrLlin4::Ctx q{U, dU, nullptr, nullptr, Cu, Du, wW, wN, wE, wS};
+    SweepTimer timer(s);
+    for (int it = 0; it < iter; it++) { // disparitySolvers.c:186-204
+        RC(alr_pass<AlrLlin4>(who, s, q, dU, nrows, ncols, 1, true, omega, mode));
+        RC(alr_pass<AlrLlin4>(who, s, q, dU, nrows, ncols, 1, false, omega, mode));
+    }
+    timer.stop(iter > 0 ? iter : 1);
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_pde_alr4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
+                                  const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                                  int nframes, int iter, float omega, int mode)
+{
+    const char *who = "pdeip_pde_alr4_dev";
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    g.last_launches = 0;
+    const AlrPde4::Ctx q{X, TRACE, B, wW, wN, wE, wS};
+    SweepTimer timer(s);
+    for (int it = 0; it < iter; it++) { // pdeSolvers.c:308-327; frames are independent
+        RC(alr_pass<AlrPde4>(who, s, q, X, nrows, ncols, nframes, true, omega, mode));
+        RC(alr_pass<AlrPde4>(who, s, q, X, nrows, ncols, nframes, false, omega, mode));
+    }
+    timer.stop(iter > 0 ? iter : 1);
+    return PDEIP_OK;
+}
+
+// One iteration whatever `iter` says (pdeSolvers.c:362), interior columns then interior rows.
+extern "C" int pdeip_pde_alr8_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
+                                  const float *wNW, const float *wN, const float *wNE, const float *wE,
+                                  const float *wSE, const float *wS, const float *wSW, int nrows, int ncols,
+                                  int nframes, int iter, float omega, int mode)
+{
+    const char *who = "pdeip_pde_alr8_dev";
+    (void)iter;
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    g.last_launches = 0;
+    const AlrPde8::Ctx q{X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW};
+    SweepTimer timer(s);
+    RC(alr_pass<AlrPde8>(who, s, q, X, nrows, ncols, nframes, true, omega, mode));
+    RC(alr_pass<AlrPde8>(who, s, q, X, nrows, ncols, nframes, false, omega, mode));
+    timer.stop(1);
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_oflow_res_elin4_dev(void *stream, float *RU, float *RV, const float *U, const float *V,
                                          const float *M, const float *Cu, const float *Cv, const float *Du,
                                          const float *Dv, const float *wW, const float *wN, const float *wE,
@@ -673,7 +841,7 @@ static int oflow_sor_host(const char *who, bool llin, bool fill_residuals, const
                           const float *dU, const float *dV, const float *M, const float *Cu, const float *Cv,
                           const float *Du, const float *Dv, const float *wW, const float *wN, const float *wE,
                           const float *wS, int nrows, int ncols, int F, int iter, float omega, int solver,
-                          float *o0, float *o1, float *RU, float *RV)
+                          float *o0, float *o1, float *RU, float *RV, const float *const *diag = nullptr)
 {
     NONNULL(who, U); NONNULL(who, V); NONNULL(who, M); NONNULL(who, Cu); NONNULL(who, Cv); NONNULL(who, Du);
     NONNULL(who, Dv); NONNULL(who, wW); NONNULL(who, wN); NONNULL(who, wE); NONNULL(who, wS);
@@ -687,8 +855,16 @@ static int oflow_sor_host(const char *who, bool llin, bool fill_residuals, const
     const size_t n = (size_t)nrows * ncols, nf = n * (size_t)F;
 
     Arena ar;
-    RC(ar.init(pad4(n) * 12 + pad4(nf) * 7));
+    RC(ar.init(pad4(n) * 16 + pad4(nf) * 7));
     float *dUin = ar.take(n), *dVin = ar.take(n), *ddU = ar.take(n), *ddV = ar.take(n);
+    float *ddiag[4] = {nullptr, nullptr, nullptr, nullptr}; // wNW, wNE, wSE, wSW: only the line solvers read them
+    if (diag && solver == PDEIP_SOLVER_ALR)
+        for (int k = 0; k < 4; k++) {
+            ddiag[k] = ar.take(n);
+            RC(upload(ddiag[k], diag[k], n));
+        }
+    else
+        diag = nullptr;
     float *dM = ar.take(nf), *dCu = ar.take(nf), *dCv = ar.take(nf), *dDu = ar.take(nf), *dDv = ar.take(nf);
     float *dwW = ar.take(n), *dwN = ar.take(n), *dwE = ar.take(n), *dwS = ar.take(n);
     float *do0 = ar.take(n), *do1 = ar.take(n), *dRU = ar.take(nf), *dRV = ar.take(nf);
@@ -701,7 +877,13 @@ static int oflow_sor_host(const char *who, bool llin, bool fill_residuals, const
     if (iter > 0) { // copy the iterate in, relax it in place (Oflow_sor_elin4_2d.c:341-346)
         HIPCHK(hipMemcpyAsync(do0, llin ? ddU : dUin, n * sizeof(float), hipMemcpyDeviceToDevice, 0));
         HIPCHK(hipMemcpyAsync(do1, llin ? ddV : dVin, n * sizeof(float), hipMemcpyDeviceToDevice, 0));
-        if (llin)
+        if (solver == PDEIP_SOLVER_ALR && diag)
+            RC(pdeip_oflow_alr_llin8_dev(nullptr, dUin, dVin, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, ddiag[0], dwN, ddiag[1], dwE, ddiag[2], dwS, ddiag[3], nrows, ncols, iter, omega, g.mode));
+        else if (solver == PDEIP_SOLVER_ALR && llin)
+            RC(pdeip_oflow_alr_llin4_dev(nullptr, dUin, dVin, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode));
+        else if (solver == PDEIP_SOLVER_ALR)
+            RC(pdeip_oflow_alr_elin4_dev(nullptr, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode));
+        else if (llin)
             RC(pdeip_oflow_sor_llin4_dev(nullptr, dUin, dVin, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
         else
             RC(pdeip_oflow_sor_elin4_dev(nullptr, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
@@ -758,10 +940,11 @@ extern "C" int pdeip_oflow_sor_llin8(const float *U, const float *V, const float
 {
     const char *who = "Oflow_sor_llin8_2d";
     NONNULL(who, wNW); NONNULL(who, wNE); NONNULL(who, wSE); NONNULL(who, wSW);
-    // GS_SOR_llin8_2d never reads the diagonal weights (opticalflowSolvers.c:1550-1591), and the gateway
-    // leaves RU,RV unfilled (Oflow_sor_llin8_2d.c:466-488).
+    // GS_SOR_llin8_2d never reads the diagonal weights (opticalflowSolvers.c:1550-1591) -- only the line
+    // solvers do -- and the gateway leaves RU,RV unfilled (Oflow_sor_llin8_2d.c:466-488).
+    const float *diag[4] = {wNW, wNE, wSE, wSW};
     return oflow_sor_host(who, true, false, U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, nrows, ncols,
-                          nframes_coef, iter, omega, solver, dU_out, dV_out, RU, RV);
+                          nframes_coef, iter, omega, solver, dU_out, dV_out, RU, RV, diag);
 }
 
 static int oflow_lhs_host(const char *who, bool llin, const float *U, const float *V, const float *dU,
@@ -831,7 +1014,10 @@ extern "C" int pdeip_disp_sor_llin4(const float *U, const float *dU, const float
     float *dwW = ar.take(n), *dwN = ar.take(n), *dwE = ar.take(n), *dwS = ar.take(n);
     RC(upload(dUin, U, n)); RC(upload(ddU, dU, n)); RC(upload(dCu, Cu, n)); RC(upload(dDu, Du, n));
     RC(upload(dwW, wW, n)); RC(upload(dwN, wN, n)); RC(upload(dwE, wE, n)); RC(upload(dwS, wS, n));
-    RC(pdeip_disp_sor_llin4_dev(nullptr, dUin, ddU, dCu, dDu, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
+    if (solver == PDEIP_SOLVER_ALR)
+        RC(pdeip_disp_alr_llin4_dev(nullptr, dUin, ddU, dCu, dDu, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode));
+    else
+        RC(pdeip_disp_sor_llin4_dev(nullptr, dUin, ddU, dCu, dDu, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
     RC(download(dU_out, ddU, n));
     RC(pdeip_persist_error());
     return PDEIP_OK;
@@ -860,7 +1046,10 @@ extern "C" int pdeip_pde_sor4(const float *X, const float *TRACE, const float *B
     float *dwW = ar.take(nf), *dwN = ar.take(nf), *dwE = ar.take(nf), *dwS = ar.take(nf);
     RC(upload(dX, X, nf)); RC(upload(dT, TRACE, nf)); RC(upload(dB, B, nf));
     RC(upload(dwW, wW, nf)); RC(upload(dwN, wN, nf)); RC(upload(dwE, wE, nf)); RC(upload(dwS, wS, nf));
-    RC(pdeip_pde_sor4_dev(nullptr, dX, dT, dB, dwW, dwN, dwE, dwS, nrows, ncols, nframes, iter, omega, g.mode, 0));
+    if (solver == PDEIP_SOLVER_ALR)
+        RC(pdeip_pde_alr4_dev(nullptr, dX, dT, dB, dwW, dwN, dwE, dwS, nrows, ncols, nframes, iter, omega, g.mode));
+    else
+        RC(pdeip_pde_sor4_dev(nullptr, dX, dT, dB, dwW, dwN, dwE, dwS, nrows, ncols, nframes, iter, omega, g.mode, 0));
     RC(download(X_out, dX, nf));
     RC(pdeip_persist_error());
     return PDEIP_OK;
@@ -878,7 +1067,7 @@ extern "C" int pdeip_pde_sor8(const float *X, const float *TRACE, const float *B
     RC(check_solver(who, solver));
     RC(use_device());
     const size_t nf = (size_t)nrows * ncols * nframes;
-    if (iter <= 0) {
+    if (iter <= 0 && solver != PDEIP_SOLVER_ALR) { // GS_ALR_SOR_8_2d runs its one iteration regardless (pdeSolvers.c:362)
         memcpy(X_out, X, nf * sizeof(float));
         return PDEIP_OK;
     }
@@ -892,8 +1081,12 @@ extern "C" int pdeip_pde_sor8(const float *X, const float *TRACE, const float *B
         dw[k] = ar.take(nf);
         RC(upload(dw[k], hw[k], nf));
     }
-    RC(pdeip_pde_sor8_dev(nullptr, dX, dT, dB, dw[0], dw[1], dw[2], dw[3], dw[4], dw[5], dw[6], dw[7], nrows, ncols,
-                          nframes, iter, omega, g.mode, 0));
+    if (solver == PDEIP_SOLVER_ALR)
+        RC(pdeip_pde_alr8_dev(nullptr, dX, dT, dB, dw[0], dw[1], dw[2], dw[3], dw[4], dw[5], dw[6], dw[7], nrows, ncols,
+                              nframes, iter, omega, g.mode));
+    else
+        RC(pdeip_pde_sor8_dev(nullptr, dX, dT, dB, dw[0], dw[1], dw[2], dw[3], dw[4], dw[5], dw[6], dw[7], nrows, ncols,
+                              nframes, iter, omega, g.mode, 0));
     RC(download(X_out, dX, nf));
     return PDEIP_OK;
 }

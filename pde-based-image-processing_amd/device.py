@@ -84,6 +84,57 @@ def pde_sor8(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, iter, omega, mode=
               int(iter), float(omega), int(mode), int(col0))
 
 
+# ---- alternating line relaxation (solver 2); mode EXACT_ORDER = reference line order, RED_BLACK = zebra ----
+
+def oflow_alr_elin4(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER):
+    """In place on U, V (GS_ALR_SOR_elin4_2d, opticalflowSolvers.c:196)."""
+    _chk(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_oflow_alr_elin4_dev", _stream(), *_p(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS), nrows, ncols,
+              int(iter), float(omega), int(mode))
+
+
+def oflow_alr_llin4(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER):
+    """In place on dU, dV (GS_ALR_SOR_llin4_2d, opticalflowSolvers.c:690)."""
+    _chk(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_oflow_alr_llin4_dev", _stream(), *_p(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS), nrows,
+              ncols, int(iter), float(omega), int(mode))
+
+
+def oflow_alr_llin8(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wNW, wN, wNE, wE, wSE, wS, wSW, iter, omega,
+                    mode=capi.MODE_EXACT_ORDER):
+    """In place on dU, dV (GS_ALR_SOR_llin8_2d, opticalflowSolvers.c:1677)."""
+    _chk(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wNW, wN, wNE, wE, wSE, wS, wSW)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_oflow_alr_llin8_dev", _stream(), *_p(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wNW, wN, wNE, wE, wSE, wS, wSW),
+              nrows, ncols, int(iter), float(omega), int(mode))
+
+
+def disp_alr_llin4(U, dU, Cu, Du, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER):
+    """In place on dU (disparitySolvers.c:154)."""
+    _chk(U, dU, Cu, Du, wW, wN, wE, wS)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_disp_alr_llin4_dev", _stream(), *_p(U, dU, Cu, Du, wW, wN, wE, wS), nrows, ncols, int(iter),
+              float(omega), int(mode))
+
+
+def pde_alr4(X, TRACE, B, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER):
+    """In place on X (GS_ALR_SOR_4_2d, pdeSolvers.c:277)."""
+    _chk(X, TRACE, B, wW, wN, wE, wS)
+    nrows, ncols, F = _dims(X)
+    capi.call("pdeip_pde_alr4_dev", _stream(), *_p(X, TRACE, B, wW, wN, wE, wS), nrows, ncols, F, int(iter),
+              float(omega), int(mode))
+
+
+def pde_alr8(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, iter, omega, mode=capi.MODE_EXACT_ORDER):
+    """In place on X; one iteration whatever `iter` is (GS_ALR_SOR_8_2d, pdeSolvers.c:344)."""
+    _chk(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW)
+    nrows, ncols, F = _dims(X)
+    capi.call("pdeip_pde_alr8_dev", _stream(), *_p(X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW), nrows, ncols, F,
+              int(iter), float(omega), int(mode))
+
+
 def oflow_res_elin4(RU, RV, U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS):
     _chk(RU, RV, U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS)
     nrows, ncols, _ = _dims(U)

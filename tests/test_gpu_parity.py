@@ -149,8 +149,6 @@ def test_solver_errors(pdeip):
     p = pb.elin4(91, 16, 16)
     with pytest.raises(pdeip.mex_api.MexError, match="no such solver"):
         pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(1), np.float32(1.9), np.float32(7))
-    with pytest.raises(pdeip.mex_api.MexError, match="alternating line relaxation"):
-        pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(1), np.float32(1.9), np.float32(2))
     q = pb.pde4(92, 16, 16)
     with pytest.raises(pdeip.mex_api.MexError, match="no such solver"):
         pdeip.mex_api.PDEsolver4(*q.values(), np.float32(1), np.float32(1.9), np.float32(3))
