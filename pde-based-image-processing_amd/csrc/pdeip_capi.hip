@@ -26,7 +26,7 @@ using namespace pdeip;
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_CTL, WS_ORDER, WS_NSLOT };
+enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_CTL, WS_ORDER, WS_ALR, WS_NSLOT };
 
 struct Context {
     int device = 0;
@@ -567,42 +567,133 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
 // ------------------------------------------------------------------------------------------------
 constexpr int ALR_LEX_MAX_LINE = 10000; // one float4 per line element in LDS (160 KB per workgroup)
 
-// One direction of one field: all lines, in the reference's order (EXACT_ORDER) or zebra (RED_BLACK).
+static int check_alr_line(const char *who, int mode, int nrows, int ncols)
+{
+    const int n = nrows > ncols ? nrows : ncols;
+    if (mode == PDEIP_MODE_EXACT_ORDER && n > ALR_LEX_MAX_LINE)
+        return set_err(PDEIP_ERR_UNSUPPORTED, "%s: exact-order line relaxation holds one line in LDS: at most %d pixels per line (got %d)",
+                       who, ALR_LEX_MAX_LINE, n);
+    return PDEIP_OK;
+}
+
+// Workspace of one exact-order call: per (chain, direction) the cp and divisor planes of k_alr_factor.
+struct AlrFactors {
+    float *cp[2][2], *dv[2][2]; // [chain][vertical ? 0 : 1]
+};
+
 template <class Mdl>
-static int alr_pass(const char *who, hipStream_t s, const typename Mdl::Ctx &q, float *x, int nrows, int ncols,
-                    int nframes, bool vertical, float omega, int mode)
+static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, int nch, int nrows, int ncols, int nframes, AlrFactors *f)
+{
+    const size_t fs = (size_t)nrows * ncols, plane = fs * nframes;
+    float *base;
+    RC(ws_get(WS_ALR, plane * 8 * sizeof(float), &base));
+    const int lo = Mdl::INTERIOR_LINES ? 1 : 0;
+    for (int c = 0; c < nch; c++)
+        for (int d = 0; d < 2; d++) {
+            f->cp[c][d] = base + plane * (size_t)((c * 2 + d) * 2);
+            f->dv[c][d] = f->cp[c][d] + plane;
+            const int hi = (d == 0 ? ncols : nrows) - 1 - lo;
+            const dim3 grid((unsigned)((hi - lo + 1 + 63) / 64), (unsigned)nframes);
+            if (d == 0) hipLaunchKernelGGL((k_alr_factor<Mdl, true>), grid, dim3(64), 0, s, q[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
+            else hipLaunchKernelGGL((k_alr_factor<Mdl, false>), grid, dim3(64), 0, s, q[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
+            g.last_launches++;
+        }
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+// One direction, reference line order, for the `nch` fields in `order` (chain 1 trails chain 0 by a line).
+template <class Mdl>
+static int alr_lex_pass(hipStream_t s, const typename Mdl::Ctx *q, float *const *x, const AlrFactors &f, const int *order,
+                        int nch, int nrows, int ncols, int nframes, bool vertical, float omega)
 {
     const int lo = Mdl::INTERIOR_LINES ? 1 : 0;
     const int hi = (vertical ? ncols : nrows) - 1 - lo;
     const int n = vertical ? nrows : ncols;
     const size_t fs = (size_t)nrows * ncols;
-    if (mode == PDEIP_MODE_EXACT_ORDER) {
-        if (n > ALR_LEX_MAX_LINE)
-            return set_err(PDEIP_ERR_UNSUPPORTED, "%s: exact-order line relaxation holds one line in LDS: at most %d pixels per line (got %d)",
-                           who, ALR_LEX_MAX_LINE, n);
-        const size_t lds = (size_t)n * sizeof(float4);
-        static size_t lds_set = 0;
-        if (lds > 64 * 1024 && lds > lds_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_alr_lex<Mdl>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set = lds;
+    const int d = vertical ? 0 : 1;
+    const size_t line_bytes = (size_t)n * sizeof(float4);
+    if (nch == 2 && 2 * line_bytes <= 160 * 1024) {
+        AlrChains<Mdl, 2> ch;
+        for (int c = 0; c < 2; c++) ch.c[c] = AlrChain<Mdl>{q[order[c]], x[order[c]], f.cp[order[c]][d], f.dv[order[c]][d]};
+        static size_t lds_set[2] = {0, 0};
+        if (2 * line_bytes > 64 * 1024 && 2 * line_bytes > lds_set[d]) {
+            const void *fn = vertical ? reinterpret_cast<const void *>(&k_alr_lex<Mdl, 2, true>) : reinterpret_cast<const void *>(&k_alr_lex<Mdl, 2, false>);
+            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * line_bytes)));
+            lds_set[d] = 2 * line_bytes;
         }
-        hipLaunchKernelGGL(k_alr_lex<Mdl>, dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), lds, s, q, x, nrows, ncols, fs,
-                           vertical ? 1 : 0, lo, hi, omega);
+        if (vertical) hipLaunchKernelGGL((k_alr_lex<Mdl, 2, true>), dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), 2 * line_bytes, s, ch, nrows, ncols, fs, lo, hi, omega);
+        else hipLaunchKernelGGL((k_alr_lex<Mdl, 2, false>), dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), 2 * line_bytes, s, ch, nrows, ncols, fs, lo, hi, omega);
         g.last_launches++;
     } else {
-        float *cp, *dp;
-        RC(ws_get(WS_AUX0, fs * nframes * sizeof(float), &cp));
-        RC(ws_get(WS_AUX1, fs * nframes * sizeof(float), &dp));
-        for (int colour = 0; colour < 2; colour++) {
-            const int first = lo + (((lo & 1) != colour) ? 1 : 0);
-            if (first > hi) continue;
-            const int count = (hi - first) / 2 + 1;
-            hipLaunchKernelGGL(k_alr_zebra<Mdl>, dim3((unsigned)((count + 63) / 64), (unsigned)nframes), dim3(64), 0, s, q, x, cp, dp,
-                               nrows, ncols, fs, vertical ? 1 : 0, lo, hi, colour, omega);
+        static size_t lds_set[2] = {0, 0};
+        if (line_bytes > 64 * 1024 && line_bytes > lds_set[d]) {
+            const void *fn = vertical ? reinterpret_cast<const void *>(&k_alr_lex<Mdl, 1, true>) : reinterpret_cast<const void *>(&k_alr_lex<Mdl, 1, false>);
+            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_bytes));
+            lds_set[d] = line_bytes;
+        }
+        for (int c = 0; c < nch; c++) {
+            AlrChains<Mdl, 1> ch;
+            ch.c[0] = AlrChain<Mdl>{q[order[c]], x[order[c]], f.cp[order[c]][d], f.dv[order[c]][d]};
+            if (vertical) hipLaunchKernelGGL((k_alr_lex<Mdl, 1, true>), dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), line_bytes, s, ch, nrows, ncols, fs, lo, hi, omega);
+            else hipLaunchKernelGGL((k_alr_lex<Mdl, 1, false>), dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), line_bytes, s, ch, nrows, ncols, fs, lo, hi, omega);
             g.last_launches++;
         }
     }
     HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+// One direction of one field in zebra order: even lines, then odd lines, one lane per line.
+template <class Mdl>
+static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, int nrows, int ncols, int nframes, bool vertical,
+                          float omega)
+{
+    const int lo = Mdl::INTERIOR_LINES ? 1 : 0;
+    const int hi = (vertical ? ncols : nrows) - 1 - lo;
+    const size_t fs = (size_t)nrows * ncols;
+    float *cp, *dp;
+    RC(ws_get(WS_AUX0, fs * nframes * sizeof(float), &cp));
+    RC(ws_get(WS_AUX1, fs * nframes * sizeof(float), &dp));
+    for (int colour = 0; colour < 2; colour++) {
+        const int first = lo + (((lo & 1) != colour) ? 1 : 0);
+        if (first > hi) continue;
+        const int count = (hi - first) / 2 + 1;
+        const dim3 grid((unsigned)((count + 63) / 64), (unsigned)nframes);
+        if (vertical) hipLaunchKernelGGL((k_alr_zebra<Mdl, true>), grid, dim3(64), 0, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
+        else hipLaunchKernelGGL((k_alr_zebra<Mdl, false>), grid, dim3(64), 0, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
+        g.last_launches++;
+    }
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+// The iteration loop shared by every line-relaxation entry point.  q[c] / x[c]: context and iterate
+// plane of field c; the reference relaxes columns of field 0 then field 1, rows of field 1 then
+// field 0 (opticalflowSolvers.c:231-258); single-field solvers: columns, then rows.
+template <class Mdl>
+static int run_alr(const char *who, hipStream_t s, const typename Mdl::Ctx *q, float *const *x, int nch, int nrows, int ncols,
+                   int nframes, int iter, float omega, int mode)
+{
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(check_mode(who, mode));
+    RC(check_alr_line(who, mode, nrows, ncols));
+    g.last_launches = 0;
+    if (iter <= 0) return PDEIP_OK;
+    const int fwd[2] = {0, 1}, rev[2] = {1, 0};
+    AlrFactors f{};
+    if (mode == PDEIP_MODE_EXACT_ORDER) RC(alr_factor<Mdl>(s, q, nch, nrows, ncols, nframes, &f));
+    SweepTimer timer(s);
+    for (int it = 0; it < iter; it++) {
+        if (mode == PDEIP_MODE_EXACT_ORDER) {
+            RC(alr_lex_pass<Mdl>(s, q, x, f, fwd, nch, nrows, ncols, nframes, true, omega));
+            RC(alr_lex_pass<Mdl>(s, q, x, f, nch == 2 ? rev : fwd, nch, nrows, ncols, nframes, false, omega));
+        } else {
+            for (int c = 0; c < nch; c++) RC(alr_zebra_pass<Mdl>(s, q[c], x[c], nrows, ncols, nframes, true, omega));
+            for (int c = nch - 1; c >= 0; c--) RC(alr_zebra_pass<Mdl>(s, q[c], x[c], nrows, ncols, nframes, false, omega));
+        }
+    }
+    timer.stop(iter);
     return PDEIP_OK;
 }
 
@@ -611,21 +702,9 @@ extern "C" int pdeip_oflow_alr_elin4_dev(void *stream, float *U, float *V, const
                                          const float *wN, const float *wE, const float *wS, int nrows, int ncols,
                                          int iter, float omega, int mode)
 {
-    const char *who = "pdeip_oflow_alr_elin4_dev";
-    RC(check_dims(who, nrows, ncols, 1));
-    RC(check_mode(who, mode));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    g.last_launches = 0;
-    const AlrElin4::Ctx qu{U, V, M, Cu, Du, wW, wN, wE, wS}, qv{V, U, M, Cv, Dv, wW, wN, wE, wS};
-    SweepTimer timer(s);
-    for (int it = 0; it < iter; it++) { // opticalflowSolvers.c:231-258: columns U then V, rows V then U
-        RC(alr_pass<AlrElin4>(who, s, qu, U, nrows, ncols, 1, true, omega, mode));
-        RC(alr_pass<AlrElin4>(who, s, qv, V, nrows, ncols, 1, true, omega, mode));
-        RC(alr_pass<AlrElin4>(who, s, qv, V, nrows, ncols, 1, false, omega, mode));
-        RC(alr_pass<AlrElin4>(who, s, qu, U, nrows, ncols, 1, false, omega, mode));
-    }
-    timer.stop(iter > 0 ? iter : 1);
-    return PDEIP_OK;
+    const AlrElin4::Ctx q[2] = {{U, V, M, Cu, Du, wW, wN, wE, wS}, {V, U, M, Cv, Dv, wW, wN, wE, wS}};
+    float *const x[2] = {U, V};
+    return run_alr<AlrElin4>("pdeip_oflow_alr_elin4_dev", static_cast<hipStream_t>(stream), q, x, 2, nrows, ncols, 1, iter, omega, mode);
 }
 
 extern "C" int pdeip_oflow_alr_llin4_dev(void *stream, const float *U, const float *V, float *dU, float *dV,
@@ -633,21 +712,9 @@ extern "C" int pdeip_oflow_alr_llin4_dev(void *stream, const float *U, const flo
                                          const float *Dv, const float *wW, const float *wN, const float *wE,
                                          const float *wS, int nrows, int ncols, int iter, float omega, int mode)
 {
-    const char *who = "pdeip_oflow_alr_llin4_dev";
-    RC(check_dims(who, nrows, ncols, 1));
-    RC(check_mode(who, mode));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    g.last_launches = 0;
-    const AlrLlin4::Ctx qu{U, dU, dV, M, Cu, Du, wW, wN, wE, wS}, qv{V, dV, dU, M, Cv, Dv, wW, wN, wE, wS};
-    SweepTimer timer(s);
-    for (int it = 0; it < iter; it++) { // :728-755
-        RC(alr_pass<AlrLlin4>(who, s, qu, dU, nrows, ncols, 1, true, omega, mode));
-        RC(alr_pass<AlrLlin4>(who, s, qv, dV, nrows, ncols, 1, true, omega, mode));
-        RC(alr_pass<AlrLlin4>(who, s, qv, dV, nrows, ncols, 1, false, omega, mode));
-        RC(alr_pass<AlrLlin4>(who, s, qu, dU, nrows, ncols, 1, false, omega, mode));
-    }
-    timer.stop(iter > 0 ? iter : 1);
-    return PDEIP_OK;
+    const AlrLlin4::Ctx q[2] = {{U, dU, dV, M, Cu, Du, wW, wN, wE, wS}, {V, dV, dU, M, Cv, Dv, wW, wN, wE, wS}};
+    float *const x[2] = {dU, dV};
+    return run_alr<AlrLlin4>("pdeip_oflow_alr_llin4_dev", static_cast<hipStream_t>(stream), q, x, 2, nrows, ncols, 1, iter, omega, mode);
 }
 
 extern "C" int pdeip_oflow_alr_llin8_dev(void *stream, const float *U, const float *V, float *dU, float *dV,
@@ -656,60 +723,28 @@ extern "C" int pdeip_oflow_alr_llin8_dev(void *stream, const float *U, const flo
                                          const float *wNE, const float *wE, const float *wSE, const float *wS,
                                          const float *wSW, int nrows, int ncols, int iter, float omega, int mode)
 {
-    const char *who = "pdeip_oflow_alr_llin8_dev";
-    RC(check_dims(who, nrows, ncols, 1));
-    RC(check_mode(who, mode));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    g.last_launches = 0;
-    const AlrLlin8::Ctx qu{U, dU, dV, M, Cu, Du, {wN, wS, wE, wW, wNW, wNE, wSW, wSE}};
-    const AlrLlin8::Ctx qv{V, dV, dU, M, Cv, Dv, {wN, wS, wE, wW, wNW, wNE, wSW, wSE}};
-    SweepTimer timer(s);
-    for (int it = 0; it < iter; it++) { // :1718-1746
-        RC(alr_pass<AlrLlin8>(who, s, qu, dU, nrows, ncols, 1, true, omega, mode));
-        RC(alr_pass<AlrLlin8>(who, s, qv, dV, nrows, ncols, 1, true, omega, mode));
-        RC(alr_pass<AlrLlin8>(who, s, qv, dV, nrows, ncols, 1, false, omega, mode));
-        RC(alr_pass<AlrLlin8>(who, s, qu, dU, nrows, ncols, 1, false, omega, mode));
-    }
-    timer.stop(iter > 0 ? iter : 1);
-    return PDEIP_OK;
+    const AlrLlin8::Ctx q[2] = {{U, dU, dV, M, Cu, Du, {wN, wS, wE, wW, wNW, wNE, wSW, wSE}},
+                                {V, dV, dU, M, Cv, Dv, {wN, wS, wE, wW, wNW, wNE, wSW, wSE}}};
+    float *const x[2] = {dU, dV};
+    return run_alr<AlrLlin8>("pdeip_oflow_alr_llin8_dev", static_cast<hipStream_t>(stream), q, x, 2, nrows, ncols, 1, iter, omega, mode);
 }
 
 extern "C" int pdeip_disp_alr_llin4_dev(void *stream, const float *U, float *dU, const float *Cu, const float *Du,
                                         const float *wW, const float *wN, const float *wE, const float *wS,
                                         int nrows, int ncols, int iter, float omega, int mode)
 {
-    const char *who = "pdeip_disp_alr_llin4_dev";
-    RC(check_dims(who, nrows, ncols, 1));
-    RC(check_mode(who, mode));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    g.last_launches = 0;
-    const AlrLlin4::Ctx q{U, dU, nullptr, nullptr, Cu, Du, wW, wN, wE, wS};
-    SweepTimer timer(s);
-    for (int it = 0; it < iter; it++) { // disparitySolvers.c:186-204
-        RC(alr_pass<AlrLlin4>(who, s, q, dU, nrows, ncols, 1, true, omega, mode));
-        RC(alr_pass<AlrLlin4>(who, s, q, dU, nrows, ncols, 1, false, omega, mode));
-    }
-    timer.stop(iter > 0 ? iter : 1);
-    return PDEIP_OK;
+    const AlrDisp4::Ctx q[1] = {{U, dU, nullptr, nullptr, Cu, Du, wW, wN, wE, wS}};
+    float *const x[1] = {dU};
+    return run_alr<AlrDisp4>("pdeip_disp_alr_llin4_dev", static_cast<hipStream_t>(stream), q, x, 1, nrows, ncols, 1, iter, omega, mode);
 }
 
 extern "C" int pdeip_pde_alr4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
                                   const float *wN, const float *wE, const float *wS, int nrows, int ncols,
                                   int nframes, int iter, float omega, int mode)
 {
-    const char *who = "pdeip_pde_alr4_dev";
-    RC(check_dims(who, nrows, ncols, nframes));
-    RC(check_mode(who, mode));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    g.last_launches = 0;
-    const AlrPde4::Ctx q{X, TRACE, B, wW, wN, wE, wS};
-    SweepTimer timer(s);
-    for (int it = 0; it < iter; it++) { // pdeSolvers.c:308-327; frames are independent
-        RC(alr_pass<AlrPde4>(who, s, q, X, nrows, ncols, nframes, true, omega, mode));
-        RC(alr_pass<AlrPde4>(who, s, q, X, nrows, ncols, nframes, false, omega, mode));
-    }
-    timer.stop(iter > 0 ? iter : 1);
-    return PDEIP_OK;
+    const AlrPde4::Ctx q[1] = {{X, TRACE, B, wW, wN, wE, wS}};
+    float *const x[1] = {X};
+    return run_alr<AlrPde4>("pdeip_pde_alr4_dev", static_cast<hipStream_t>(stream), q, x, 1, nrows, ncols, nframes, iter, omega, mode);
 }
 
 // One iteration whatever `iter` says (pdeSolvers.c:362), interior columns then interior rows.
@@ -718,18 +753,10 @@ extern "C" int pdeip_pde_alr8_dev(void *stream, float *X, const float *TRACE, co
                                   const float *wSE, const float *wS, const float *wSW, int nrows, int ncols,
                                   int nframes, int iter, float omega, int mode)
 {
-    const char *who = "pdeip_pde_alr8_dev";
     (void)iter;
-    RC(check_dims(who, nrows, ncols, nframes));
-    RC(check_mode(who, mode));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    g.last_launches = 0;
-    const AlrPde8::Ctx q{X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW};
-    SweepTimer timer(s);
-    RC(alr_pass<AlrPde8>(who, s, q, X, nrows, ncols, nframes, true, omega, mode));
-    RC(alr_pass<AlrPde8>(who, s, q, X, nrows, ncols, nframes, false, omega, mode));
-    timer.stop(1);
-    return PDEIP_OK;
+    const AlrPde8::Ctx q[1] = {{X, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW}};
+    float *const x[1] = {X};
+    return run_alr<AlrPde8>("pdeip_pde_alr8_dev", static_cast<hipStream_t>(stream), q, x, 1, nrows, ncols, nframes, 1, omega, mode);
 }
 
 extern "C" int pdeip_oflow_res_elin4_dev(void *stream, float *RU, float *RV, const float *U, const float *V,

@@ -1,0 +1,15 @@
+#!/bin/bash
+# kernel trace of the line-relaxation kernels at 4K (run on the GPU box)
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_alr
+rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/time_alr.py 2160 3840 1 > $OUT/run.log 2>&1
+python3 - <<PY
+import csv, glob, collections
+f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+for r in rows:
+    name = r["Kernel_Name"]
+    if "alr" in name:
+        print("%-60s %10.3f ms  grid=%s" % (name[:60], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r.get("Grid_Size_X", r.get("Grid_Size"))))
+PY
