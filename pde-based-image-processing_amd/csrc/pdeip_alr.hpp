@@ -28,6 +28,37 @@ struct Tri {
     float a, b, c, d;
 };
 
+// Plane addressing.  The column pass works on the planes as MATLAB hands them over (element (i,j) at
+// j*nrows + i: a column is contiguous).  The row pass works on TRANSPOSED copies (element (i,j) at
+// i*ncols + j: a row is contiguous) that the host keeps in step -- a line is then contiguous in both
+// passes, and the strided walk along image rows (one cache line and one address translation per pixel
+// and plane) never happens.
+template <bool vertical> struct AlrGeo {
+    __device__ __forceinline__ static size_t pos(int i, int j, int nrows, int ncols) { return vertical ? (size_t)j * nrows + i : (size_t)i * ncols + j; }
+    __device__ __forceinline__ static long dS(int nrows, int ncols) { return vertical ? 1 : ncols; }  // to the south neighbour
+    __device__ __forceinline__ static long dE(int nrows, int ncols) { return vertical ? nrows : 1; }  // to the east neighbour
+};
+
+// out[f][a][b] = in[f][b][a]: `in` is [F][nb][na] with a fastest; 32x32 tiles through LDS, coalesced both ways.
+__global__ void __launch_bounds__(256) k_alr_transpose(float *__restrict__ out, const float *__restrict__ in, int na, int nb)
+{
+    __shared__ float tile[32][33];
+    const size_t fo = (size_t)blockIdx.z * na * nb;
+    const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int a = a0 + tx, b = b0 + ty + r;
+        if (a < na && b < nb) tile[ty + r][tx] = in[fo + (size_t)b * na + a];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int b = b0 + tx, a = a0 + ty + r;
+        if (a < na && b < nb) out[fo + (size_t)a * nb + b] = tile[tx][ty + r];
+    }
+}
+
 // element k of line l: (i,j) = (k,l) on a column, (l,k) on a row
 template <class Mdl, bool VERT>
 __device__ __forceinline__ Tri line_coef(const typename Mdl::Ctx &q, int l, int k, int nrows, int ncols)
@@ -52,7 +83,8 @@ struct AlrElin4 {
     template <bool vertical>
     __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
     {
-        const size_t pos = (size_t)j * nrows + i;
+        const size_t pos = AlrGeo<vertical>::pos(i, j, nrows, ncols);
+        const long dS = AlrGeo<vertical>::dS(nrows, ncols), dE = AlrGeo<vertical>::dE(nrows, ncols);
         const bool hasN = i > 0, hasS = i < nrows - 1, hasW = j > 0, hasE = j < ncols - 1;
         const float wN = q.wN[pos], wS = q.wS[pos], wE = q.wE[pos], wW = q.wW[pos];
         float b = 0.0f, d = 0.0f;
@@ -64,13 +96,13 @@ struct AlrElin4 {
         if (hasW) acc_add(b, hb, wW);
         // loads are unconditional (clamped addresses): a branch around a load serialises the whole step
         if (vertical) { // d = wW*U_w + wE*U_e (:1919)
-            const float xw = q.X[hasW ? pos - nrows : pos], xe = q.X[hasE ? pos + nrows : pos];
+            const float xw = q.X[hasW ? pos - dE : pos], xe = q.X[hasE ? pos + dE : pos];
             if (hasW) acc_add(d, hd, wW * xw);
             if (hasE) acc_add(d, hd, wE * xe);
             t.a = hasN ? -wN : 0.0f;
             t.c = hasS ? -wS : 0.0f;
         } else { // d = wS*U_s + wN*U_n (:2247)
-            const float xs = q.X[hasS ? pos + 1 : pos], xn = q.X[hasN ? pos - 1 : pos];
+            const float xs = q.X[hasS ? pos + dS : pos], xn = q.X[hasN ? pos - dS : pos];
             if (hasS) acc_add(d, hd, wS * xs);
             if (hasN) acc_add(d, hd, wN * xn);
             t.a = hasW ? -wW : 0.0f;
@@ -99,10 +131,11 @@ template <bool COUPLED> struct AlrLlin4T {
     template <bool vertical>
     __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
     {
-        const size_t pos = (size_t)j * nrows + i;
+        const size_t pos = AlrGeo<vertical>::pos(i, j, nrows, ncols);
+        const long dS = AlrGeo<vertical>::dS(nrows, ncols), dE = AlrGeo<vertical>::dE(nrows, ncols);
         const bool hasN = i > 0, hasS = i < nrows - 1, hasW = j > 0, hasE = j < ncols - 1;
-        const size_t wpos = hasW ? pos - nrows : pos, epos = hasE ? pos + nrows : pos; // clamped: loads are unconditional
-        const size_t npos = hasN ? pos - 1 : pos, spos = hasS ? pos + 1 : pos;
+        const size_t wpos = hasW ? pos - dE : pos, epos = hasE ? pos + dE : pos; // clamped: loads are unconditional
+        const size_t npos = hasN ? pos - dS : pos, spos = hasS ? pos + dS : pos;
         const float wN = q.wN[pos], wS = q.wS[pos], wE = q.wE[pos], wW = q.wW[pos];
         const float Uc = q.U[pos];
         const float Uw = q.U[wpos], Ue = q.U[epos], Us = q.U[spos], Un = q.U[npos];
@@ -189,8 +222,9 @@ struct AlrLlin8 {
     template <bool vertical>
     __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
     {
-        const size_t pos = (size_t)j * nrows + i;
-        const long off[8] = {-1, 1, nrows, -(long)nrows, -(long)nrows - 1, (long)nrows - 1, -(long)nrows + 1, (long)nrows + 1};
+        const size_t pos = AlrGeo<vertical>::pos(i, j, nrows, ncols);
+        const long dS = AlrGeo<vertical>::dS(nrows, ncols), dE = AlrGeo<vertical>::dE(nrows, ncols);
+        const long off[8] = {-dS, dS, dE, -dE, -dE - dS, dE - dS, -dE + dS, dE + dS}; // N,S,E,W,NW,NE,SW,SE
         const signed char(*cs)[9] = vertical ? ALR_L8[0][third(j, ncols)][third(i, nrows)] : ALR_L8[1][third(i, nrows)][third(j, ncols)];
         const float Uc = q.U[pos];
         float b = 0.0f, d = 0.0f;
@@ -239,20 +273,21 @@ struct AlrPde4 {
     template <bool vertical>
     __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
     {
-        const size_t pos = (size_t)j * nrows + i;
+        const size_t pos = AlrGeo<vertical>::pos(i, j, nrows, ncols);
+        const long dS = AlrGeo<vertical>::dS(nrows, ncols), dE = AlrGeo<vertical>::dE(nrows, ncols);
         const bool hasN = i > 0, hasS = i < nrows - 1, hasW = j > 0, hasE = j < ncols - 1;
         const float wN = q.wN[pos], wS = q.wS[pos], wE = q.wE[pos], wW = q.wW[pos];
         float b = 0.0f, d = 0.0f;
         bool hb = false, hd = false;
         Tri t;
         if (vertical) { // pdeSolvers.c:593
-            const float xw = q.X[hasW ? pos - nrows : pos], xe = q.X[hasE ? pos + nrows : pos];
+            const float xw = q.X[hasW ? pos - dE : pos], xe = q.X[hasE ? pos + dE : pos];
             if (hasW) acc_add(d, hd, wW * xw);
             if (hasE) acc_add(d, hd, wE * xe);
             t.a = hasN ? -wN : 0.0f;
             t.c = hasS ? -wS : 0.0f;
         } else { // :956
-            const float xs = q.X[hasS ? pos + 1 : pos], xn = q.X[hasN ? pos - 1 : pos];
+            const float xs = q.X[hasS ? pos + dS : pos], xn = q.X[hasN ? pos - dS : pos];
             if (hasS) acc_add(d, hd, wS * xs);
             if (hasN) acc_add(d, hd, wN * xn);
             t.a = hasW ? -wW : 0.0f;
@@ -286,10 +321,11 @@ struct AlrPde8 {
     template <bool vertical>
     __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
     {
-        const size_t pos = (size_t)j * nrows + i;
+        const size_t pos = AlrGeo<vertical>::pos(i, j, nrows, ncols);
+        const long dS = AlrGeo<vertical>::dS(nrows, ncols), dE = AlrGeo<vertical>::dE(nrows, ncols);
         const bool hasN = i > 0, hasS = i < nrows - 1, hasW = j > 0, hasE = j < ncols - 1;
         // clamped one-step offsets: every load below is unconditional
-        const long oN = hasN ? -1 : 0, oS = hasS ? 1 : 0, oW = hasW ? -(long)nrows : 0, oE = hasE ? (long)nrows : 0;
+        const long oN = hasN ? -dS : 0, oS = hasS ? dS : 0, oW = hasW ? -dE : 0, oE = hasE ? dE : 0;
         const float *X = q.X + pos;
         const float wW = q.wW[pos], wNW = q.wNW[pos], wN = q.wN[pos], wNE = q.wNE[pos];
         const float wE = q.wE[pos], wSE = q.wSE[pos], wS = q.wS[pos], wSW = q.wSW[pos];
@@ -341,9 +377,9 @@ __global__ void __launch_bounds__(64) k_alr_zebra(typename Mdl::Ctx q, float *x,
     x += fo;
     cp += fo;
     dp += fo;
-    const int n = vertical ? nrows : ncols;
-    const size_t stride = vertical ? 1 : (size_t)nrows;
-    const size_t base = vertical ? (size_t)l * nrows : (size_t)l;
+    const int n = vertical ? nrows : ncols; // line length; line l starts at l * n in either layout
+    constexpr size_t stride = 1;
+    const size_t base = (size_t)l * n;
     const float om1 = 1.0f - omega;
 
     // The recurrences are serial, the loads are not: fetch the coefficients of ZCH steps at once so that
@@ -430,9 +466,9 @@ __global__ void __launch_bounds__(64) k_alr_factor(typename Mdl::Ctx q, float *_
     q.shift(fo);
     cp += fo;
     dv += fo;
-    const int n = vertical ? nrows : ncols;
-    const size_t stride = vertical ? 1 : (size_t)nrows;
-    const size_t base = vertical ? (size_t)l * nrows : (size_t)l;
+    const int n = vertical ? nrows : ncols; // line length; line l starts at l * n in either layout
+    constexpr size_t stride = 1;
+    const size_t base = (size_t)l * n;
     constexpr int ZCH = 8;
     const Tri c0 = line_coef<Mdl, VERT>(q, l, 0, nrows, ncols);
     float cpv = c0.c / c0.b;
@@ -472,13 +508,13 @@ template <class Mdl, int NCH> struct AlrChains {
     AlrChain<Mdl> c[NCH];
 };
 
-__device__ __forceinline__ float alr_from_lower_lane(float v, float lane0_value)
-{ // lane l <- lane l-1 (v_mov_b32_dpp wave_shr:1); lane 0 gets lane0_value
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0_value), __float_as_int(v), 0x138, 0xf, 0xf, false));
+__device__ __forceinline__ float alr_from_lower_lane(float v)
+{ // lane l <- lane l-1 (DPP wave_shr:1, folds into the consuming multiply); lane 0 reads 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float alr_from_upper_lane(float v, float lane63_value)
-{ // lane l <- lane l+1 (wave_shl:1); lane 63 gets lane63_value
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane63_value), __float_as_int(v), 0x130, 0xf, 0xf, false));
+__device__ __forceinline__ float alr_from_upper_lane(float v)
+{ // lane l <- lane l+1 (wave_shl:1); lane 63 reads 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
 // Both recurrences of one line out of LDS, run by ONE WAVE; element = (a, div, cp, d) on entry, .w = the
@@ -486,11 +522,14 @@ __device__ __forceinline__ float alr_from_upper_lane(float v, float lane63_value
 //
 // The recurrences are serial, so only one value is "live" at a time -- but fetching each element's
 // operands into the lane that holds that value costs more than the arithmetic.  Instead lane u keeps the
-// operands of element k0+u of a 64-element block, and the live value travels: 64 times over, every lane
-// evaluates  dp = (d - dp[lane-1] * a) * div  with its lower neighbour's current value (one DPP
-// wave_shr:1).  Lane 0 is right after the first pass, lane 1 after the second, ... and a lane that is
-// already right recomputes the same number, so after 64 passes all 64 are final: three dependent VALU
-// instructions per element, each with exactly the operands and the rounding of the serial loop.
+// operands of one element of a 63-element block, and the live value travels: 63 times over, every lane
+// evaluates  dp = (d - dp[lane-1] * a) * div  with its lower neighbour's current value (DPP wave_shr:1).
+// Lane 0 carries the value entering the block (a = 0, div = 1, d = carry reproduce it exactly), lane 1 is
+// right after the first pass, lane 2 after the second, ... and a lane that is already right recomputes
+// the same number, so after 63 passes all are final: three dependent VALU instructions per element,
+// each with exactly the operands and the rounding of the serial loop.
+constexpr int ALR_BLK = 63;
+
 __device__ __forceinline__ void alr_serial_wave(float4 *L, int n, int lane)
 {
     float carry; // wave-uniform: dp of the element before the current block
@@ -500,27 +539,25 @@ __device__ __forceinline__ void alr_serial_wave(float4 *L, int n, int lane)
         if (lane == 0) L[0].w = carry;
     }
     const int nmid = n - 2; // elements 1 .. n-2
-    const int nblk = (nmid + 63) / 64;
+    const int nblk = (nmid + ALR_BLK - 1) / ALR_BLK;
+    // lane u >= 1 of block m holds element 1 + 63 m + (u - 1)
+    float4 nxt = L[min(lane, n - 2)]; // block 0 (lane 0's slot is overwritten below)
     for (int m = 0; m < nblk; ++m) {
-        const int k0 = 1 + 64 * m, k = k0 + lane;
-        const int cnt = min(64, n - 1 - k0);
-        const bool valid = lane < cnt;
-        const float4 e = L[valid ? k : n - 2];
+        const int k0 = 1 + ALR_BLK * m, k = k0 + lane - 1;
+        const int cnt = min(ALR_BLK, n - 1 - k0);
+        const bool valid = lane >= 1 && lane <= cnt;
+        float4 e = nxt;
+        nxt = L[min(k + ALR_BLK, n - 2)]; // next block's operands, in flight during this block's passes
+        if (lane == 0) e = make_float4(0.0f, 1.0f, 0.0f, carry);
         float dp = 0.0f;
-        if (cnt == 64) {
+        if (cnt == ALR_BLK) {
 #pragma unroll
-            for (int u = 0; u < 64; ++u) {
-                const float prev = alr_from_lower_lane(dp, carry);
-                dp = (e.w - prev * e.x) * e.y;
-            }
+            for (int u = 0; u <= ALR_BLK; ++u) dp = (e.w - alr_from_lower_lane(dp) * e.x) * e.y;
         } else {
-            for (int u = 0; u < cnt; ++u) {
-                const float prev = alr_from_lower_lane(dp, carry);
-                dp = (e.w - prev * e.x) * e.y;
-            }
+            for (int u = 0; u <= cnt; ++u) dp = (e.w - alr_from_lower_lane(dp) * e.x) * e.y;
         }
         if (valid) L[k].w = dp;
-        carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dp), cnt - 1));
+        carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dp), cnt));
     }
     float xs; // wave-uniform: solution of the element after the current block
     {
@@ -528,22 +565,23 @@ __device__ __forceinline__ void alr_serial_wave(float4 *L, int n, int lane)
         xs = (e.w - carry * e.x) / e.y; // last element: divided, not multiplied by a reciprocal
         if (lane == 0) L[n - 1].w = xs;
     }
+    // back-substitution x = dp - cp * x[lane+1]: lane 63 carries the value entering the block from above
+    // (dp = xs, cp = 0); lane u <= 62 of block m holds element 1 + 63 m + u
+    nxt = L[min(max(1 + ALR_BLK * (nblk - 1) + lane, 1), n - 2)];
     for (int m = nblk - 1; m >= 0; --m) {
-        const int k0 = 1 + 64 * m, k = k0 + lane;
-        const int cnt = min(64, n - 1 - k0);
+        const int k0 = 1 + ALR_BLK * m, k = k0 + lane;
+        const int cnt = min(ALR_BLK, n - 1 - k0);
         const bool valid = lane < cnt;
-        const float4 e = L[valid ? k : n - 2]; // .w = dp, .z = cp
-        float x = xs;
-        if (cnt == 64) {
+        float4 e = nxt; // .w = dp, .z = cp
+        nxt = L[min(max(k - ALR_BLK, 1), n - 2)];
+        if (!valid) e = make_float4(0.0f, 0.0f, 0.0f, xs); // lane 63 (and lanes past a short block) hold the entering value
+        float x = valid ? 0.0f : xs;
+        if (cnt == ALR_BLK) { // lane 63: xs - 0 * 0 = xs, exactly, whatever xs is
 #pragma unroll
-            for (int u = 0; u < 64; ++u) {
-                const float up = alr_from_upper_lane(x, xs);
-                x = e.w - e.z * up;
-            }
-        } else { // lanes past the end of the line stand in for the element after it
+            for (int u = 0; u <= ALR_BLK; ++u) x = e.w - e.z * alr_from_upper_lane(x);
+        } else {
             for (int u = 0; u < cnt; ++u) {
-                const float up = alr_from_upper_lane(x, xs);
-                const float t = e.w - e.z * up;
+                const float t = e.w - e.z * alr_from_upper_lane(x);
                 x = valid ? t : xs;
             }
         }
@@ -571,8 +609,8 @@ __global__ void __launch_bounds__(ALR_LEX_THREADS) k_alr_lex(AlrChains<Mdl, NCH>
         ch.c[c].cp += fo;
         ch.c[c].dv += fo;
     }
-    const int n = vertical ? nrows : ncols;
-    const size_t stride = vertical ? 1 : (size_t)nrows;
+    const int n = vertical ? nrows : ncols; // line length; line l starts at l * n in either layout
+    constexpr size_t stride = 1;
     const float om1 = 1.0f - omega;
     const int tid = threadIdx.x;
 
@@ -583,7 +621,7 @@ __global__ void __launch_bounds__(ALR_LEX_THREADS) k_alr_lex(AlrChains<Mdl, NCH>
             const int l = s - c;
             if (l < lo || l > hi) continue;
             float4 *L = alr_lds + (size_t)c * n;
-            const size_t base = vertical ? (size_t)l * nrows : (size_t)l;
+            const size_t base = (size_t)l * n;
             for (int k = tid; k < n; k += ALR_LEX_THREADS) {
                 const Tri t = line_coef<Mdl, VERT>(ch.c[c].q, l, k, nrows, ncols);
                 const size_t pos = base + (size_t)k * stride;
@@ -603,7 +641,7 @@ __global__ void __launch_bounds__(ALR_LEX_THREADS) k_alr_lex(AlrChains<Mdl, NCH>
             for (int c = 0; c < NCH; ++c) {
                 const int l = s + 1 - c;
                 if (l < lo || l > hi) continue;
-                const size_t base = vertical ? (size_t)l * nrows : (size_t)l;
+                const size_t base = (size_t)l * n;
                 for (int k = tid - 64 * NCH; k < n; k += ALR_LEX_THREADS - 64 * NCH) {
                     const Tri t = line_coef<Mdl, VERT>(ch.c[c].q, l, k, nrows, ncols);
                     const size_t pos = base + (size_t)k * stride;
@@ -618,7 +656,7 @@ __global__ void __launch_bounds__(ALR_LEX_THREADS) k_alr_lex(AlrChains<Mdl, NCH>
             if (l < lo || l > hi) continue;
             const float4 *L = alr_lds + (size_t)c * n;
             float *x = ch.c[c].x;
-            const size_t base = vertical ? (size_t)l * nrows : (size_t)l;
+            const size_t base = (size_t)l * n;
             for (int k = tid; k < n; k += ALR_LEX_THREADS) {
                 const size_t pos = base + (size_t)k * stride;
                 x[pos] = omega * L[k].w + om1 * x[pos];

@@ -26,7 +26,7 @@ using namespace pdeip;
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_CTL, WS_ORDER, WS_ALR, WS_NSLOT };
+enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_CTL, WS_ORDER, WS_ALR, WS_ALR_T, WS_NSLOT };
 
 struct Context {
     int device = 0;
@@ -582,7 +582,8 @@ struct AlrFactors {
 };
 
 template <class Mdl>
-static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, int nch, int nrows, int ncols, int nframes, AlrFactors *f)
+static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, const typename Mdl::Ctx *qt, int nch, int nrows, int ncols, int nframes,
+                      AlrFactors *f)
 {
     const size_t fs = (size_t)nrows * ncols, plane = fs * nframes;
     float *base;
@@ -595,7 +596,7 @@ static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, int nch, int nr
             const int hi = (d == 0 ? ncols : nrows) - 1 - lo;
             const dim3 grid((unsigned)((hi - lo + 1 + 63) / 64), (unsigned)nframes);
             if (d == 0) hipLaunchKernelGGL((k_alr_factor<Mdl, true>), grid, dim3(64), 0, s, q[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
-            else hipLaunchKernelGGL((k_alr_factor<Mdl, false>), grid, dim3(64), 0, s, q[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
+            else hipLaunchKernelGGL((k_alr_factor<Mdl, false>), grid, dim3(64), 0, s, qt[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
             g.last_launches++;
         }
     HIPCHK(hipGetLastError());
@@ -668,6 +669,63 @@ static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, i
     return PDEIP_OK;
 }
 
+// The row passes run on transposed copies of every plane (pdeip_alr.hpp, AlrGeo).  A model's Ctx is a plain
+// struct of plane pointers; each distinct plane gets one transposed twin in the WS_ALR_T workspace.  The
+// coefficient planes are transposed once per call, the iterate planes around every row pass.
+struct AlrTwin {
+    static constexpr int MAXP = 40;
+    const float *orig[MAXP];
+    float *twin[MAXP];
+    int count = 0;
+    float *find(const float *p) const
+    {
+        for (int k = 0; k < count; k++)
+            if (orig[k] == p) return twin[k];
+        return nullptr;
+    }
+};
+
+static int alr_transpose(hipStream_t s, float *out, const float *in, int na, int nb, int nframes)
+{
+    hipLaunchKernelGGL(k_alr_transpose, dim3((unsigned)((na + 31) / 32), (unsigned)((nb + 31) / 32), (unsigned)nframes), dim3(256), 0, s, out, in, na, nb);
+    g.last_launches++;
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+template <class Ctx>
+static int alr_make_twins(hipStream_t s, const Ctx *q, Ctx *qt, int nch, float *const *x, float **xt, int nrows, int ncols, int nframes,
+                          AlrTwin *tw)
+{
+    static_assert(sizeof(Ctx) % sizeof(float *) == 0, "a line-relaxation context is a struct of plane pointers");
+    constexpr int NP = (int)(sizeof(Ctx) / sizeof(float *));
+    const size_t plane = (size_t)nrows * ncols * nframes;
+    const float *ptrs[2][NP];
+    for (int c = 0; c < nch; c++) {
+        memcpy(ptrs[c], &q[c], sizeof(Ctx));
+        for (int k = 0; k < NP; k++)
+            if (ptrs[c][k] && !tw->find(ptrs[c][k])) {
+                if (tw->count == AlrTwin::MAXP) return set_err(PDEIP_ERR_ARG, "line relaxation: too many planes");
+                tw->orig[tw->count++] = ptrs[c][k];
+            }
+    }
+    float *base;
+    RC(ws_get(WS_ALR_T, plane * tw->count * sizeof(float), &base));
+    for (int k = 0; k < tw->count; k++) {
+        tw->twin[k] = base + plane * k;
+        bool iterate = false;
+        for (int c = 0; c < nch; c++) iterate = iterate || tw->orig[k] == x[c];
+        if (!iterate) RC(alr_transpose(s, tw->twin[k], tw->orig[k], nrows, ncols, nframes)); // coefficient plane: once per call
+    }
+    for (int c = 0; c < nch; c++) {
+        const float *tp[NP];
+        for (int k = 0; k < NP; k++) tp[k] = ptrs[c][k] ? tw->find(ptrs[c][k]) : nullptr;
+        memcpy(&qt[c], tp, sizeof(Ctx));
+        xt[c] = tw->find(x[c]);
+    }
+    return PDEIP_OK;
+}
+
 // The iteration loop shared by every line-relaxation entry point.  q[c] / x[c]: context and iterate
 // plane of field c; the reference relaxes columns of field 0 then field 1, rows of field 1 then
 // field 0 (opticalflowSolvers.c:231-258); single-field solvers: columns, then rows.
@@ -681,17 +739,24 @@ static int run_alr(const char *who, hipStream_t s, const typename Mdl::Ctx *q, f
     g.last_launches = 0;
     if (iter <= 0) return PDEIP_OK;
     const int fwd[2] = {0, 1}, rev[2] = {1, 0};
+    typename Mdl::Ctx qt[2];
+    float *xt[2] = {nullptr, nullptr};
+    AlrTwin tw;
+    RC(alr_make_twins(s, q, qt, nch, x, xt, nrows, ncols, nframes, &tw));
     AlrFactors f{};
-    if (mode == PDEIP_MODE_EXACT_ORDER) RC(alr_factor<Mdl>(s, q, nch, nrows, ncols, nframes, &f));
+    if (mode == PDEIP_MODE_EXACT_ORDER) RC(alr_factor<Mdl>(s, q, qt, nch, nrows, ncols, nframes, &f));
     SweepTimer timer(s);
     for (int it = 0; it < iter; it++) {
-        if (mode == PDEIP_MODE_EXACT_ORDER) {
+        if (mode == PDEIP_MODE_EXACT_ORDER)
             RC(alr_lex_pass<Mdl>(s, q, x, f, fwd, nch, nrows, ncols, nframes, true, omega));
-            RC(alr_lex_pass<Mdl>(s, q, x, f, nch == 2 ? rev : fwd, nch, nrows, ncols, nframes, false, omega));
-        } else {
+        else
             for (int c = 0; c < nch; c++) RC(alr_zebra_pass<Mdl>(s, q[c], x[c], nrows, ncols, nframes, true, omega));
-            for (int c = nch - 1; c >= 0; c--) RC(alr_zebra_pass<Mdl>(s, q[c], x[c], nrows, ncols, nframes, false, omega));
-        }
+        for (int c = 0; c < nch; c++) RC(alr_transpose(s, xt[c], x[c], nrows, ncols, nframes));
+        if (mode == PDEIP_MODE_EXACT_ORDER)
+            RC(alr_lex_pass<Mdl>(s, qt, xt, f, nch == 2 ? rev : fwd, nch, nrows, ncols, nframes, false, omega));
+        else
+            for (int c = nch - 1; c >= 0; c--) RC(alr_zebra_pass<Mdl>(s, qt[c], xt[c], nrows, ncols, nframes, false, omega));
+        for (int c = 0; c < nch; c++) RC(alr_transpose(s, x[c], xt[c], ncols, nrows, nframes));
     }
     timer.stop(iter);
     return PDEIP_OK;

@@ -34,6 +34,13 @@ CASES = [
     ("pde4_frames_nan", "PDEsolver4", lambda: pb.pde4(142, 33, 29, nframes=3, nan_frac=0.06), dict(it=5, omega=1.75)),
     ("pde8_a", "PDEsolver8", lambda: pb.pde8(151, 24, 40), dict(it=4, omega=1.75)),
     ("pde8_frames_nan", "PDEsolver8", lambda: pb.pde8(152, 33, 29, nframes=3, nan_frac=0.06), dict(it=5, omega=1.75)),
+    # solver = 2: alternating line relaxation ('lex' = the reference's line order, 'colour' = zebra)
+    ("alr_elin4_nan", "Oflow_sor_elin4_2d", lambda: pb.elin4(201, 33, 29, nframes=2, nan_frac=0.05), dict(it=3, omega=1.5, nargout=4, solver=2)),
+    ("alr_llin4_a", "Oflow_sor_llin4_2d", lambda: pb.llin4(202, 24, 40, nan_frac=0.03), dict(it=2, omega=1.4, nargout=2, solver=2)),
+    ("alr_llin8_a", "Oflow_sor_llin8_2d", lambda: pb.llin8(203, 33, 29, nan_frac=0.03), dict(it=2, omega=1.4, nargout=2, solver=2)),
+    ("alr_disp4_a", "Disp_sor_llin4_2d", lambda: pb.disp4(204, 24, 40, nan_frac=0.03), dict(it=3, omega=1.4, nargout=1, solver=2)),
+    ("alr_pde4_frames", "PDEsolver4", lambda: pb.pde4(205, 33, 29, nframes=2, nan_frac=0.05), dict(it=3, omega=1.3, solver=2)),
+    ("alr_pde8_frames", "PDEsolver8", lambda: pb.pde8(206, 33, 29, nframes=2, nan_frac=0.05), dict(it=3, omega=1.3, solver=2)),
     ("diffweights_a", "DdiffWeights", lambda: dict(pb.diffweights(161, 24, 40), eps=np.float32(1e-5)), dict()),
     ("diffweights_frames", "DdiffWeights", lambda: dict(pb.diffweights(162, 33, 29, nframes=3), eps=np.float32(1e-3)), dict()),
     ("warp_a", "BilinInterp_2d", lambda: pb.warp(171, 24, 40), dict()),
@@ -55,7 +62,8 @@ def run_case(gateway, p, kw, order):
     fn = getattr(orc, gateway)
     args = list(p.values())
     if gateway in ORDERED:
-        out = fn(*args, kw["it"], kw["omega"], order=order, **({"nargout": kw["nargout"]} if "nargout" in kw else {}))
+        out = fn(*args, kw["it"], kw["omega"], solver=kw.get("solver", 1), order=order,
+                 **({"nargout": kw["nargout"]} if "nargout" in kw else {}))
     else:
         out = fn(*args)
     return out if isinstance(out, tuple) else (out,)

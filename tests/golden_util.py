@@ -35,8 +35,10 @@ def call(api, meta, inputs, single):
     if meta["gateway"] in ORDERED:
         args += [sc(meta["it"]), sc(meta["omega"])]
         if single:
-            args.append(np.float32(1))  # solver
+            args.append(np.float32(meta.get("solver", 1)))
     elif meta["gateway"] == "DdiffWeights":
         args[1] = sc(float(np.asarray(args[1]).reshape(())))
     kw = {"nargout": meta["nargout"]} if "nargout" in meta else {}
+    if not single and meta["gateway"] in ORDERED:
+        kw["solver"] = meta.get("solver", 1)
     return fn, args, kw
