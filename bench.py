@@ -211,6 +211,28 @@ def main():
                                    "host_cpus": os.cpu_count()}
             out["parity"] = {"mode": "exact_order vs cpu oracle, first call", "rms_u": float(np.sqrt((du * du).mean())),
                              "rms_v": float(np.sqrt((dv * dv).mean())), "max_abs": float(max(np.abs(du).max(), np.abs(dv).max()))}
+            # ---- solver 2 (alternating line relaxation, the MATLAB drivers' default), same frame ----------
+            # one ALR iteration = column lines of U,V then row lines of V,U.  exact = reference line order
+            # (bit-identical, serial by construction), zebra = even/odd lines concurrently.
+            lib = sys.modules["oracle_lib"].lib()
+            hu, hv = U0.cpu().numpy().copy(), V0.cpu().numpy().copy()
+            hc = [t.cpu().numpy() for t in coef_full]
+            t0 = time.perf_counter()
+            lib.orc_oflow_alr_elin4(hu.ctypes.data, hv.ctypes.data, *[a.ctypes.data for a in hc], NROWS, NCOLS, 1, ctypes.c_float(1.5), 0)
+            alr_cpu = time.perf_counter() - t0
+            alr = {"unit": "iterations/s", "cpu_oracle": round(1.0 / alr_cpu, 3), "omega": 1.5}
+            for name, mode, reps in (("exact_order", capi.MODE_EXACT_ORDER, 1), ("zebra", capi.MODE_RED_BLACK, 4)):
+                Ua, Va = U0.clone(), V0.clone()
+                dev.oflow_alr_elin4(Ua, Va, *coef_full, 1, 1.5, mode)
+                torch.cuda.synchronize()
+                if mode == capi.MODE_EXACT_ORDER:
+                    alr["exact_order_max_abs_vs_cpu"] = float(max(np.abs(Ua.cpu().numpy().astype(np.float64) - hu).max(),
+                                                                   np.abs(Va.cpu().numpy().astype(np.float64) - hv).max()))
+                t0 = time.perf_counter()
+                dev.oflow_alr_elin4(Ua, Va, *coef_full, reps, 1.5, mode)
+                torch.cuda.synchronize()
+                alr[name] = round(reps / (time.perf_counter() - t0), 3)
+            out["line_relaxation"] = alr
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -52,8 +52,12 @@ extern "C" {
 #define PDEIP_MODE_EXACT_ORDER 0
 #define PDEIP_MODE_RED_BLACK 1
 
-#define PDEIP_SOLVER_SOR 1 /* point-wise Gauss-Seidel SOR */
-#define PDEIP_SOLVER_ALR 2 /* alternating line relaxation */
+/* `solver` argument of the solver gateways (e.g. Oflow_sor_elin4_2d.c:328-338).  Both are device paths:
+ *   1 -> GS_SOR_*      point Gauss-Seidel SOR
+ *   2 -> GS_ALR_SOR_*  alternating line relaxation (the MATLAB drivers' default); in PDEIP_MODE_EXACT_ORDER the
+ *        reference's line order (bit-identical, serial by construction), in PDEIP_MODE_RED_BLACK zebra order. */
+#define PDEIP_SOLVER_SOR 1
+#define PDEIP_SOLVER_ALR 2
 
 /* ---- library state ------------------------------------------------------------------ */
 const char *pdeip_version(void);
