@@ -59,12 +59,31 @@ __global__ void __launch_bounds__(256) k_alr_transpose(float *__restrict__ out, 
     }
 }
 
-// element k of line l: (i,j) = (k,l) on a column, (l,k) on a row
-template <class Mdl, bool VERT>
-__device__ __forceinline__ Tri line_coef(const typename Mdl::Ctx &q, int l, int k, int nrows, int ncols)
+// 16-byte load at 4-byte alignment (a vector type with reduced alignment keeps it one global_load_dwordx4)
+typedef float alr_v4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void alr_ld4(const float *p, float (&v)[4])
 {
-    return VERT ? Mdl::template coef<true>(q, k, l, nrows, ncols) : Mdl::template coef<false>(q, l, k, nrows, ncols);
+    const alr_v4 t = *reinterpret_cast<const alr_v4 *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
+
+// Where element k of line l sits and what surrounds it, in line terms: `before`/`after` are the
+// neighbours on the line, `prev`/`next` the same element of the neighbouring lines.  On a column (MATLAB
+// layout) before/after/prev/next = N/S/W/E, on a row (transposed layout) W/E/N/S; in both a line is
+// contiguous and the neighbouring lines are n elements away.
+struct AlrAt {
+    size_t pos;
+    long n; // line length = distance to the same element of the next line
+    bool hasBefore, hasAfter, hasPrev, hasNext;
+    __device__ __forceinline__ AlrAt(int l, int k, int n_, int nlines)
+        : pos((size_t)l * n_ + k), n(n_), hasBefore(k > 0), hasAfter(k < n_ - 1), hasPrev(l > 0), hasNext(l < nlines - 1)
+    {
+    }
+    __device__ __forceinline__ size_t prev() const { return hasPrev ? pos - n : pos; } // clamped: loads stay unconditional
+    __device__ __forceinline__ size_t next() const { return hasNext ? pos + n : pos; }
+    __device__ __forceinline__ size_t before() const { return hasBefore ? pos - 1 : pos; }
+    __device__ __forceinline__ size_t after() const { return hasAfter ? pos + 1 : pos; }
+};
 
 // "the terms that are present, in this order", as a C expression t1 + t2 + ... evaluates them
 __device__ __forceinline__ void acc_add(float &v, bool &have, float t)
@@ -73,6 +92,8 @@ __device__ __forceinline__ void acc_add(float &v, bool &have, float t)
     have = true;
 }
 
+// (line_coef / line_coef4 below the models)
+
 // ---- early linearisation, 4 neighbours (opticalflowSolvers.c:1763-2410) ------------------------------
 struct AlrElin4 {
     struct Ctx {
@@ -80,43 +101,65 @@ struct AlrElin4 {
         __device__ void shift(size_t) {}
     };
     static constexpr bool INTERIOR_LINES = false;
+    static constexpr bool HAS_COEF4 = true;
+    struct In { // x1, x2: the two off-line neighbours of X in the order they enter d: W,E on a column; S,N on a row
+        float wN, wS, wE, wW, x1, x2, C, D, M, O;
+    };
     template <bool vertical>
-    __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
+    __device__ __forceinline__ static Tri math(const In &v, bool hasN, bool hasS, bool hasW, bool hasE)
     {
-        const size_t pos = AlrGeo<vertical>::pos(i, j, nrows, ncols);
-        const long dS = AlrGeo<vertical>::dS(nrows, ncols), dE = AlrGeo<vertical>::dE(nrows, ncols);
-        const bool hasN = i > 0, hasS = i < nrows - 1, hasW = j > 0, hasE = j < ncols - 1;
-        const float wN = q.wN[pos], wS = q.wS[pos], wE = q.wE[pos], wW = q.wW[pos];
         float b = 0.0f, d = 0.0f;
         bool hb = false, hd = false;
         Tri t;
-        if (hasN) acc_add(b, hb, wN); // b = wN + wS + wE + wW, missing ones skipped (:1917)
-        if (hasS) acc_add(b, hb, wS);
-        if (hasE) acc_add(b, hb, wE);
-        if (hasW) acc_add(b, hb, wW);
-        // loads are unconditional (clamped addresses): a branch around a load serialises the whole step
+        if (hasN) acc_add(b, hb, v.wN); // b = wN + wS + wE + wW, missing ones skipped (:1917)
+        if (hasS) acc_add(b, hb, v.wS);
+        if (hasE) acc_add(b, hb, v.wE);
+        if (hasW) acc_add(b, hb, v.wW);
         if (vertical) { // d = wW*U_w + wE*U_e (:1919)
-            const float xw = q.X[hasW ? pos - dE : pos], xe = q.X[hasE ? pos + dE : pos];
-            if (hasW) acc_add(d, hd, wW * xw);
-            if (hasE) acc_add(d, hd, wE * xe);
-            t.a = hasN ? -wN : 0.0f;
-            t.c = hasS ? -wS : 0.0f;
+            if (hasW) acc_add(d, hd, v.wW * v.x1);
+            if (hasE) acc_add(d, hd, v.wE * v.x2);
+            t.a = hasN ? -v.wN : 0.0f;
+            t.c = hasS ? -v.wS : 0.0f;
         } else { // d = wS*U_s + wN*U_n (:2247)
-            const float xs = q.X[hasS ? pos + dS : pos], xn = q.X[hasN ? pos - dS : pos];
-            if (hasS) acc_add(d, hd, wS * xs);
-            if (hasN) acc_add(d, hd, wN * xn);
-            t.a = hasW ? -wW : 0.0f;
-            t.c = hasE ? -wE : 0.0f;
+            if (hasS) acc_add(d, hd, v.wS * v.x1);
+            if (hasN) acc_add(d, hd, v.wN * v.x2);
+            t.a = hasW ? -v.wW : 0.0f;
+            t.c = hasE ? -v.wE : 0.0f;
         }
-        const float C = q.C[pos], D = q.D[pos], MO = q.M[pos] * q.O[pos];
-        if (!is_nan(C)) { // :1921-1926
-            b += D;
-            d += C;
+        const float MO = v.M * v.O;
+        if (!is_nan(v.C)) { // :1921-1926
+            b += v.D;
+            d += v.C;
             d -= MO;
         }
         t.b = b;
         t.d = d;
         return t;
+    }
+    template <bool vertical> __device__ __forceinline__ static Tri coef(const Ctx &q, const AlrAt &at)
+    {
+        const size_t p = at.pos;
+        const In v{q.wN[p], q.wS[p], q.wE[p], q.wW[p], q.X[vertical ? at.prev() : at.next()], q.X[vertical ? at.next() : at.prev()],
+                   q.C[p], q.D[p], q.M[p], q.O[p]};
+        return vertical ? math<true>(v, at.hasBefore, at.hasAfter, at.hasPrev, at.hasNext)
+                        : math<false>(v, at.hasPrev, at.hasNext, at.hasBefore, at.hasAfter);
+    }
+    // elements k..k+3 of one line (all four inside it), operands fetched 16 bytes at a time
+    template <bool vertical> __device__ __forceinline__ static void coef4(const Ctx &q, int l, int k, int n, int nlines, Tri (&out)[4])
+    {
+        const AlrAt at(l, k, n, nlines);
+        const size_t p = at.pos;
+        float wN[4], wS[4], wE[4], wW[4], x1[4], x2[4], C[4], D[4], M[4], O[4];
+        alr_ld4(q.wN + p, wN); alr_ld4(q.wS + p, wS); alr_ld4(q.wE + p, wE); alr_ld4(q.wW + p, wW);
+        alr_ld4(q.X + (vertical ? at.prev() : at.next()), x1); alr_ld4(q.X + (vertical ? at.next() : at.prev()), x2);
+        alr_ld4(q.C + p, C); alr_ld4(q.D + p, D); alr_ld4(q.M + p, M); alr_ld4(q.O + p, O);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const In v{wN[e], wS[e], wE[e], wW[e], x1[e], x2[e], C[e], D[e], M[e], O[e]};
+            const bool hasBefore = k + e > 0, hasAfter = k + e < n - 1;
+            out[e] = vertical ? math<true>(v, hasBefore, hasAfter, at.hasPrev, at.hasNext)
+                              : math<false>(v, at.hasPrev, at.hasNext, hasBefore, hasAfter);
+        }
     }
 };
 
@@ -128,53 +171,89 @@ template <bool COUPLED> struct AlrLlin4T {
         __device__ void shift(size_t) {}
     };
     static constexpr bool INTERIOR_LINES = false;
+    static constexpr bool HAS_COEF4 = true;
+    struct In { // d1, d2: the increments of the two off-line neighbours: W,E on a column; S,N on a row
+        float wN, wS, wE, wW, Uc, Uw, Ue, Us, Un, d1, d2, C, D, M, O;
+    };
     template <bool vertical>
-    __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
+    __device__ __forceinline__ static Tri math(const In &v, bool hasN, bool hasS, bool hasW, bool hasE)
     {
-        const size_t pos = AlrGeo<vertical>::pos(i, j, nrows, ncols);
-        const long dS = AlrGeo<vertical>::dS(nrows, ncols), dE = AlrGeo<vertical>::dE(nrows, ncols);
-        const bool hasN = i > 0, hasS = i < nrows - 1, hasW = j > 0, hasE = j < ncols - 1;
-        const size_t wpos = hasW ? pos - dE : pos, epos = hasE ? pos + dE : pos; // clamped: loads are unconditional
-        const size_t npos = hasN ? pos - dS : pos, spos = hasS ? pos + dS : pos;
-        const float wN = q.wN[pos], wS = q.wS[pos], wE = q.wE[pos], wW = q.wW[pos];
-        const float Uc = q.U[pos];
-        const float Uw = q.U[wpos], Ue = q.U[epos], Us = q.U[spos], Un = q.U[npos];
         float b = 0.0f, d = 0.0f;
         bool hb = false, hd = false;
         Tri t;
-        if (hasN) acc_add(b, hb, wN);
-        if (hasS) acc_add(b, hb, wS);
-        if (hasE) acc_add(b, hb, wE);
-        if (hasW) acc_add(b, hb, wW);
+        if (hasN) acc_add(b, hb, v.wN);
+        if (hasS) acc_add(b, hb, v.wS);
+        if (hasE) acc_add(b, hb, v.wE);
+        if (hasW) acc_add(b, hb, v.wW);
         // d: W, E, S, N; neighbours that are not on the line carry their increment (:2589-2592, :2933-2936)
         if (vertical) {
-            const float dw = q.X[wpos], de = q.X[epos];
-            if (hasW) acc_add(d, hd, wW * (Uw - Uc + dw));
-            if (hasE) acc_add(d, hd, wE * (Ue - Uc + de));
-            if (hasS) acc_add(d, hd, wS * (Us - Uc));
-            if (hasN) acc_add(d, hd, wN * (Un - Uc));
-            t.a = hasN ? -wN : 0.0f;
-            t.c = hasS ? -wS : 0.0f;
+            if (hasW) acc_add(d, hd, v.wW * (v.Uw - v.Uc + v.d1));
+            if (hasE) acc_add(d, hd, v.wE * (v.Ue - v.Uc + v.d2));
+            if (hasS) acc_add(d, hd, v.wS * (v.Us - v.Uc));
+            if (hasN) acc_add(d, hd, v.wN * (v.Un - v.Uc));
+            t.a = hasN ? -v.wN : 0.0f;
+            t.c = hasS ? -v.wS : 0.0f;
         } else {
-            const float ds = q.X[spos], dn = q.X[npos];
-            if (hasW) acc_add(d, hd, wW * (Uw - Uc));
-            if (hasE) acc_add(d, hd, wE * (Ue - Uc));
-            if (hasS) acc_add(d, hd, wS * (Us - Uc + ds));
-            if (hasN) acc_add(d, hd, wN * (Un - Uc + dn));
-            t.a = hasW ? -wW : 0.0f;
-            t.c = hasE ? -wE : 0.0f;
+            if (hasW) acc_add(d, hd, v.wW * (v.Uw - v.Uc));
+            if (hasE) acc_add(d, hd, v.wE * (v.Ue - v.Uc));
+            if (hasS) acc_add(d, hd, v.wS * (v.Us - v.Uc + v.d1));
+            if (hasN) acc_add(d, hd, v.wN * (v.Un - v.Uc + v.d2));
+            t.a = hasW ? -v.wW : 0.0f;
+            t.c = hasE ? -v.wE : 0.0f;
         }
-        const float C = q.C[pos], D = q.D[pos];
         float MO = 0.0f;
-        if constexpr (COUPLED) MO = q.M[pos] * q.O[pos];
-        if (!is_nan(C)) {
-            b += D;
-            d += C;
+        if constexpr (COUPLED) MO = v.M * v.O;
+        if (!is_nan(v.C)) {
+            b += v.D;
+            d += v.C;
             if constexpr (COUPLED) d -= MO;
         }
         t.b = b;
         t.d = d;
         return t;
+    }
+    template <bool vertical> __device__ __forceinline__ static Tri coef(const Ctx &q, const AlrAt &at)
+    {
+        const size_t p = at.pos;
+        // geographic neighbours: on a column W/E = prev/next line and N/S = before/after; on a row N/S = prev/next, W/E = before/after
+        const size_t pw = vertical ? at.prev() : at.before(), pe = vertical ? at.next() : at.after();
+        const size_t pn = vertical ? at.before() : at.prev(), ps = vertical ? at.after() : at.next();
+        In v{q.wN[p], q.wS[p], q.wE[p], q.wW[p], q.U[p], q.U[pw], q.U[pe], q.U[ps], q.U[pn],
+             q.X[vertical ? pw : ps], q.X[vertical ? pe : pn], q.C[p], q.D[p], 0.0f, 0.0f};
+        if constexpr (COUPLED) {
+            v.M = q.M[p];
+            v.O = q.O[p];
+        }
+        return vertical ? math<true>(v, at.hasBefore, at.hasAfter, at.hasPrev, at.hasNext)
+                        : math<false>(v, at.hasPrev, at.hasNext, at.hasBefore, at.hasAfter);
+    }
+    template <bool vertical> __device__ __forceinline__ static void coef4(const Ctx &q, int l, int k, int n, int nlines, Tri (&out)[4])
+    {
+        const AlrAt at(l, k, n, nlines);
+        const size_t p = at.pos;
+        float wN[4], wS[4], wE[4], wW[4], Uc[4], Up[4], Un[4], dp[4], dn[4], C[4], D[4], M[4] = {0, 0, 0, 0}, O[4] = {0, 0, 0, 0};
+        alr_ld4(q.wN + p, wN); alr_ld4(q.wS + p, wS); alr_ld4(q.wE + p, wE); alr_ld4(q.wW + p, wW);
+        alr_ld4(q.U + p, Uc); alr_ld4(q.U + at.prev(), Up); alr_ld4(q.U + at.next(), Un);
+        alr_ld4(q.X + at.prev(), dp); alr_ld4(q.X + at.next(), dn);
+        alr_ld4(q.C + p, C); alr_ld4(q.D + p, D);
+        if constexpr (COUPLED) {
+            alr_ld4(q.M + p, M);
+            alr_ld4(q.O + p, O);
+        }
+        const float Ubefore = q.U[at.before()];                 // element k-1 (or k itself on the first element: unused then)
+        const float Uafter = q.U[k + 4 <= n - 1 ? p + 4 : p + 3]; // element k+4 (or k+3 on the last group: unused then)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ub = e == 0 ? Ubefore : Uc[e - 1], ua = e == 3 ? Uafter : Uc[e + 1];
+            const bool hasBefore = k + e > 0, hasAfter = k + e < n - 1;
+            if (vertical) { // W/E = prev/next line, N/S = before/after
+                const In v{wN[e], wS[e], wE[e], wW[e], Uc[e], Up[e], Un[e], ua, ub, dp[e], dn[e], C[e], D[e], M[e], O[e]};
+                out[e] = math<true>(v, hasBefore, hasAfter, at.hasPrev, at.hasNext);
+            } else { // N/S = prev/next line, W/E = before/after
+                const In v{wN[e], wS[e], wE[e], wW[e], Uc[e], ub, ua, Un[e], Up[e], dn[e], dp[e], C[e], D[e], M[e], O[e]};
+                out[e] = math<false>(v, at.hasPrev, at.hasNext, hasBefore, hasAfter);
+            }
+        }
     }
 };
 
@@ -218,6 +297,7 @@ struct AlrLlin8 {
         __device__ void shift(size_t) {}
     };
     static constexpr bool INTERIOR_LINES = false;
+    static constexpr bool HAS_COEF4 = false;
     __device__ __forceinline__ static int third(int k, int n) { return k == 0 ? 0 : (k == n - 1 ? 2 : 1); }
     template <bool vertical>
     __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
@@ -270,42 +350,63 @@ struct AlrPde4 {
         }
     };
     static constexpr bool INTERIOR_LINES = false;
+    static constexpr bool HAS_COEF4 = true;
+    struct In { // x1, x2: the two off-line neighbours in the order they enter d: W,E on a column; S,N on a row
+        float wN, wS, wE, wW, x1, x2, T, B;
+    };
     template <bool vertical>
-    __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
+    __device__ __forceinline__ static Tri math(const In &v, bool hasN, bool hasS, bool hasW, bool hasE)
     {
-        const size_t pos = AlrGeo<vertical>::pos(i, j, nrows, ncols);
-        const long dS = AlrGeo<vertical>::dS(nrows, ncols), dE = AlrGeo<vertical>::dE(nrows, ncols);
-        const bool hasN = i > 0, hasS = i < nrows - 1, hasW = j > 0, hasE = j < ncols - 1;
-        const float wN = q.wN[pos], wS = q.wS[pos], wE = q.wE[pos], wW = q.wW[pos];
         float b = 0.0f, d = 0.0f;
         bool hb = false, hd = false;
         Tri t;
         if (vertical) { // pdeSolvers.c:593
-            const float xw = q.X[hasW ? pos - dE : pos], xe = q.X[hasE ? pos + dE : pos];
-            if (hasW) acc_add(d, hd, wW * xw);
-            if (hasE) acc_add(d, hd, wE * xe);
-            t.a = hasN ? -wN : 0.0f;
-            t.c = hasS ? -wS : 0.0f;
+            if (hasW) acc_add(d, hd, v.wW * v.x1);
+            if (hasE) acc_add(d, hd, v.wE * v.x2);
+            t.a = hasN ? -v.wN : 0.0f;
+            t.c = hasS ? -v.wS : 0.0f;
         } else { // :956
-            const float xs = q.X[hasS ? pos + dS : pos], xn = q.X[hasN ? pos - dS : pos];
-            if (hasS) acc_add(d, hd, wS * xs);
-            if (hasN) acc_add(d, hd, wN * xn);
-            t.a = hasW ? -wW : 0.0f;
-            t.c = hasE ? -wE : 0.0f;
+            if (hasS) acc_add(d, hd, v.wS * v.x1);
+            if (hasN) acc_add(d, hd, v.wN * v.x2);
+            t.a = hasW ? -v.wW : 0.0f;
+            t.c = hasE ? -v.wE : 0.0f;
         }
-        const float T = q.T[pos], Bv = q.B[pos];
-        if (!is_nan(T)) { // :595-599
-            b = T;
-            d += Bv;
+        if (!is_nan(v.T)) { // :595-599
+            b = v.T;
+            d += v.B;
         } else { // :601-603: wN + wS + wW + wE, missing ones skipped
-            if (hasN) acc_add(b, hb, wN);
-            if (hasS) acc_add(b, hb, wS);
-            if (hasW) acc_add(b, hb, wW);
-            if (hasE) acc_add(b, hb, wE);
+            if (hasN) acc_add(b, hb, v.wN);
+            if (hasS) acc_add(b, hb, v.wS);
+            if (hasW) acc_add(b, hb, v.wW);
+            if (hasE) acc_add(b, hb, v.wE);
         }
         t.b = b;
         t.d = d;
         return t;
+    }
+    template <bool vertical> __device__ __forceinline__ static Tri coef(const Ctx &q, const AlrAt &at)
+    {
+        const size_t p = at.pos;
+        const In v{q.wN[p], q.wS[p], q.wE[p], q.wW[p], q.X[vertical ? at.prev() : at.next()], q.X[vertical ? at.next() : at.prev()],
+                   q.T[p], q.B[p]};
+        return vertical ? math<true>(v, at.hasBefore, at.hasAfter, at.hasPrev, at.hasNext)
+                        : math<false>(v, at.hasPrev, at.hasNext, at.hasBefore, at.hasAfter);
+    }
+    template <bool vertical> __device__ __forceinline__ static void coef4(const Ctx &q, int l, int k, int n, int nlines, Tri (&out)[4])
+    {
+        const AlrAt at(l, k, n, nlines);
+        const size_t p = at.pos;
+        float wN[4], wS[4], wE[4], wW[4], x1[4], x2[4], T[4], B[4];
+        alr_ld4(q.wN + p, wN); alr_ld4(q.wS + p, wS); alr_ld4(q.wE + p, wE); alr_ld4(q.wW + p, wW);
+        alr_ld4(q.X + (vertical ? at.prev() : at.next()), x1); alr_ld4(q.X + (vertical ? at.next() : at.prev()), x2);
+        alr_ld4(q.T + p, T); alr_ld4(q.B + p, B);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const In v{wN[e], wS[e], wE[e], wW[e], x1[e], x2[e], T[e], B[e]};
+            const bool hasBefore = k + e > 0, hasAfter = k + e < n - 1;
+            out[e] = vertical ? math<true>(v, hasBefore, hasAfter, at.hasPrev, at.hasNext)
+                              : math<false>(v, at.hasPrev, at.hasNext, hasBefore, hasAfter);
+        }
     }
 };
 
@@ -318,6 +419,7 @@ struct AlrPde8 {
         }
     };
     static constexpr bool INTERIOR_LINES = true; // interior columns, then interior rows (pdeSolvers.c:1153, :1290)
+    static constexpr bool HAS_COEF4 = false;
     template <bool vertical>
     __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
     {
@@ -358,6 +460,16 @@ struct AlrPde8 {
         return t;
     }
 };
+
+// element k of line l: (i,j) = (k,l) on a column, (l,k) on a row
+template <class Mdl, bool VERT>
+__device__ __forceinline__ Tri line_coef(const typename Mdl::Ctx &q, int l, int k, int nrows, int ncols)
+{
+    if constexpr (Mdl::HAS_COEF4)
+        return Mdl::template coef<VERT>(q, AlrAt(l, k, VERT ? nrows : ncols, VERT ? ncols : nrows));
+    else
+        return VERT ? Mdl::template coef<true>(q, k, l, nrows, ncols) : Mdl::template coef<false>(q, l, k, nrows, ncols);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Zebra order: one lane per line of the active colour.  cp/dp are scratch planes with x's layout.
@@ -439,6 +551,205 @@ __global__ void __launch_bounds__(64) k_alr_zebra(typename Mdl::Ctx q, float *x,
         }
     }
     x[base] = omega * xs + om1 * old;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Zebra order, 4-neighbour models: one workgroup = 64 lines of the active colour, one SOLVER wave
+// (lane = line, runs the recurrences) fed by seven MOVER waves.
+//
+// A lane that walks its own line makes every load instruction touch 64 cache lines for 256 useful
+// bytes, and one wave can keep only ~63 such loads in flight: k_alr_zebra is bound by that, not by the
+// recurrences.  Here the movers fetch the operands of [64 lines x 8 elements] tiles with 16-byte loads
+// (two lanes per line), turn them into (a,b,c,d) rows with the same Model::math as everywhere else and
+// park them in LDS; the solver reads its line's rows back (conflict-free with one float4 of padding
+// per line) and leaves cp,dp in their place, which the movers write out with 16-byte stores during the
+// next round.  Back-substitution runs the same pipeline downwards on (cp, dp, old x) and writes the
+// blended x.  Rounds of 7 tiles are double-buffered; one __syncthreads per round is the only
+// synchronisation.  Arithmetic and operand order are those of k_alr_zebra (bit-identical).
+// ------------------------------------------------------------------------------------------------
+constexpr int ZB_NM = 7;                       // mover waves = tiles per round
+constexpr int ZB_TE = 8;                       // elements per tile
+constexpr int ZB_LS = ZB_TE + 1;               // float4 per line in a tile (padded)
+constexpr int ZB_TILE = 64 * ZB_LS;            // float4 per tile
+constexpr int ZB_THREADS = 64 * (1 + ZB_NM);
+constexpr size_t ZB_LDS_BYTES = (size_t)2 * ZB_NM * ZB_TILE * sizeof(float4);
+
+__device__ __forceinline__ void alr_st4(float *p, float a, float b, float c, float d)
+{
+    alr_v4 t;
+    t.x = a; t.y = b; t.z = c; t.w = d;
+    *reinterpret_cast<alr_v4 *>(p) = t;
+}
+
+template <class Mdl, bool VERT>
+__global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra2(typename Mdl::Ctx q, float *x, float *__restrict__ cp,
+                                                           float *__restrict__ dp, int nrows, int ncols, size_t frame_stride,
+                                                           int lo, int hi, int colour, float omega)
+{
+    extern __shared__ float4 zb_lds[]; // [2][ZB_NM][ZB_TILE]
+    const size_t fo = (size_t)blockIdx.y * frame_stride;
+    q.shift(fo);
+    x += fo;
+    cp += fo;
+    dp += fo;
+    const int n = VERT ? nrows : ncols, nlines = VERT ? ncols : nrows;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int first = lo + (((lo & 1) != colour) ? 1 : 0);
+    const int lastc = hi - (((hi & 1) != colour) ? 1 : 0);        // last line of this colour
+    const int line0 = first + 128 * (int)blockIdx.x;               // workgroup line index L -> line0 + 2 L
+    const float om1 = 1.0f - omega;
+    constexpr int RE = ZB_NM * ZB_TE;
+    const int nrounds = (n + RE - 1) / RE;
+
+    // mover: lane -> (line index within the workgroup, 4-element group of the tile), two passes per tile
+    const int mslot = wave - 1;
+    auto tile_of = [&](int buf, int slot) { return zb_lds + ((size_t)buf * ZB_NM + slot) * ZB_TILE; };
+
+    auto produce = [&](int r, int buf) { // operands of round r, slot mslot -> (a,b,c,d) rows
+        const int k0 = (r * ZB_NM + mslot) * ZB_TE;
+        if (k0 >= n) return;
+        float4 *T = tile_of(buf, mslot);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int L = (lane >> 1) + 32 * rr, g = lane & 1, k = k0 + 4 * g;
+            const int l = min(line0 + 2 * L, lastc); // clamped: a workgroup past the last line still loads valid memory
+            if (k + 3 <= n - 1) {
+                Tri t[4];
+                Mdl::template coef4<VERT>(q, l, k, n, nlines, t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[L * ZB_LS + 4 * g + e] = make_float4(t[e].a, t[e].b, t[e].c, t[e].d);
+            } else {
+                for (int e = 0; e < 4 && k + e <= n - 1; ++e) {
+                    const Tri t = Mdl::template coef<VERT>(q, AlrAt(l, k + e, n, nlines));
+                    T[L * ZB_LS + 4 * g + e] = make_float4(t.a, t.b, t.c, t.d);
+                }
+            }
+        }
+    };
+    auto store_fwd = [&](int r, int buf) { // cp,dp of round r (left in .z,.w by the solver) -> global
+        const int k0 = (r * ZB_NM + mslot) * ZB_TE;
+        if (k0 >= n) return;
+        const float4 *T = tile_of(buf, mslot);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int L = (lane >> 1) + 32 * rr, g = lane & 1, k = k0 + 4 * g;
+            const int l = line0 + 2 * L;
+            if (l > lastc || k > n - 1) continue;
+            const size_t pos = (size_t)l * n + k;
+            const float4 e0 = T[L * ZB_LS + 4 * g], e1 = T[L * ZB_LS + 4 * g + 1], e2 = T[L * ZB_LS + 4 * g + 2], e3 = T[L * ZB_LS + 4 * g + 3];
+            if (k + 3 <= n - 1) {
+                alr_st4(cp + pos, e0.z, e1.z, e2.z, e3.z);
+                alr_st4(dp + pos, e0.w, e1.w, e2.w, e3.w);
+            } else {
+                const float4 ee[4] = {e0, e1, e2, e3};
+                for (int e = 0; e < 4 && k + e <= n - 1; ++e) {
+                    cp[pos + e] = ee[e].z;
+                    dp[pos + e] = ee[e].w;
+                }
+            }
+        }
+    };
+    auto load_bwd = [&](int r, int buf) { // (cp, dp, old x) of round r -> rows (., old x, cp, dp)
+        const int k0 = (r * ZB_NM + mslot) * ZB_TE;
+        if (k0 >= n) return;
+        float4 *T = tile_of(buf, mslot);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int L = (lane >> 1) + 32 * rr, g = lane & 1, k = k0 + 4 * g;
+            const int l = min(line0 + 2 * L, lastc);
+            if (k > n - 1) continue;
+            const size_t pos = (size_t)l * n + k;
+            if (k + 3 <= n - 1) {
+                float c[4], d[4], o[4];
+                alr_ld4(cp + pos, c); alr_ld4(dp + pos, d); alr_ld4(x + pos, o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[L * ZB_LS + 4 * g + e] = make_float4(0.0f, o[e], c[e], d[e]);
+            } else {
+                for (int e = 0; e < 4 && k + e <= n - 1; ++e) T[L * ZB_LS + 4 * g + e] = make_float4(0.0f, x[pos + e], cp[pos + e], dp[pos + e]);
+            }
+        }
+    };
+    auto store_bwd = [&](int r, int buf) { // blended x of round r (left in .x by the solver) -> global
+        const int k0 = (r * ZB_NM + mslot) * ZB_TE;
+        if (k0 >= n) return;
+        const float4 *T = tile_of(buf, mslot);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int L = (lane >> 1) + 32 * rr, g = lane & 1, k = k0 + 4 * g;
+            const int l = line0 + 2 * L;
+            if (l > lastc || k > n - 1) continue;
+            const size_t pos = (size_t)l * n + k;
+            if (k + 3 <= n - 1) {
+                alr_st4(x + pos, T[L * ZB_LS + 4 * g].x, T[L * ZB_LS + 4 * g + 1].x, T[L * ZB_LS + 4 * g + 2].x, T[L * ZB_LS + 4 * g + 3].x);
+            } else {
+                for (int e = 0; e < 4 && k + e <= n - 1; ++e) x[pos + e] = T[L * ZB_LS + 4 * g + e].x;
+            }
+        }
+    };
+
+    // ---- forward elimination (opticalflowSolvers.c:1890-1950) -------------------------------------------
+    float cpv = 0.0f, dpv = 0.0f; // solver state
+    if (wave > 0) produce(0, 0);
+    __syncthreads();
+    for (int r = 0; r < nrounds; ++r) {
+        if (wave == 0) {
+            for (int m = 0; m < ZB_NM; ++m) {
+                float4 *T = tile_of(r & 1, m) + lane * ZB_LS;
+                const int k0 = (r * ZB_NM + m) * ZB_TE;
+#pragma unroll
+                for (int e = 0; e < ZB_TE; ++e) {
+                    const int k = k0 + e;
+                    if (k > n - 1) break;
+                    const float4 t = T[e]; // (a, b, c, d)
+                    if (k == 0) {
+                        cpv = t.z / t.y;
+                        dpv = t.w / t.y;
+                    } else if (k == n - 1) { // divided, not multiplied by a reciprocal; cp = 0 closes the back-substitution
+                        dpv = (t.w - dpv * t.x) / (t.y - cpv * t.x);
+                        cpv = 0.0f;
+                    } else {
+                        const float div = 1.0f / (t.y - cpv * t.x);
+                        cpv = t.z * div;
+                        dpv = (t.w - dpv * t.x) * div;
+                    }
+                    T[e].z = cpv;
+                    T[e].w = dpv;
+                }
+            }
+        } else {
+            if (r >= 1) store_fwd(r - 1, (r - 1) & 1);
+            if (r + 1 < nrounds) produce(r + 1, (r + 1) & 1);
+        }
+        __syncthreads();
+    }
+    if (wave > 0) {
+        store_fwd(nrounds - 1, (nrounds - 1) & 1);
+        // ---- back-substitution with the lagged SOR blend (:1951-1958): x_k = dp_k - cp_k x_{k+1} ----------
+        load_bwd(nrounds - 1, (nrounds - 1) & 1); // same thread stored these cp,dp: program order makes them visible
+    }
+    __syncthreads();
+    float xs = 0.0f;
+    for (int r = nrounds - 1; r >= 0; --r) {
+        if (wave == 0) {
+            for (int m = ZB_NM - 1; m >= 0; --m) {
+                float4 *T = tile_of(r & 1, m) + lane * ZB_LS;
+                const int k0 = (r * ZB_NM + m) * ZB_TE;
+#pragma unroll
+                for (int e = ZB_TE - 1; e >= 0; --e) {
+                    const int k = k0 + e;
+                    if (k > n - 1) continue;
+                    const float4 t = T[e]; // (., old x, cp, dp)
+                    xs = t.w - t.z * xs;
+                    T[e].x = omega * xs + om1 * t.y;
+                }
+            }
+        } else {
+            if (r + 1 <= nrounds - 1) store_bwd(r + 1, (r + 1) & 1);
+            if (r - 1 >= 0) load_bwd(r - 1, (r - 1) & 1);
+        }
+        __syncthreads();
+    }
+    if (wave > 0) store_bwd(0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------

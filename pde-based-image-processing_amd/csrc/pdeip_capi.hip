@@ -661,6 +661,21 @@ static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, i
         if (first > hi) continue;
         const int count = (hi - first) / 2 + 1;
         const dim3 grid((unsigned)((count + 63) / 64), (unsigned)nframes);
+        if constexpr (Mdl::HAS_COEF4) {
+            static const bool legacy = env_int("PDEIP_ALR_ZEBRA1", 0) != 0; // the one-lane-per-line kernel, for A/B timing
+            if (!legacy) {
+                static bool attr_set[2] = {false, false};
+                if (!attr_set[vertical ? 0 : 1]) {
+                    const void *fn = vertical ? reinterpret_cast<const void *>(&k_alr_zebra2<Mdl, true>) : reinterpret_cast<const void *>(&k_alr_zebra2<Mdl, false>);
+                    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+                    attr_set[vertical ? 0 : 1] = true;
+                }
+                if (vertical) hipLaunchKernelGGL((k_alr_zebra2<Mdl, true>), grid, dim3(ZB_THREADS), ZB_LDS_BYTES, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
+                else hipLaunchKernelGGL((k_alr_zebra2<Mdl, false>), grid, dim3(ZB_THREADS), ZB_LDS_BYTES, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
+                g.last_launches++;
+                continue;
+            }
+        }
         if (vertical) hipLaunchKernelGGL((k_alr_zebra<Mdl, true>), grid, dim3(64), 0, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
         else hipLaunchKernelGGL((k_alr_zebra<Mdl, false>), grid, dim3(64), 0, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
         g.last_launches++;

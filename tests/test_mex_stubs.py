@@ -121,8 +121,11 @@ def test_stubs_run_like_matlab_would_call_them(pdeip, oracle):
     w_ = pb.warp(6, 24, 31, nframes=2)
     err, outs = call(build_stub("BilinInterp_2d", pdeip), 1, [w_["Iin"], w_["X"], w_["Y"]])
     assert err is None and pb.bit_equal(outs[0], oracle.BilinInterp_2d(w_["Iin"], w_["X"], w_["Y"]))
-    err, _ = call(build_stub("Oflow_sor_elin4_2d", pdeip), 2, list(p.values()) + [np.float32(4), np.float32(1.9), np.float32(2)])
-    assert "alternating line relaxation" in err
+    # solver = 2, the drivers' default (alternating line relaxation), through the same stub
+    err, outs = call(build_stub("Oflow_sor_elin4_2d", pdeip), 2, list(p.values()) + [np.float32(2), np.float32(1.5), np.float32(2)])
+    assert err is None
+    for g, w in zip(outs, oracle.Oflow_sor_elin4_2d(*p.values(), 2, 1.5, solver=2)):
+        assert pb.bit_equal(g, w)
     ip = pb.image_pair(7, 21, 26, nframes=2)
     err, outs = call(build_stub("FstDerivatives5", pdeip), 3, [ip["It0"], ip["It1"]])
     assert err is None
