@@ -554,25 +554,33 @@ __global__ void __launch_bounds__(64) k_alr_zebra(typename Mdl::Ctx q, float *x,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Zebra order, 4-neighbour models: one workgroup = 64 lines of the active colour, one SOLVER wave
+// Zebra order, 4-neighbour models: one workgroup = 16 lines of the active colour, one SOLVER wave
 // (lane = line, runs the recurrences) fed by seven MOVER waves.
 //
 // A lane that walks its own line makes every load instruction touch 64 cache lines for 256 useful
 // bytes, and one wave can keep only ~63 such loads in flight: k_alr_zebra is bound by that, not by the
-// recurrences.  Here the movers fetch the operands of [64 lines x 8 elements] tiles with 16-byte loads
-// (two lanes per line), turn them into (a,b,c,d) rows with the same Model::math as everywhere else and
-// park them in LDS; the solver reads its line's rows back (conflict-free with one float4 of padding
-// per line) and leaves cp,dp in their place, which the movers write out with 16-byte stores during the
-// next round.  Back-substitution runs the same pipeline downwards on (cp, dp, old x) and writes the
-// blended x.  Rounds of 7 tiles are double-buffered; one __syncthreads per round is the only
-// synchronisation.  Arithmetic and operand order are those of k_alr_zebra (bit-identical).
+// recurrences.  Here the movers fetch the operands of [16 lines x 32 elements] tiles with 16-byte loads
+// (eight lanes cover 128 contiguous bytes of a line), turn them into (a,b,c,d) rows with the same
+// Model::math as everywhere else and park them in LDS; the solver reads its line's rows back and leaves
+// cp,dp in their place, which the movers write out with 16-byte stores during the next round.
+// Back-substitution runs the same pipeline downwards on (cp, dp, old x) and writes the blended x.
+// Rounds of 7 tiles are double-buffered; one barrier per round is the only synchronisation.  Only 16
+// lines per workgroup because the frame has only ~1000-2000 lines per colour: the recurrences cost the
+// same however many lanes run them, but 120 workgroups pull operands through 120 CUs' memory paths
+// instead of 30.  Arithmetic and operand order are those of k_alr_zebra (bit-identical).
 // ------------------------------------------------------------------------------------------------
-constexpr int ZB_NM = 7;                       // mover waves = tiles per round
-constexpr int ZB_TE = 8;                       // elements per tile
-constexpr int ZB_LS = ZB_TE + 1;               // float4 per line in a tile (padded)
-constexpr int ZB_TILE = 64 * ZB_LS;            // float4 per tile
+constexpr int ZB_NM = 7;                        // mover waves = tiles per round
+constexpr int ZB_LW = 16;                       // lines per workgroup
+constexpr int ZB_TE = 32;                       // elements per tile
+constexpr int ZB_SB = 8;                        // elements the solver holds in registers at a time
+constexpr int ZB_GP = ZB_TE / 4;                // 4-element groups per line of a tile
+constexpr int ZB_LP = 64 / ZB_GP;               // lines one mover pass covers
+constexpr int ZB_NP = ZB_LW / ZB_LP;            // mover passes per tile
+constexpr int ZB_LS = ZB_TE + 1;                // float4 per line in a tile (padded)
+constexpr int ZB_TILE = ZB_LW * ZB_LS;          // float4 per tile
 constexpr int ZB_THREADS = 64 * (1 + ZB_NM);
 constexpr size_t ZB_LDS_BYTES = (size_t)2 * ZB_NM * ZB_TILE * sizeof(float4);
+static_assert(ZB_NP * ZB_LP == ZB_LW && ZB_TE % ZB_SB == 0, "zebra tile geometry");
 
 __device__ __forceinline__ void alr_st4(float *p, float a, float b, float c, float d)
 {
@@ -581,175 +589,266 @@ __device__ __forceinline__ void alr_st4(float *p, float a, float b, float c, flo
     *reinterpret_cast<alr_v4 *>(p) = t;
 }
 
-template <class Mdl, bool VERT>
+// FACTOR: forward recurrence of the coefficient-only part, once per call: cp -> cp plane; the divisor
+//         1/(b - cp' a) -> dv plane (b itself for the first element, the bare denominator for the last:
+//         those two are divided by, as in the reference).  No back-substitution.
+// APPLY:  one relaxation of the lines first, first+lstep, ... <= lastc with those planes: the forward
+//         recurrence is down to dp = (d - dp' a) * dv -- three dependent instructions instead of a division.
+enum { ZB_FACTOR = 1, ZB_APPLY = 2 };
+
+template <class Mdl, bool VERT, int MODE>
 __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra2(typename Mdl::Ctx q, float *x, float *__restrict__ cp,
-                                                           float *__restrict__ dp, int nrows, int ncols, size_t frame_stride,
-                                                           int lo, int hi, int colour, float omega)
+                                                           float *__restrict__ dv, float *__restrict__ dp, int nrows, int ncols,
+                                                           size_t frame_stride, int first, int lastc, int lstep, float omega)
 {
     extern __shared__ float4 zb_lds[]; // [2][ZB_NM][ZB_TILE]
     const size_t fo = (size_t)blockIdx.y * frame_stride;
     q.shift(fo);
     x += fo;
     cp += fo;
+    dv += fo;
     dp += fo;
     const int n = VERT ? nrows : ncols, nlines = VERT ? ncols : nrows;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int first = lo + (((lo & 1) != colour) ? 1 : 0);
-    const int lastc = hi - (((hi & 1) != colour) ? 1 : 0);        // last line of this colour
-    const int line0 = first + 128 * (int)blockIdx.x;               // workgroup line index L -> line0 + 2 L
+    const int line0 = first + lstep * ZB_LW * (int)blockIdx.x;     // workgroup line index L -> line0 + lstep * L
     const float om1 = 1.0f - omega;
     constexpr int RE = ZB_NM * ZB_TE;
     const int nrounds = (n + RE - 1) / RE;
 
-    // mover: lane -> (line index within the workgroup, 4-element group of the tile), two passes per tile
+    // mover: lane -> (line index within the workgroup, 4-element group of the tile), ZB_NP passes per tile
     const int mslot = wave - 1;
-    auto tile_of = [&](int buf, int slot) { return zb_lds + ((size_t)buf * ZB_NM + slot) * ZB_TILE; };
+    const int mg = lane % ZB_GP, ml = lane / ZB_GP;
+    auto tile_of = [&](int buf, int slot) __attribute__((always_inline)) { return zb_lds + ((size_t)buf * ZB_NM + slot) * ZB_TILE; };
 
-    auto produce = [&](int r, int buf) { // operands of round r, slot mslot -> (a,b,c,d) rows
+    auto produce = [&](int r, int buf) __attribute__((always_inline)) { // operands of round r, slot mslot -> (a,b,c,d) rows
         const int k0 = (r * ZB_NM + mslot) * ZB_TE;
         if (k0 >= n) return;
         float4 *T = tile_of(buf, mslot);
+        if (k0 + ZB_TE - 1 <= n - 1) { // whole tile inside the line (wave-uniform): all passes' loads go out together
+            Tri t[ZB_NP][4];
+            float fc[ZB_NP][4], fd[ZB_NP][4];
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int L = (lane >> 1) + 32 * rr, g = lane & 1, k = k0 + 4 * g;
-            const int l = min(line0 + 2 * L, lastc); // clamped: a workgroup past the last line still loads valid memory
-            if (k + 3 <= n - 1) {
-                Tri t[4];
-                Mdl::template coef4<VERT>(q, l, k, n, nlines, t);
+            for (int rr = 0; rr < ZB_NP; ++rr) {
+                const int l = min(line0 + lstep * (ml + ZB_LP * rr), lastc);
+                Mdl::template coef4<VERT>(q, l, k0 + 4 * mg, n, nlines, t[rr]);
+                if (MODE == ZB_APPLY) {
+                    alr_ld4(cp + (size_t)l * n + k0 + 4 * mg, fc[rr]);
+                    alr_ld4(dv + (size_t)l * n + k0 + 4 * mg, fd[rr]);
+                }
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) T[L * ZB_LS + 4 * g + e] = make_float4(t[e].a, t[e].b, t[e].c, t[e].d);
-            } else {
-                for (int e = 0; e < 4 && k + e <= n - 1; ++e) {
+            for (int rr = 0; rr < ZB_NP; ++rr)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    T[(ml + ZB_LP * rr) * ZB_LS + 4 * mg + e] = MODE == ZB_APPLY ? make_float4(t[rr][e].a, fd[rr][e], fc[rr][e], t[rr][e].d)
+                                                                                  : make_float4(t[rr][e].a, t[rr][e].b, t[rr][e].c, t[rr][e].d);
+            return;
+        }
+#pragma unroll
+        for (int rr = 0; rr < ZB_NP; ++rr) {
+            const int L = ml + ZB_LP * rr, k = k0 + 4 * mg;
+            const int l = min(line0 + lstep * L, lastc); // clamped: a workgroup past the last line still loads valid memory
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e <= n - 1) {
                     const Tri t = Mdl::template coef<VERT>(q, AlrAt(l, k + e, n, nlines));
-                    T[L * ZB_LS + 4 * g + e] = make_float4(t.a, t.b, t.c, t.d);
+                    const size_t pos = (size_t)l * n + k + e;
+                    T[L * ZB_LS + 4 * mg + e] = MODE == ZB_APPLY ? make_float4(t.a, dv[pos], cp[pos], t.d) : make_float4(t.a, t.b, t.c, t.d);
                 }
-            }
         }
     };
-    auto store_fwd = [&](int r, int buf) { // cp,dp of round r (left in .z,.w by the solver) -> global
-        const int k0 = (r * ZB_NM + mslot) * ZB_TE;
-        if (k0 >= n) return;
+    // results of a finished tile: grabbed into registers first (the tile is about to be refilled), written
+    // to global after the next tile's loads have been consumed, so no store sits on the critical path
+    float ra[ZB_NP][4], rb[ZB_NP][4]; // forward: cp, dp; backward: blended x (ra)
+    auto grab = [&](int buf, bool fwd) __attribute__((always_inline)) {
         const float4 *T = tile_of(buf, mslot);
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int L = (lane >> 1) + 32 * rr, g = lane & 1, k = k0 + 4 * g;
-            const int l = line0 + 2 * L;
-            if (l > lastc || k > n - 1) continue;
-            const size_t pos = (size_t)l * n + k;
-            const float4 e0 = T[L * ZB_LS + 4 * g], e1 = T[L * ZB_LS + 4 * g + 1], e2 = T[L * ZB_LS + 4 * g + 2], e3 = T[L * ZB_LS + 4 * g + 3];
-            if (k + 3 <= n - 1) {
-                alr_st4(cp + pos, e0.z, e1.z, e2.z, e3.z);
-                alr_st4(dp + pos, e0.w, e1.w, e2.w, e3.w);
-            } else {
-                const float4 ee[4] = {e0, e1, e2, e3};
-                for (int e = 0; e < 4 && k + e <= n - 1; ++e) {
-                    cp[pos + e] = ee[e].z;
-                    dp[pos + e] = ee[e].w;
-                }
+        for (int rr = 0; rr < ZB_NP; ++rr)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 t = T[(ml + ZB_LP * rr) * ZB_LS + 4 * mg + e];
+                ra[rr][e] = fwd ? t.z : t.x;
+                rb[rr][e] = t.w;
+            }
+    };
+    auto put = [&](int r, bool fwd) __attribute__((always_inline)) { // FACTOR: ra -> cp, rb -> dv; APPLY forward: rb -> dp, backward: ra -> x
+        const int k0 = (r * ZB_NM + mslot) * ZB_TE;
+#pragma unroll
+        for (int rr = 0; rr < ZB_NP; ++rr) {
+            const int k = k0 + 4 * mg;
+            const int l = line0 + lstep * (ml + ZB_LP * rr);
+            const size_t pos = (size_t)min(l, lastc) * n + min(k, n - 1);
+            float *pa = fwd ? cp : x, *pb = MODE == ZB_FACTOR ? dv : dp;
+            const bool use_a = !fwd || MODE == ZB_FACTOR;
+            if (l <= lastc && k + 3 <= n - 1) {
+                if (use_a) alr_st4(pa + pos, ra[rr][0], ra[rr][1], ra[rr][2], ra[rr][3]);
+                if (fwd) alr_st4(pb + pos, rb[rr][0], rb[rr][1], rb[rr][2], rb[rr][3]);
+            } else if (l <= lastc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e <= n - 1) {
+                        if (use_a) pa[pos + e] = ra[rr][e];
+                        if (fwd) pb[pos + e] = rb[rr][e];
+                    }
             }
         }
     };
-    auto load_bwd = [&](int r, int buf) { // (cp, dp, old x) of round r -> rows (., old x, cp, dp)
+    auto load_bwd = [&](int r, int buf) __attribute__((always_inline)) { // (cp, dp, old x) of round r -> rows (., old x, cp, dp)
         const int k0 = (r * ZB_NM + mslot) * ZB_TE;
         if (k0 >= n) return;
         float4 *T = tile_of(buf, mslot);
+        if (k0 + ZB_TE - 1 <= n - 1) {
+            float c[ZB_NP][4], d[ZB_NP][4], o[ZB_NP][4];
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int L = (lane >> 1) + 32 * rr, g = lane & 1, k = k0 + 4 * g;
-            const int l = min(line0 + 2 * L, lastc);
-            if (k > n - 1) continue;
-            const size_t pos = (size_t)l * n + k;
-            if (k + 3 <= n - 1) {
-                float c[4], d[4], o[4];
-                alr_ld4(cp + pos, c); alr_ld4(dp + pos, d); alr_ld4(x + pos, o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) T[L * ZB_LS + 4 * g + e] = make_float4(0.0f, o[e], c[e], d[e]);
-            } else {
-                for (int e = 0; e < 4 && k + e <= n - 1; ++e) T[L * ZB_LS + 4 * g + e] = make_float4(0.0f, x[pos + e], cp[pos + e], dp[pos + e]);
+            for (int rr = 0; rr < ZB_NP; ++rr) {
+                const size_t pos = (size_t)min(line0 + lstep * (ml + ZB_LP * rr), lastc) * n + k0 + 4 * mg;
+                alr_ld4(cp + pos, c[rr]); alr_ld4(dp + pos, d[rr]); alr_ld4(x + pos, o[rr]);
             }
+#pragma unroll
+            for (int rr = 0; rr < ZB_NP; ++rr)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[(ml + ZB_LP * rr) * ZB_LS + 4 * mg + e] = make_float4(0.0f, o[rr][e], c[rr][e], d[rr][e]);
+            return;
+        }
+#pragma unroll
+        for (int rr = 0; rr < ZB_NP; ++rr) {
+            const int L = ml + ZB_LP * rr, k = k0 + 4 * mg;
+            const size_t pos = (size_t)min(line0 + lstep * L, lastc) * n + min(k, n - 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e <= n - 1) T[L * ZB_LS + 4 * mg + e] = make_float4(0.0f, x[pos + e], cp[pos + e], dp[pos + e]);
         }
     };
-    auto store_bwd = [&](int r, int buf) { // blended x of round r (left in .x by the solver) -> global
-        const int k0 = (r * ZB_NM + mslot) * ZB_TE;
-        if (k0 >= n) return;
-        const float4 *T = tile_of(buf, mslot);
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int L = (lane >> 1) + 32 * rr, g = lane & 1, k = k0 + 4 * g;
-            const int l = line0 + 2 * L;
-            if (l > lastc || k > n - 1) continue;
-            const size_t pos = (size_t)l * n + k;
-            if (k + 3 <= n - 1) {
-                alr_st4(x + pos, T[L * ZB_LS + 4 * g].x, T[L * ZB_LS + 4 * g + 1].x, T[L * ZB_LS + 4 * g + 2].x, T[L * ZB_LS + 4 * g + 3].x);
-            } else {
-                for (int e = 0; e < 4 && k + e <= n - 1; ++e) x[pos + e] = T[L * ZB_LS + 4 * g + e].x;
-            }
-        }
-    };
+    // LDS hand-off only: global stores need not have landed (nothing re-reads them across threads in this
+    // kernel), so the barrier does not drain them as __syncthreads() would
+    auto lds_barrier = [&]() __attribute__((always_inline)) { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // solver: the round is a sequence of ZB_NM * ZB_TE / ZB_SB sub-blocks of ZB_SB elements of this lane's line
+    constexpr int SPT = ZB_TE / ZB_SB, NSUB = ZB_NM * SPT;
+    auto sub_rows = [&](int buf, int j) __attribute__((always_inline)) { return tile_of(buf, j / SPT) + lane * ZB_LS + (j % SPT) * ZB_SB; };
+    const bool solver = wave == 0 && lane < ZB_LW;
 
     // ---- forward elimination (opticalflowSolvers.c:1890-1950) -------------------------------------------
-    float cpv = 0.0f, dpv = 0.0f; // solver state
-    if (wave > 0) produce(0, 0);
-    __syncthreads();
-    for (int r = 0; r < nrounds; ++r) {
-        if (wave == 0) {
-            for (int m = 0; m < ZB_NM; ++m) {
-                float4 *T = tile_of(r & 1, m) + lane * ZB_LS;
-                const int k0 = (r * ZB_NM + m) * ZB_TE;
+    float cpv = 0.0f, dpv = 0.0f; // solver state (cp while factoring, dp while applying)
+    // one sub-block of the forward recurrence on rows already in registers; results back to LDS
+    auto fwd_block = [&](float4 (&row)[ZB_SB], float4 *T, int k0) __attribute__((always_inline)) {
+        if (k0 > n - 1) return; // past the end of the line (last round only); wave-uniform
+        if (MODE == ZB_APPLY) { // row = (a, divisor, cp, d): dp -> .w
+            if (k0 >= 1 && k0 + ZB_SB - 1 <= n - 2) {
 #pragma unroll
-                for (int e = 0; e < ZB_TE; ++e) {
-                    const int k = k0 + e;
-                    if (k > n - 1) break;
-                    const float4 t = T[e]; // (a, b, c, d)
-                    if (k == 0) {
-                        cpv = t.z / t.y;
-                        dpv = t.w / t.y;
-                    } else if (k == n - 1) { // divided, not multiplied by a reciprocal; cp = 0 closes the back-substitution
-                        dpv = (t.w - dpv * t.x) / (t.y - cpv * t.x);
-                        cpv = 0.0f;
-                    } else {
-                        const float div = 1.0f / (t.y - cpv * t.x);
-                        cpv = t.z * div;
-                        dpv = (t.w - dpv * t.x) * div;
-                    }
-                    T[e].z = cpv;
+                for (int e = 0; e < ZB_SB; ++e) {
+                    dpv = (row[e].w - dpv * row[e].x) * row[e].y;
+                    T[e].w = dpv;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < ZB_SB; ++e) {
+                    const int k = k0 + e; // wave-uniform
+                    if (k == 0) dpv = row[e].w / row[e].y;
+                    else if (k == n - 1) dpv = (row[e].w - dpv * row[e].x) / row[e].y;
+                    else if (k < n - 1) dpv = (row[e].w - dpv * row[e].x) * row[e].y;
                     T[e].w = dpv;
                 }
             }
-        } else {
-            if (r >= 1) store_fwd(r - 1, (r - 1) & 1);
-            if (r + 1 < nrounds) produce(r + 1, (r + 1) & 1);
-        }
-        __syncthreads();
-    }
-    if (wave > 0) {
-        store_fwd(nrounds - 1, (nrounds - 1) & 1);
-        // ---- back-substitution with the lagged SOR blend (:1951-1958): x_k = dp_k - cp_k x_{k+1} ----------
-        load_bwd(nrounds - 1, (nrounds - 1) & 1); // same thread stored these cp,dp: program order makes them visible
-    }
-    __syncthreads();
-    float xs = 0.0f;
-    for (int r = nrounds - 1; r >= 0; --r) {
-        if (wave == 0) {
-            for (int m = ZB_NM - 1; m >= 0; --m) {
-                float4 *T = tile_of(r & 1, m) + lane * ZB_LS;
-                const int k0 = (r * ZB_NM + m) * ZB_TE;
+        } else if (k0 >= 1 && k0 + ZB_SB - 1 <= n - 2) { // FACTOR, no first / last element in this sub-block
 #pragma unroll
-                for (int e = ZB_TE - 1; e >= 0; --e) {
-                    const int k = k0 + e;
-                    if (k > n - 1) continue;
-                    const float4 t = T[e]; // (., old x, cp, dp)
-                    xs = t.w - t.z * xs;
-                    T[e].x = omega * xs + om1 * t.y;
-                }
+            for (int e = 0; e < ZB_SB; ++e) {
+                const float div = 1.0f / (row[e].y - cpv * row[e].x);
+                cpv = row[e].z * div;
+                T[e].z = cpv;
+                T[e].w = div;
             }
         } else {
-            if (r + 1 <= nrounds - 1) store_bwd(r + 1, (r + 1) & 1);
-            if (r - 1 >= 0) load_bwd(r - 1, (r - 1) & 1);
+#pragma unroll
+            for (int e = 0; e < ZB_SB; ++e) {
+                const int k = k0 + e; // wave-uniform
+                float dvv = 0.0f;
+                if (k == 0) {
+                    dvv = row[e].y; // the first element is divided by b
+                    cpv = row[e].z / row[e].y;
+                } else if (k == n - 1) { // ... and the last by its bare denominator; cp = 0 closes the back-substitution
+                    dvv = row[e].y - cpv * row[e].x;
+                    cpv = 0.0f;
+                } else if (k < n - 1) {
+                    dvv = 1.0f / (row[e].y - cpv * row[e].x);
+                    cpv = row[e].z * dvv;
+                }
+                T[e].z = cpv;
+                T[e].w = dvv;
+            }
         }
-        __syncthreads();
+    };
+    auto fetch = [&](float4 (&row)[ZB_SB], int buf, int j) __attribute__((always_inline)) {
+        const float4 *T = sub_rows(buf, min(max(j, 0), NSUB - 1));
+#pragma unroll
+        for (int e = 0; e < ZB_SB; ++e) row[e] = T[e];
+    };
+    static_assert(NSUB % 2 == 0, "the solver ping-pongs two register sets");
+
+    if (wave > 0) produce(0, 0);
+    lds_barrier();
+    for (int r = 0; r < nrounds; ++r) {
+        if (solver) {
+            // two register sets: the next sub-block's rows are in flight from LDS while this one's steps run
+            float4 A[ZB_SB], B[ZB_SB];
+            const int kr = __builtin_amdgcn_readfirstlane(r * RE);
+            fetch(A, r & 1, 0);
+            for (int j = 0; j < NSUB; j += 2) {
+                fetch(B, r & 1, j + 1);
+                fwd_block(A, sub_rows(r & 1, j), kr + j * ZB_SB);
+                fetch(A, r & 1, j + 2);
+                fwd_block(B, sub_rows(r & 1, j + 1), kr + (j + 1) * ZB_SB);
+            }
+        } else if (wave > 0) {
+            if (r >= 1) grab((r - 1) & 1, true);
+            if (r + 1 < nrounds) produce(r + 1, (r + 1) & 1);
+            if (r >= 1) put(r - 1, true);
+        }
+        lds_barrier();
     }
-    if (wave > 0) store_bwd(0, 0);
+    if (wave > 0) {
+        grab((nrounds - 1) & 1, true);
+        put(nrounds - 1, true);
+    }
+    if (MODE == ZB_FACTOR) return;
+    if (wave > 0) {
+        __threadfence_block(); // every dp this thread reloads below was stored by this thread: drain them once
+        // ---- back-substitution with the lagged SOR blend (:1951-1958): x_k = dp_k - cp_k x_{k+1} ----------
+        load_bwd(nrounds - 1, (nrounds - 1) & 1);
+    }
+    lds_barrier();
+    float xs = 0.0f;
+    auto bwd_block = [&](float4 (&row)[ZB_SB], float4 *T, int k0) __attribute__((always_inline)) { // row = (., old x, cp, dp)
+        if (k0 > n - 1) return;
+#pragma unroll
+        for (int e = ZB_SB - 1; e >= 0; --e) {
+            if (k0 + e <= n - 1) { // wave-uniform
+                xs = row[e].w - row[e].z * xs;
+                T[e].x = omega * xs + om1 * row[e].y;
+            }
+        }
+    };
+    for (int r = nrounds - 1; r >= 0; --r) {
+        if (solver) {
+            float4 A[ZB_SB], B[ZB_SB];
+            const int kr = __builtin_amdgcn_readfirstlane(r * RE);
+            fetch(A, r & 1, NSUB - 1);
+            for (int j = NSUB - 1; j >= 0; j -= 2) {
+                fetch(B, r & 1, j - 1);
+                bwd_block(A, sub_rows(r & 1, j), kr + j * ZB_SB);
+                fetch(A, r & 1, j - 2);
+                bwd_block(B, sub_rows(r & 1, j - 1), kr + (j - 1) * ZB_SB);
+            }
+        } else if (wave > 0) {
+            if (r + 1 <= nrounds - 1) grab((r + 1) & 1, false);
+            if (r - 1 >= 0) load_bwd(r - 1, (r - 1) & 1);
+            if (r + 1 <= nrounds - 1) put(r + 1, false);
+        }
+        lds_barrier();
+    }
+    if (wave > 0) {
+        grab(0, false);
+        put(0, false);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -581,6 +581,25 @@ struct AlrFactors {
     float *cp[2][2], *dv[2][2]; // [chain][vertical ? 0 : 1]
 };
 
+template <class Mdl, bool VERT, int MODE>
+static int zebra2_launch(hipStream_t s, const typename Mdl::Ctx &q, float *x, float *cp, float *dv, float *dp, int nrows, int ncols,
+                         int nframes, int first, int lastc, int lstep, float omega)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_alr_zebra2<Mdl, VERT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
+        attr_set = true;
+    }
+    const int count = (lastc - first) / lstep + 1;
+    hipLaunchKernelGGL((k_alr_zebra2<Mdl, VERT, MODE>), dim3((unsigned)((count + ZB_LW - 1) / ZB_LW), (unsigned)nframes), dim3(ZB_THREADS),
+                       ZB_LDS_BYTES, s, q, x, cp, dv, dp, nrows, ncols, (size_t)nrows * ncols, first, lastc, lstep, omega);
+    g.last_launches++;
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+// cp and divisor planes of every (field, direction): the part of the Thomas recurrence that depends on the
+// coefficient planes only, once per call (pdeip_alr.hpp).  Column planes from q, row planes from the transposed qt.
 template <class Mdl>
 static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, const typename Mdl::Ctx *qt, int nch, int nrows, int ncols, int nframes,
                       AlrFactors *f)
@@ -594,10 +613,15 @@ static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, const typename 
             f->cp[c][d] = base + plane * (size_t)((c * 2 + d) * 2);
             f->dv[c][d] = f->cp[c][d] + plane;
             const int hi = (d == 0 ? ncols : nrows) - 1 - lo;
-            const dim3 grid((unsigned)((hi - lo + 1 + 63) / 64), (unsigned)nframes);
-            if (d == 0) hipLaunchKernelGGL((k_alr_factor<Mdl, true>), grid, dim3(64), 0, s, q[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
-            else hipLaunchKernelGGL((k_alr_factor<Mdl, false>), grid, dim3(64), 0, s, qt[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
-            g.last_launches++;
+            if constexpr (Mdl::HAS_COEF4) {
+                if (d == 0) RC((zebra2_launch<Mdl, true, ZB_FACTOR>(s, q[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
+                else RC((zebra2_launch<Mdl, false, ZB_FACTOR>(s, qt[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
+            } else {
+                const dim3 grid((unsigned)((hi - lo + 1 + 63) / 64), (unsigned)nframes);
+                if (d == 0) hipLaunchKernelGGL((k_alr_factor<Mdl, true>), grid, dim3(64), 0, s, q[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
+                else hipLaunchKernelGGL((k_alr_factor<Mdl, false>), grid, dim3(64), 0, s, qt[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
+                g.last_launches++;
+            }
         }
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
@@ -645,10 +669,11 @@ static int alr_lex_pass(hipStream_t s, const typename Mdl::Ctx *q, float *const 
     return PDEIP_OK;
 }
 
-// One direction of one field in zebra order: even lines, then odd lines, one lane per line.
+// One direction of one field in zebra order: even lines, then odd lines.  4-neighbour models: k_alr_zebra2 with
+// the per-call factor planes (cpf, dvf); the others: one lane per line (k_alr_zebra).
 template <class Mdl>
-static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, int nrows, int ncols, int nframes, bool vertical,
-                          float omega)
+static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, const float *cpf, const float *dvf, int nrows, int ncols,
+                          int nframes, bool vertical, float omega)
 {
     const int lo = Mdl::INTERIOR_LINES ? 1 : 0;
     const int hi = (vertical ? ncols : nrows) - 1 - lo;
@@ -659,23 +684,16 @@ static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, i
     for (int colour = 0; colour < 2; colour++) {
         const int first = lo + (((lo & 1) != colour) ? 1 : 0);
         if (first > hi) continue;
-        const int count = (hi - first) / 2 + 1;
-        const dim3 grid((unsigned)((count + 63) / 64), (unsigned)nframes);
+        const int lastc = hi - (((hi & 1) != colour) ? 1 : 0);
         if constexpr (Mdl::HAS_COEF4) {
-            static const bool legacy = env_int("PDEIP_ALR_ZEBRA1", 0) != 0; // the one-lane-per-line kernel, for A/B timing
-            if (!legacy) {
-                static bool attr_set[2] = {false, false};
-                if (!attr_set[vertical ? 0 : 1]) {
-                    const void *fn = vertical ? reinterpret_cast<const void *>(&k_alr_zebra2<Mdl, true>) : reinterpret_cast<const void *>(&k_alr_zebra2<Mdl, false>);
-                    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
-                    attr_set[vertical ? 0 : 1] = true;
-                }
-                if (vertical) hipLaunchKernelGGL((k_alr_zebra2<Mdl, true>), grid, dim3(ZB_THREADS), ZB_LDS_BYTES, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
-                else hipLaunchKernelGGL((k_alr_zebra2<Mdl, false>), grid, dim3(ZB_THREADS), ZB_LDS_BYTES, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
-                g.last_launches++;
+            if (cpf) {
+                if (vertical) RC((zebra2_launch<Mdl, true, ZB_APPLY>(s, q, x, const_cast<float *>(cpf), const_cast<float *>(dvf), dp, nrows, ncols, nframes, first, lastc, 2, omega)));
+                else RC((zebra2_launch<Mdl, false, ZB_APPLY>(s, q, x, const_cast<float *>(cpf), const_cast<float *>(dvf), dp, nrows, ncols, nframes, first, lastc, 2, omega)));
                 continue;
             }
         }
+        const int count = (hi - first) / 2 + 1;
+        const dim3 grid((unsigned)((count + 63) / 64), (unsigned)nframes);
         if (vertical) hipLaunchKernelGGL((k_alr_zebra<Mdl, true>), grid, dim3(64), 0, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
         else hipLaunchKernelGGL((k_alr_zebra<Mdl, false>), grid, dim3(64), 0, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
         g.last_launches++;
@@ -759,18 +777,19 @@ static int run_alr(const char *who, hipStream_t s, const typename Mdl::Ctx *q, f
     AlrTwin tw;
     RC(alr_make_twins(s, q, qt, nch, x, xt, nrows, ncols, nframes, &tw));
     AlrFactors f{};
-    if (mode == PDEIP_MODE_EXACT_ORDER) RC(alr_factor<Mdl>(s, q, qt, nch, nrows, ncols, nframes, &f));
+    static const bool zebra1 = env_int("PDEIP_ALR_ZEBRA1", 0) != 0; // the one-lane-per-line kernel for every model (A/B timing)
+    if (mode == PDEIP_MODE_EXACT_ORDER || (Mdl::HAS_COEF4 && !zebra1)) RC(alr_factor<Mdl>(s, q, qt, nch, nrows, ncols, nframes, &f));
     SweepTimer timer(s);
     for (int it = 0; it < iter; it++) {
         if (mode == PDEIP_MODE_EXACT_ORDER)
             RC(alr_lex_pass<Mdl>(s, q, x, f, fwd, nch, nrows, ncols, nframes, true, omega));
         else
-            for (int c = 0; c < nch; c++) RC(alr_zebra_pass<Mdl>(s, q[c], x[c], nrows, ncols, nframes, true, omega));
+            for (int c = 0; c < nch; c++) RC(alr_zebra_pass<Mdl>(s, q[c], x[c], f.cp[c][0], f.dv[c][0], nrows, ncols, nframes, true, omega));
         for (int c = 0; c < nch; c++) RC(alr_transpose(s, xt[c], x[c], nrows, ncols, nframes));
         if (mode == PDEIP_MODE_EXACT_ORDER)
             RC(alr_lex_pass<Mdl>(s, qt, xt, f, nch == 2 ? rev : fwd, nch, nrows, ncols, nframes, false, omega));
         else
-            for (int c = nch - 1; c >= 0; c--) RC(alr_zebra_pass<Mdl>(s, qt[c], xt[c], nrows, ncols, nframes, false, omega));
+            for (int c = nch - 1; c >= 0; c--) RC(alr_zebra_pass<Mdl>(s, qt[c], xt[c], f.cp[c][1], f.dv[c][1], nrows, ncols, nframes, false, omega));
         for (int c = 0; c < nch; c++) RC(alr_transpose(s, x[c], xt[c], ncols, nrows, nframes));
     }
     timer.stop(iter);
