@@ -221,7 +221,7 @@ def main():
             lib.orc_oflow_alr_elin4(hu.ctypes.data, hv.ctypes.data, *[a.ctypes.data for a in hc], NROWS, NCOLS, 1, ctypes.c_float(1.5), 0)
             alr_cpu = time.perf_counter() - t0
             alr = {"unit": "iterations/s", "cpu_oracle": round(1.0 / alr_cpu, 3), "omega": 1.5}
-            for name, mode, reps in (("exact_order", capi.MODE_EXACT_ORDER, 1), ("zebra", capi.MODE_RED_BLACK, 4)):
+            for name, mode, reps in (("exact_order", capi.MODE_EXACT_ORDER, 1), ("zebra", capi.MODE_RED_BLACK, 20)):
                 Ua, Va = U0.clone(), V0.clone()
                 dev.oflow_alr_elin4(Ua, Va, *coef_full, 1, 1.5, mode)
                 torch.cuda.synchronize()
