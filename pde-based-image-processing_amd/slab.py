@@ -47,6 +47,7 @@ class SlabDomain:
         self.hi = min(ncols, self.c1 + halo)      # one past the last
         self.left = rank - 1 if rank > 0 else None
         self.right = rank + 1 if rank < world - 1 else None
+        self._ops_cache = {}  # exchange(): P2P op lists per set of planes
 
     @property
     def col0(self):
@@ -69,24 +70,34 @@ class SlabDomain:
         """Refresh the halo columns of every local 2-D plane in `fields` from the neighbours' owned columns."""
         if self.world == 1:
             return
-        H, ops, staged = self.halo, [], []
+        H, staged = self.halo, []
         # gloo moves host memory only: a rehearsal of the multi-rank path on CUDA tensors over gloo stages
         # the halo columns through the host (never the case with the nccl/RCCL backend)
         via_host = fields[0].is_cuda and dist.get_backend(self.group) == "gloo"
-        own0, own1 = self.c0 - self.lo, self.c1 - self.lo
-        for t in fields:
-            pairs = []
-            if self.left is not None:
-                pairs.append((t[own0:own0 + H], t[own0 - H:own0], self.left))
-            if self.right is not None:
-                pairs.append((t[own1 - H:own1], t[own1:own1 + H], self.right))
-            for src, dst, peer in pairs:
-                if via_host:
-                    hsrc, hdst = src.cpu(), torch.empty(dst.shape, dtype=dst.dtype)
-                    staged.append((dst, hdst))
-                    src, dst = hsrc, hdst
-                ops.append(dist.P2POp(dist.isend, src, peer, self.group))
-                ops.append(dist.P2POp(dist.irecv, dst, peer, self.group))
+        # the op list only depends on which buffers are exchanged: built once per set of planes (a solver
+        # call per step would otherwise spend more host time here than the sweeps take on the GPU)
+        key = tuple(t.data_ptr() for t in fields)
+        ops = None if via_host else self._ops_cache.get(key)
+        if ops is None:
+            ops = []
+            own0, own1 = self.c0 - self.lo, self.c1 - self.lo
+            for t in fields:
+                pairs = []
+                if self.left is not None:
+                    pairs.append((t[own0:own0 + H], t[own0 - H:own0], self.left))
+                if self.right is not None:
+                    pairs.append((t[own1 - H:own1], t[own1:own1 + H], self.right))
+                for src, dst, peer in pairs:
+                    if via_host:
+                        hsrc, hdst = src.cpu(), torch.empty(dst.shape, dtype=dst.dtype)
+                        staged.append((dst, hdst))
+                        src, dst = hsrc, hdst
+                    ops.append(dist.P2POp(dist.isend, src, peer, self.group))
+                    ops.append(dist.P2POp(dist.irecv, dst, peer, self.group))
+            if not via_host:
+                if len(self._ops_cache) > 16:
+                    self._ops_cache.clear()
+                self._ops_cache[key] = ops
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         for dst, hdst in staged:
