@@ -11,7 +11,7 @@ import problems as pb
 
 pytestmark = pytest.mark.gpu
 
-SIZES = [(32, 48), (97, 131), (3, 3), (5, 300), (260, 7), (131, 70)]
+SIZES = [(32, 48), (97, 131), (3, 3), (5, 300), (260, 7), (131, 70), (531, 777), (226, 450)]  # incl. partial tiles / rounds of the zebra kernel
 MODES = [(0, 0), (1, 1)]
 TWO = np.float32(2)
 

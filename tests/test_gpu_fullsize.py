@@ -83,3 +83,21 @@ def test_properties_at_4k(pdeip, mode):
         Xk = api.PDEsolver4(*[np.asfortranarray(v[:, :, k]) for v in q.values()], np.float32(3), np.float32(1.75), np.float32(1))
         assert pb.bit_equal(X[:, :, k], Xk), "frame %d" % k
     pdeip.mex_api.set_mode(0)
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+def test_line_relaxation_at_config_sizes(pdeip, oracle, mode, order):
+    """solver = 2 (the drivers' default) at C2 / C3 / C5 sizes: reference line order and zebra order."""
+    pdeip.mex_api.set_mode(mode)
+    two = np.float32(2)
+    p = pb.llin4(711, 1080, 1920, nan_frac=0.01)
+    _check(pdeip.mex_api.Oflow_sor_llin4_2d(*p.values(), np.float32(2), np.float32(1.5), two),
+           oracle.Oflow_sor_llin4_2d(*p.values(), 2, 1.5, solver=2, order=order), "C2 llin4 ALR")
+    q = pb.pde8(712, 1080, 1920, nan_frac=0.001)   # TVdenoise8's default solver; one iteration whatever iter says
+    _check(pdeip.mex_api.PDEsolver8(*q.values(), np.float32(4), np.float32(1.3), two),
+           oracle.PDEsolver8(*q.values(), 4, 1.3, solver=2, order=order), "C3-shaped pde8 ALR")
+    d = pb.disp4(713, 1988, 2880, nan_frac=0.01)
+    _check(pdeip.mex_api.Disp_sor_llin4_2d(*d.values(), np.float32(1), np.float32(1.5), two),
+           oracle.Disp_sor_llin4_2d(*d.values(), 1, 1.5, solver=2, order=order), "C5 disparity ALR")
+    pdeip.mex_api.set_mode(0)
+
