@@ -233,6 +233,40 @@ def main():
                 torch.cuda.synchronize()
                 alr[name] = round(reps / (time.perf_counter() - t0), 3)
             out["line_relaxation"] = alr
+            # ---- one late-linearisation pyramid level resident in HBM (BASELINE config C2: 1080x1920, 3 channels) --
+            # firstLoop body = warp, derivatives, 4 x [robust assembly, diffusion weights, Oflow_sor_llin4_2d iter=4], median
+            import importlib
+            import importlib.util
+            fl = importlib.import_module("pde-based-image-processing_amd.flow_level")
+            spec = importlib.util.spec_from_file_location("matlab_side", os.path.join(ROOT, "oracle", "matlab_side.py"))
+            ms = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(ms)
+            rng = np.random.default_rng(2)
+            jj, ii = np.meshgrid(np.arange(1920), np.arange(1080))
+            tex = lambda di, dj, c: (np.sin(0.021 * (ii + di) + c) * np.cos(0.017 * (jj + dj) - c) + 0.3 * np.sin(0.11 * (ii + di) + 0.07 * (jj + dj))).astype(np.float32)
+            I0 = np.asfortranarray(np.stack([tex(0, 0, c) for c in range(3)], axis=2))
+            I1 = np.asfortranarray(np.stack([tex(0.7, -0.4, c) for c in range(3)], axis=2))
+            Z = np.zeros((1080, 1920), dtype=np.float32, order="F")
+            lp = dict(firstLoop=1, secondLoop=4, iter=4, omega=1.9, solver=1, alpha=0.4, b1=0.7, b2=0.0, order=0)
+            dI0, dI1, dZ = dev.to_device(I0), dev.to_device(I1), dev.to_device(Z)
+            level = {}
+            for name, mode in (("exact_order", capi.MODE_EXACT_ORDER), ("red_black", capi.MODE_RED_BLACK)):
+                lv = fl.FlowLlinLevel(lp, mode=mode)
+                gU, gV = lv.run(dI0, dI1, dZ, dZ)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    gU, gV = lv.run(dI0, dI1, dZ, dZ)
+                torch.cuda.synchronize()
+                level[name + "_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+                if mode == capi.MODE_EXACT_ORDER:
+                    t0 = time.perf_counter()
+                    wU, wV = ms.flow_level(sys.modules["oracle_lib"], I0, I1, Z, Z, lp)
+                    level["cpu_statement_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+                    level["exact_order_max_abs_vs_cpu"] = float(max(np.abs(dev.to_matlab(gU).astype(np.float64) - wU).max(),
+                                                                    np.abs(dev.to_matlab(gV).astype(np.float64) - wV).max()))
+            level["workload"] = "FlowEminND_llin_2D_v10 firstLoop body, 1080x1920x3, secondLoop=4, iter=4, solver=1"
+            out["flow_level"] = level
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

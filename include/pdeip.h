@@ -264,6 +264,26 @@ int pdeip_snd_derivatives5_dev(void *stream, const float *It0, const float *It1,
                                int nframes, float *Idxt, float *Idyt, float *Idxx, float *Idyy,
                                float *Idxy);
 
+/* ---- MATLAB-side stages of one late-linearisation pyramid level, device-resident ("next row" f2) --------
+ * What matlab/optical_flow/FlowEminND_llin_2D_v10.m runs between its MEX calls inside firstLoop/secondLoop
+ * (:208-356), so that a level can stay in HBM (pde-based-image-processing_amd/flow_level.py drives them).
+ * Restatements of MATLAB array code: single/double typing and expression order as written there;
+ * checked against oracle/matlab_side.py, not against MATLAB ("parity unpinned"). */
+/* X = single((1:cols) + U), Y = single((1:rows)' + V): the warp coordinates (:223) */
+int pdeip_flow_coords_dev(void *stream, const float *U, const float *V, int nrows, int ncols, float *X, float *Y);
+/* robust data-term assembly (:283-327): gD = b./(alpha*sqrt((It - Ix.*dU - Iy.*dV).^2 + 1e-5)) per channel of one or
+ * two data terms ([nrows x ncols x C] derivative arrays; C2 = 0: no second term), then nansum over all channels of
+ * (Iy.*Ix).*gD -> MGd, (It.*Ix).*gD -> CuGd, (It.*Iy).*gD -> CvGd, (Ix.*Ix).*gD -> DuGd, (Iy.*Iy).*gD -> DvGd. */
+int pdeip_flow_assemble_dev(void *stream, const float *It1, const float *Ix1, const float *Iy1, int C1, float b1,
+                            const float *It2, const float *Ix2, const float *Iy2, int C2, float b2, const float *dU,
+                            const float *dV, float alpha, int nrows, int ncols, float *MGd, float *CuGd, float *CvGd,
+                            float *DuGd, float *DvGd);
+/* [wW wN wS wE] = OPdiffWeights(U+dU, V+dV) (:389-433), evaluated in double, returned as single */
+int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, const float *dU, const float *dV, int nrows,
+                                 int ncols, float *wW, float *wN, float *wS, float *wE);
+/* out = medfilt2(A + B, [3 3], 'symmetric') (:352); B may be NULL (out = medfilt2(A)); out must not alias A or B */
+int pdeip_median3_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+"""numpy statement of the MATLAB-side stages of one late-linearisation pyramid level.
+
+TEST INFRASTRUCTURE ONLY (see pdeip_oracle.h): the checker for csrc/pdeip_flow.hpp and flow_level.py.
+PARITY UNPINNED: this restates MATLAB array code of matlab/optical_flow/FlowEminND_llin_2D_v10.m
+(typing: `single op double -> single`, OPdiffWeights casts to double; expressions left to right); it has
+not been compared with MATLAB, which this image does not have.  IPT functions are restated by their
+documented meaning: imfilter(...,'replicate') = correlation with edge replication, circshift wraps,
+medfilt2(...,'symmetric') with a 3x3 window mirrors the edge pixel, nansum skips NaN and returns 0 for an
+all-NaN slice.
+
+Arrays are MATLAB-shaped numpy arrays [nrows, ncols(, C)], float32 unless said otherwise.
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def flow_coords(U, V):
+    """single(X+U), single(Y+V) with [X Y] = meshgrid(1:cols, 1:rows)   (:205, :223)"""
+    nrows, ncols = U.shape
+    X = np.arange(1, ncols + 1, dtype=F32)[None, :] + U.astype(F32)
+    Y = np.arange(1, nrows + 1, dtype=F32)[:, None] + V.astype(F32)
+    return X.astype(F32), Y.astype(F32)
+
+
+def _term(It, Ix, Iy, b, alpha, dU, dV):
+    It, Ix, Iy = [a if a.ndim == 3 else a[:, :, None] for a in (It, Ix, Iy)]
+    du, dv = dU.astype(F32)[:, :, None], dV.astype(F32)[:, :, None]
+    r = (It - Ix * du) - Iy * dv                                  # :283 (single)
+    opnorm = r * r
+    gD = F32(b) / (F32(alpha) * np.sqrt(opnorm + F32(0.00001)))   # :284
+    return [(Iy * Ix) * gD, (It * Ix) * gD, (It * Iy) * gD, (Ix * Ix) * gD, (Iy * Iy) * gD]  # :236-240 times gD (:321-325)
+
+
+def flow_assemble(term1, term2, dU, dV, alpha):
+    """term = (It, Ix, Iy, b) or None.  Returns MGd, CuGd, CvGd, DuGd, DvGd = nansum over all channels (:321-325)."""
+    stacks = _term(*term1[:3], term1[3], alpha, dU, dV)
+    if term2 is not None:
+        second = _term(*term2[:3], term2[3], alpha, dU, dV)
+        stacks = [np.concatenate([a, b], axis=2) for a, b in zip(stacks, second)]
+    outs = []
+    for s in stacks:
+        acc = np.zeros(s.shape[:2], dtype=F32)
+        for c in range(s.shape[2]):                               # sequential, in slice order
+            v = s[:, :, c]
+            acc = np.where(np.isnan(v), acc, (acc + v).astype(F32))
+        outs.append(acc)
+    return outs
+
+
+def _shift(A, di, dj):
+    """circshift(A, [di dj]): element (i,j) takes A(i-di, j-dj), wrapping."""
+    return np.roll(np.roll(A, di, axis=0), dj, axis=1)
+
+
+def _ver(A):  # imfilter(A, [0.25 0 -0.25]', 'replicate'): 0.25*north - 0.25*south
+    P = np.pad(A, ((1, 1), (0, 0)), mode="edge")
+    return 0.25 * P[:-2, :] - 0.25 * P[2:, :]
+
+
+def _hor(A):  # imfilter(A, [0.25 0 -0.25], 'replicate'): 0.25*west - 0.25*east
+    P = np.pad(A, ((0, 0), (1, 1)), mode="edge")
+    return 0.25 * P[:, :-2] - 0.25 * P[:, 2:]
+
+
+def op_diff_weights(U, V, dU, dV):
+    """[wW wN wS wE] = OPdiffWeights(U+dU, V+dV) (:389-433), as the single arrays handed to the solver."""
+    Uf = (U.astype(F32) + dU.astype(F32)).astype(np.float64)
+    Vf = (V.astype(F32) + dV.astype(F32)).astype(np.float64)
+    Uver, Vver, Uhor, Vhor = _ver(Uf), _ver(Vf), _hor(Uf), _hor(Vf)
+
+    def w(di, dj, Uc, Vc):
+        acc = (_shift(Uf, di, dj) - Uf) ** 2
+        acc = acc + (Uc + _shift(Uc, di, dj)) ** 2
+        acc = acc + (_shift(Vf, di, dj) - Vf) ** 2
+        acc = acc + (Vc + _shift(Vc, di, dj)) ** 2
+        return (1.0 / np.sqrt(acc + 0.00001)).astype(F32)
+
+    wW, wE = w(0, 1, Uver, Vver), w(0, -1, Uver, Vver)
+    wN, wS = w(1, 0, Uhor, Vhor), w(-1, 0, Uhor, Vhor)
+    return wW, wN, wS, wE
+
+
+def median3_sum(A, B=None):
+    """medfilt2(A + B, [3 3], 'symmetric') (:352)."""
+    S = A.astype(F32) if B is None else (A.astype(F32) + B.astype(F32)).astype(F32)
+    P = np.pad(S, 1, mode="symmetric")
+    nrows, ncols = S.shape
+    stack = np.stack([P[di:di + nrows, dj:dj + ncols] for dj in range(3) for di in range(3)], axis=0)
+    return np.sort(stack, axis=0)[4].astype(F32)
+
+
+def flow_level(orc, I1t0, I1t1, U, V, param, I2t0=None, I2t1=None):
+    """One pyramid level (:208-356, without the pyramid's imresize): firstLoop x [warp, derivatives,
+    secondLoop x (assembly, diffusion weights, Oflow_sor_llin4_2d)], median.  `orc` = tests/oracle_lib.
+    param: firstLoop, secondLoop, iter, omega, solver, alpha, b1, b2, order (oracle sweep/line order)."""
+    U, V = U.astype(F32), V.astype(F32)
+    for _ in range(param["firstLoop"]):
+        X, Y = flow_coords(U, V)
+        w1 = orc.BilinInterp_2d(I1t1, X, Y)
+        t1 = orc.FstDerivatives5(I1t0, w1) + (param["b1"],)
+        t2 = None
+        if I2t1 is not None:
+            w2 = orc.BilinInterp_2d(I2t1, X, Y)
+            t2 = orc.FstDerivatives5(I2t0, w2) + (param["b2"],)
+        dU, dV = np.zeros_like(U), np.zeros_like(V)
+        for _ in range(param["secondLoop"]):
+            MGd, CuGd, CvGd, DuGd, DvGd = flow_assemble(t1, t2, dU, dV, param["alpha"])
+            wW, wN, wS, wE = op_diff_weights(U, V, dU, dV)
+            dU, dV = orc.Oflow_sor_llin4_2d(U, V, dU, dV, MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wE, wS, param["iter"],
+                                            param["omega"], solver=param["solver"], order=param["order"])
+        U, V = median3_sum(U, dU), median3_sum(V, dV)
+    return U, V

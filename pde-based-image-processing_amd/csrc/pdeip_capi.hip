@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "pdeip_alr.hpp"
+#include "pdeip_flow.hpp"
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
 #include "pdeip_sor_exact.hpp"
@@ -954,6 +955,51 @@ extern "C" int pdeip_snd_derivatives5_dev(void *stream, const float *It0, const 
     RC(check_deriv_dims("pdeip_snd_derivatives5_dev", nrows, ncols, nframes));
     hipLaunchKernelGGL(k_snd_derivatives5, pixel_grid(nrows, ncols, nframes), dim3(256), 0, static_cast<hipStream_t>(stream),
                        Idxt, Idyt, Idxx, Idyy, Idxy, It0, It1, nrows, ncols, (size_t)nrows * ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MATLAB-side stages of one late-linearisation pyramid level (pdeip_flow.hpp), device-resident only
+// ------------------------------------------------------------------------------------------------
+extern "C" int pdeip_flow_coords_dev(void *stream, const float *U, const float *V, int nrows, int ncols, float *X, float *Y)
+{
+    RC(check_dims("pdeip_flow_coords_dev", nrows, ncols, 1));
+    hipLaunchKernelGGL(k_flow_coords, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), X, Y, U, V, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_flow_assemble_dev(void *stream, const float *It1, const float *Ix1, const float *Iy1, int C1, float b1,
+                                       const float *It2, const float *Ix2, const float *Iy2, int C2, float b2, const float *dU,
+                                       const float *dV, float alpha, int nrows, int ncols, float *MGd, float *CuGd, float *CvGd,
+                                       float *DuGd, float *DvGd)
+{
+    const char *who = "pdeip_flow_assemble_dev";
+    RC(check_dims(who, nrows, ncols, C1));
+    if (C2 < 0 || (C2 > 0 && (!It2 || !Ix2 || !Iy2))) return set_err(PDEIP_ERR_ARG, "%s: second data term needs its three derivative arrays", who);
+    const FlowTerm t1{It1, Ix1, Iy1, C1, b1}, t2{It2, Ix2, Iy2, C2, b2};
+    hipLaunchKernelGGL(k_flow_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), MGd, CuGd, CvGd, DuGd,
+                       DvGd, t1, t2, dU, dV, alpha, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, const float *dU, const float *dV, int nrows,
+                                            int ncols, float *wW, float *wN, float *wS, float *wE)
+{
+    RC(check_dims("pdeip_flow_opdiffweights_dev", nrows, ncols, 1));
+    hipLaunchKernelGGL(k_flow_opdiffweights, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), wW, wN, wS, wE, U,
+                       V, dU, dV, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_median3_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out)
+{
+    RC(check_dims("pdeip_median3_dev", nrows, ncols, 1));
+    if (out == A || out == B) return set_err(PDEIP_ERR_ARG, "pdeip_median3_dev: output must not alias an input");
+    hipLaunchKernelGGL(k_median3_sum, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), out, A, B, nrows, ncols);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

@@ -1,0 +1,144 @@
+// pdeip_flow.hpp -- the stages the MATLAB driver runs BETWEEN the MEX calls of one pyramid level of
+// the late-linearisation optical flow (matlab/optical_flow/FlowEminND_llin_2D_v10.m:208-356), as device
+// kernels, so that a whole firstLoop body (warp -> derivatives -> [robust weights, diffusion weights,
+// assembly, solver] x secondLoop -> median) stays in HBM instead of crossing PCIe 13 planes per call.
+//
+// These are restatements of MATLAB array code, not of C: there is no reference build to compare with.
+// What is reproduced is MATLAB's typing (single op double -> single; OPdiffWeights casts to double) and
+// the left-to-right order of each expression; oracle/matlab_side.py is the numpy statement of the same
+// and the tests compare bit for bit against it.  ("parity unpinned" with respect to MATLAB itself.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pdeip_models.hpp"
+#include "pdeip_pointwise.hpp"
+
+namespace pdeip {
+
+// single(X+U), single(Y+V) of the warp (FlowEminND_llin_2D_v10.m:223): X,Y = meshgrid(1:cols,1:rows)
+__global__ void k_flow_coords(float *X, float *Y, const float *U, const float *V, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    X[pos] = (float)(j + 1) + U[pos];
+    Y[pos] = (float)(i + 1) + V[pos];
+}
+
+// One data term of the robust assembly (:283-327): for each channel c
+//   OPnorm = (It - Ix.*dU - Iy.*dV).^2;  gD = b./(alpha*sqrt(OPnorm+0.00001))          (all single)
+//   M = Iy.*Ix; Cu = It.*Ix; Cv = It.*Iy; Du = Ix.*Ix; Dv = Iy.*Iy                     (:236-240)
+// and the five planes accumulate nansum(cat(3, M.*gD, ...), 3): NaN products are skipped, in channel
+// order, first term then second term; a pixel whose products are all NaN gets 0 (nansum's empty sum).
+struct FlowTerm {
+    const float *It, *Ix, *Iy; // [nrows x ncols x C]
+    int C;
+    float b;
+};
+
+__device__ __forceinline__ void nan_add(float &acc, float v)
+{
+    if (!is_nan(v)) acc = acc + v;
+}
+
+__global__ void k_flow_assemble(float *MGd, float *CuGd, float *CvGd, float *DuGd, float *DvGd, FlowTerm t1, FlowTerm t2,
+                                const float *dU, const float *dV, float alpha, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t n = (size_t)nrows * ncols;
+    const float du = dU[pos], dv = dV[pos];
+    float m = 0.0f, cu = 0.0f, cv = 0.0f, Du = 0.0f, Dv = 0.0f;
+#pragma unroll
+    for (int term = 0; term < 2; ++term) {
+        const FlowTerm &t = term == 0 ? t1 : t2;
+        for (int c = 0; c < t.C; ++c) {
+            const size_t p = (size_t)c * n + pos;
+            const float It = t.It[p], Ix = t.Ix[p], Iy = t.Iy[p];
+            float r = It - Ix * du; // (It - Ix.*dU) - Iy.*dV
+            r = r - Iy * dv;
+            const float opnorm = r * r;
+            const float gD = t.b / (alpha * sqrtf(opnorm + 0.00001f));
+            nan_add(m, (Iy * Ix) * gD);
+            nan_add(cu, (It * Ix) * gD);
+            nan_add(cv, (It * Iy) * gD);
+            nan_add(Du, (Ix * Ix) * gD);
+            nan_add(Dv, (Iy * Iy) * gD);
+        }
+    }
+    MGd[pos] = m;
+    CuGd[pos] = cu;
+    CvGd[pos] = cv;
+    DuGd[pos] = Du;
+    DvGd[pos] = Dv;
+}
+
+// OPdiffWeights (:389-433) on (U+dU, V+dV): 6-point discretisation, evaluated in double like the MATLAB
+// function (it casts its inputs), circshift wrap-around at the frame edges included, cast to single on
+// the way into the solver call.  ver = imfilter(.,[0.25 0 -0.25]','replicate') = 0.25*(north) - 0.25*(south),
+// hor likewise with west/east.
+__global__ void k_flow_opdiffweights(float *wW, float *wN, float *wS, float *wE, const float *U, const float *V,
+                                     const float *dU, const float *dV, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    // value of field f (0: U+dU, 1: V+dV) at (ii,jj), double
+    auto F = [&](int f, int ii, int jj) -> double {
+        const size_t p = (size_t)jj * nrows + ii;
+        const float s = (f == 0 ? U[p] : V[p]) + (f == 0 ? dU[p] : dV[p]); // single(U) + single(dU), then double()
+        return (double)s;
+    };
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    auto ver = [&](int f, int ii, int jj) { return 0.25 * F(f, clampi(ii - 1, nrows - 1), jj) - 0.25 * F(f, clampi(ii + 1, nrows - 1), jj); };
+    auto hor = [&](int f, int ii, int jj) { return 0.25 * F(f, ii, clampi(jj - 1, ncols - 1)) - 0.25 * F(f, ii, clampi(jj + 1, ncols - 1)); };
+    const int jw = j == 0 ? ncols - 1 : j - 1, je = j == ncols - 1 ? 0 : j + 1; // circshift wraps
+    const int in_ = i == 0 ? nrows - 1 : i - 1, is = i == nrows - 1 ? 0 : i + 1;
+    double w[4]; // W, E, N, S
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int ii = d == 2 ? in_ : (d == 3 ? is : i), jj = d == 0 ? jw : (d == 1 ? je : j);
+        double acc = 0.0;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) { // (U_d - U)^2 + (Uver + Uver_d)^2 + (V_d - V)^2 + (Vver + Vver_d)^2, left to right
+            const double diff = F(f, ii, jj) - F(f, i, j);
+            const double cross = d < 2 ? ver(f, i, j) + ver(f, ii, jj) : hor(f, i, j) + hor(f, ii, jj);
+            acc = f == 0 ? diff * diff : acc + diff * diff;
+            acc = acc + cross * cross;
+        }
+        w[d] = 1.0 / sqrt(acc + 0.00001);
+    }
+    wW[pos] = (float)w[0];
+    wE[pos] = (float)w[1];
+    wN[pos] = (float)w[2];
+    wS[pos] = (float)w[3];
+}
+
+// medfilt2(A + B, [3 3], 'symmetric') (:352-353): exact selection of the 5th of 9, symmetric padding
+// (the edge pixel is mirrored, i.e. index -1 -> 0 and n -> n-1).
+__device__ __forceinline__ void cswap(float &a, float &b)
+{
+    const float lo = fminf(a, b), hi = fmaxf(a, b);
+    a = lo;
+    b = hi;
+}
+
+__global__ void k_median3_sum(float *out, const float *A, const float *B, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    float v[9];
+#pragma unroll
+    for (int dj = -1; dj <= 1; ++dj)
+#pragma unroll
+        for (int di = -1; di <= 1; ++di) {
+            const int ii = min(max(i + di, 0), nrows - 1), jj = min(max(j + dj, 0), ncols - 1);
+            const size_t p = (size_t)jj * nrows + ii;
+            v[(dj + 1) * 3 + di + 1] = B ? A[p] + B[p] : A[p];
+        }
+    // 19-exchange median-of-9 network
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+    cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+    cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
+    cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
+    cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
+    cswap(v[4], v[2]);
+    out[pos] = v[4];
+}
+
+} // namespace pdeip

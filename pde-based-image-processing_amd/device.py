@@ -171,3 +171,39 @@ def snd_derivatives5(It0, It1, Idxt, Idyt, Idxx, Idyy, Idxy):
     _chk(It0, It1, Idxt, Idyt, Idxx, Idyy, Idxy)
     nrows, ncols, F = _dims(It0)
     capi.call("pdeip_snd_derivatives5_dev", _stream(), *_p(It0, It1), nrows, ncols, F, *_p(Idxt, Idyt, Idxx, Idyy, Idxy))
+
+
+# ---- MATLAB-side stages of a late-linearisation pyramid level (csrc/pdeip_flow.hpp) ----------------------
+
+def flow_coords(U, V, X, Y):
+    _chk(U, V, X, Y)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_flow_coords_dev", _stream(), *_p(U, V), nrows, ncols, *_p(X, Y))
+
+
+def flow_assemble(term1, term2, dU, dV, alpha, MGd, CuGd, CvGd, DuGd, DvGd):
+    """term = (It, Ix, Iy, b) with [C, ncols, nrows] derivative arrays; term2 may be None."""
+    It1, Ix1, Iy1, b1 = term1
+    _chk(It1, Ix1, Iy1, dU, dV, MGd, CuGd, CvGd, DuGd, DvGd)
+    nrows, ncols, C1 = _dims(It1)
+    if term2 is None:
+        p2, C2, b2 = [None, None, None], 0, 0.0
+    else:
+        It2, Ix2, Iy2, b2 = term2
+        _chk(It2, Ix2, Iy2)
+        p2, C2 = _p(It2, Ix2, Iy2), _dims(It2)[2]
+    capi.call("pdeip_flow_assemble_dev", _stream(), *_p(It1, Ix1, Iy1), C1, float(b1), *p2, C2, float(b2), *_p(dU, dV),
+              float(alpha), nrows, ncols, *_p(MGd, CuGd, CvGd, DuGd, DvGd))
+
+
+def flow_opdiffweights(U, V, dU, dV, wW, wN, wS, wE):
+    _chk(U, V, dU, dV, wW, wN, wS, wE)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_flow_opdiffweights_dev", _stream(), *_p(U, V, dU, dV), nrows, ncols, *_p(wW, wN, wS, wE))
+
+
+def median3(A, B, out):
+    """out = medfilt2(A + B, [3 3], 'symmetric'); B may be None."""
+    _chk(A, out) if B is None else _chk(A, B, out)
+    nrows, ncols, _ = _dims(A)
+    capi.call("pdeip_median3_dev", _stream(), A.data_ptr(), None if B is None else B.data_ptr(), nrows, ncols, out.data_ptr())

@@ -1,0 +1,55 @@
+"""One pyramid level of the late-linearisation optical flow, resident in HBM.
+
+Mirror of the body of the coarse-to-fine loop of matlab/optical_flow/FlowEminND_llin_2D_v10.m:208-356
+(firstLoop x [warp, derivatives, secondLoop x (robust assembly, diffusion weights, Oflow_sor_llin4_2d)],
+median) on device planes: every stage is a kernel of libpdeip.so, nothing crosses PCIe between them and
+no host synchronisation happens inside a level.  The pyramid itself (imresize, Gaussian pre-smoothing)
+is not here: IPT's imresize has no reference to check against in this image.
+
+Planes are torch float32 CUDA tensors laid out [ncols, nrows] / [C, ncols, nrows] (device.to_device).
+"""
+import torch
+
+from . import capi, device as dev
+
+
+class FlowLlinLevel:
+    """param: firstLoop, secondLoop, iter, omega, solver (1 point SOR, 2 line relaxation), alpha, b1, b2."""
+
+    def __init__(self, param, mode=capi.MODE_EXACT_ORDER):
+        self.p, self.mode = dict(param), mode
+
+    def _solve(self, U, V, dU, dV, coef):
+        fn = dev.oflow_sor_llin4 if int(self.p["solver"]) == 1 else dev.oflow_alr_llin4
+        fn(U, V, dU, dV, *coef, int(self.p["iter"]), float(self.p["omega"]), self.mode)
+
+    def run(self, I1t0, I1t1, U, V, I2t0=None, I2t1=None):
+        """I*: [C, ncols, nrows] images of the two frames (first / optional second constancy term);
+        U, V: [ncols, nrows] flow entering the level.  Returns the flow leaving it (new tensors)."""
+        p = self.p
+        new = lambda like: torch.empty_like(like)
+        X, Y = new(U), new(U)
+        w1, d1 = new(I1t1), [new(I1t1) for _ in range(3)]
+        w2, d2 = (new(I2t1), [new(I2t1) for _ in range(3)]) if I2t1 is not None else (None, None)
+        coef = [new(U) for _ in range(9)]  # MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wE, wS
+        U, V = U.clone(), V.clone()
+        Un, Vn = new(U), new(U)
+        for _ in range(int(p["firstLoop"])):
+            dev.flow_coords(U, V, X, Y)
+            dev.warp_bilinear(I1t1, X, Y, w1)
+            dev.fst_derivatives5(I1t0, w1, *d1)                      # Idt, Idx, Idy
+            t1, t2 = (d1[0], d1[1], d1[2], p["b1"]), None
+            if I2t1 is not None:
+                dev.warp_bilinear(I2t1, X, Y, w2)
+                dev.fst_derivatives5(I2t0, w2, *d2)
+                t2 = (d2[0], d2[1], d2[2], p["b2"])
+            dU, dV = torch.zeros_like(U), torch.zeros_like(V)
+            for _ in range(int(p["secondLoop"])):
+                dev.flow_assemble(t1, t2, dU, dV, p["alpha"], *coef[:5])
+                dev.flow_opdiffweights(U, V, dU, dV, coef[5], coef[6], coef[8], coef[7])   # returns wW wN wS wE
+                self._solve(U, V, dU, dV, coef)
+            dev.median3(U, dU, Un)
+            dev.median3(V, dV, Vn)
+            U, Un = Un, U
+            V, Vn = Vn, V
+        return U, V

@@ -1,0 +1,61 @@
+"""CPU: known answers for oracle/matlab_side.py (the numpy statement of the MATLAB-side stages)."""
+import importlib.util
+import os
+
+import numpy as np
+import scipy.ndimage as ndi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("matlab_side", os.path.join(ROOT, "oracle", "matlab_side.py"))
+ms = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(ms)
+
+
+def test_median_is_scipy_median_with_mirrored_edges():
+    rng = np.random.default_rng(1)
+    A, B = rng.uniform(-1, 1, (23, 17)).astype(np.float32), rng.uniform(-1, 1, (23, 17)).astype(np.float32)
+    assert np.array_equal(ms.median3_sum(A, B), ndi.median_filter(A + B, size=3, mode="reflect"))
+    assert np.array_equal(ms.median3_sum(A), ndi.median_filter(A, size=3, mode="nearest"))  # pad 1: mirror == replicate
+
+
+def test_diffusion_weights_closed_form_on_a_ramp():
+    """U = a*col + b*row, V = 0: interior weights are 1/sqrt(step^2 + (2*0.5*cross)^2 + 1e-5)."""
+    nrows, ncols, a, b = 12, 14, 0.5, -0.25
+    jj, ii = np.meshgrid(np.arange(ncols), np.arange(nrows))
+    U = (a * jj + b * ii).astype(np.float32)
+    Z = np.zeros_like(U)
+    wW, wN, wS, wE = ms.op_diff_weights(U, Z, Z, Z)
+    # ver = 0.25*(north - south) = -0.5*b; hor = 0.25*(west - east) = -0.5*a
+    want_we = 1.0 / np.sqrt(a * a + (2 * -0.5 * b) ** 2 + 1e-5)
+    want_ns = 1.0 / np.sqrt(b * b + (2 * -0.5 * a) ** 2 + 1e-5)
+    inner = (slice(2, -2), slice(2, -2))
+    assert np.allclose(wW[inner], want_we, rtol=1e-6) and np.allclose(wE[inner], want_we, rtol=1e-6)
+    assert np.allclose(wN[inner], want_ns, rtol=1e-6) and np.allclose(wS[inner], want_ns, rtol=1e-6)
+    # circshift wraps: the first column's west neighbour is the last column
+    assert not np.isclose(wW[5, 0], want_we, rtol=1e-3)
+    assert wW.dtype == np.float32
+
+
+def test_assembly_is_nansum_over_channels():
+    rng = np.random.default_rng(2)
+    shp = (9, 8, 3)
+    It, Ix, Iy = [rng.uniform(-1, 1, shp).astype(np.float32) for _ in range(3)]
+    dU, dV = rng.uniform(-.5, .5, shp[:2]).astype(np.float32), rng.uniform(-.5, .5, shp[:2]).astype(np.float32)
+    It[2, 3, :] = np.nan          # every channel NaN -> 0, like nansum
+    It[4, 4, 1] = np.nan          # one channel NaN -> skipped
+    M, Cu, Cv, Du, Dv = ms.flow_assemble((It, Ix, Iy, 0.8), None, dU, dV, 0.5)
+    assert M[2, 3] == 0 and Du[2, 3] == 0 and np.isfinite(M).all()
+    r = It.astype(np.float64) - Ix * dU[:, :, None] - Iy * dV[:, :, None]
+    gD = 0.8 / (0.5 * np.sqrt(r * r + 1e-5))
+    assert np.allclose(Du, np.nansum(Ix.astype(np.float64) ** 2 * gD, axis=2), rtol=1e-5, atol=1e-6)
+    assert np.allclose(Cu, np.nansum(It.astype(np.float64) * Ix * gD, axis=2), rtol=1e-4, atol=1e-5)
+    # a second term adds its channels
+    M2 = ms.flow_assemble((It, Ix, Iy, 0.8), (It[:, :, :1], Ix[:, :, :1], Iy[:, :, :1], 0.8), dU, dV, 0.5)[0]
+    one = ms.flow_assemble((It[:, :, :1], Ix[:, :, :1], Iy[:, :, :1], 0.8), None, dU, dV, 0.5)[0]
+    assert np.allclose(M2, M + one, rtol=1e-5, atol=1e-6)
+
+
+def test_coords_are_one_based():
+    U = np.zeros((3, 4), dtype=np.float32)
+    X, Y = ms.flow_coords(U, U)
+    assert X[0, 0] == 1 and X[0, 3] == 4 and Y[2, 0] == 3 and X.dtype == np.float32
