@@ -278,6 +278,13 @@ int pdeip_flow_assemble_dev(void *stream, const float *It1, const float *Ix1, co
                             const float *It2, const float *Ix2, const float *Iy2, int C2, float b2, const float *dU,
                             const float *dV, float alpha, int nrows, int ncols, float *MGd, float *CuGd, float *CvGd,
                             float *DuGd, float *DvGd);
+/* disparity twin (matlab/disparity/DispEminND_llin_2D.m:258-293): CuGd = sum_c (It.*Ix).*gD, DuGd = sum_c (Ix.*Ix).*gD with
+ * gD = b./(alpha.*realsqrt((It - Ix.*dU).^2 + 1e-5)); plain sum: NaN propagates to the solver's isnan(Cu) test */
+int pdeip_disp_assemble_dev(void *stream, const float *It1, const float *Ix1, int C1, float b1, const float *It2,
+                            const float *Ix2, int C2, float b2, const float *dU, float alpha, int nrows, int ncols,
+                            float *CuGd, float *DuGd);
+/* out = A + B (single); e.g. the argument of DdiffWeights(single(U+dU), eps) (:283) */
+int pdeip_add_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out);
 /* [wW wN wS wE] = OPdiffWeights(U+dU, V+dV) (:389-433), evaluated in double, returned as single */
 int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, const float *dU, const float *dV, int nrows,
                                  int ncols, float *wW, float *wN, float *wS, float *wE);

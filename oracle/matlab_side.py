@@ -111,3 +111,46 @@ def flow_level(orc, I1t0, I1t1, U, V, param, I2t0=None, I2t1=None):
                                             param["omega"], solver=param["solver"], order=param["order"])
         U, V = median3_sum(U, dU), median3_sum(V, dV)
     return U, V
+
+
+def disp_assemble(term1, term2, dU, alpha):
+    """CuGd, DuGd of matlab/disparity/DispEminND_llin_2D.m:258-293; term = (It, Ix, b); plain sum over channels."""
+    def one(It, Ix, b):
+        It, Ix = [a if a.ndim == 3 else a[:, :, None] for a in (It, Ix)]
+        r = It - Ix * dU.astype(F32)[:, :, None]
+        gD = F32(b) / (F32(alpha) * np.sqrt(r * r + F32(0.00001)))
+        return (It * Ix) * gD, (Ix * Ix) * gD
+    cu, du = one(*term1)
+    if term2 is not None:
+        c2, d2 = one(*term2)
+        cu, du = np.concatenate([cu, c2], axis=2), np.concatenate([du, d2], axis=2)
+    outs = []
+    for s in (cu, du):
+        acc = s[:, :, 0].astype(F32)
+        for c in range(1, s.shape[2]):
+            acc = (acc + s[:, :, c]).astype(F32)
+        outs.append(acc)
+    return outs
+
+
+def disp_level(orc, I1t0, I1t1, U, param, I2t0=None, I2t1=None):
+    """One pyramid level of DispEminND_llin_2D.m (:202-316, without the pyramid's imresize)."""
+    U = U.astype(F32)
+    Z = np.zeros_like(U)
+    for _ in range(param["firstLoop"]):
+        X, Y = flow_coords(U, Z)
+        w1 = orc.BilinInterp_2d(I1t1, X, Y)
+        d = orc.FstDerivatives5(I1t0, w1)
+        t1, t2 = (d[0], d[1], param["b1"]), None
+        if I2t1 is not None:
+            w2 = orc.BilinInterp_2d(I2t1, X, Y)
+            d2 = orc.FstDerivatives5(I2t0, w2)
+            t2 = (d2[0], d2[1], param["b2"])
+        dU = np.zeros_like(U)
+        for _ in range(param["secondLoop"]):
+            CuGd, DuGd = disp_assemble(t1, t2, dU, param["alpha"])
+            wW, wN, wE, wS = orc.DdiffWeights((U + dU).astype(F32), 0.00001)
+            dU = orc.Disp_sor_llin4_2d(U, dU, CuGd, DuGd, wW, wN, wE, wS, param["iter"], param["omega"], solver=param["solver"],
+                                       order=param["order"])
+        U = median3_sum(U, dU)
+    return U

@@ -64,6 +64,8 @@ SIGNATURES = {
     "pdeip_pde_alr8_dev": _sig(1 + 11, [_I, _I, _I, _I, _F, _I]),
     "pdeip_flow_coords_dev": [_P, _P, _P, _I, _I, _P, _P],
     "pdeip_flow_assemble_dev": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _I, _F, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
+    "pdeip_disp_assemble_dev": [_P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _F, _I, _I, _P, _P],
+    "pdeip_add_dev": [_P, _P, _P, _I, _I, _P],
     "pdeip_flow_opdiffweights_dev": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "pdeip_median3_dev": [_P, _P, _P, _I, _I, _P],
     "pdeip_oflow_res_elin4_dev": _sig(1 + 13, [_I, _I, _I]),

@@ -985,6 +985,28 @@ extern "C" int pdeip_flow_assemble_dev(void *stream, const float *It1, const flo
     return PDEIP_OK;
 }
 
+extern "C" int pdeip_disp_assemble_dev(void *stream, const float *It1, const float *Ix1, int C1, float b1, const float *It2,
+                                       const float *Ix2, int C2, float b2, const float *dU, float alpha, int nrows, int ncols,
+                                       float *CuGd, float *DuGd)
+{
+    const char *who = "pdeip_disp_assemble_dev";
+    RC(check_dims(who, nrows, ncols, C1));
+    if (C2 < 0 || (C2 > 0 && (!It2 || !Ix2))) return set_err(PDEIP_ERR_ARG, "%s: second data term needs its derivative arrays", who);
+    const FlowTerm t1{It1, Ix1, nullptr, C1, b1}, t2{It2, Ix2, nullptr, C2, b2};
+    hipLaunchKernelGGL(k_disp_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), CuGd, DuGd, t1, t2, dU,
+                       alpha, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_add_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out)
+{
+    RC(check_dims("pdeip_add_dev", nrows, ncols, 1));
+    hipLaunchKernelGGL(k_add2, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), out, A, B, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, const float *dU, const float *dV, int nrows,
                                             int ncols, float *wW, float *wN, float *wS, float *wE)
 {

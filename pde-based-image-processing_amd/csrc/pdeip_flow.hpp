@@ -70,6 +70,41 @@ __global__ void k_flow_assemble(float *MGd, float *CuGd, float *CvGd, float *DuG
     DvGd[pos] = Dv;
 }
 
+// Disparity twin of the assembly (matlab/disparity/DispEminND_llin_2D.m:258-293): one unknown, and a plain
+// sum() over the channels -- a NaN (out-of-range warp) propagates into CuGd/DuGd, where the solver's
+// isnan(Cu) test picks it up (disparitySolvers.c:66).
+__global__ void k_disp_assemble(float *CuGd, float *DuGd, FlowTerm t1, FlowTerm t2, const float *dU, float alpha, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t n = (size_t)nrows * ncols;
+    const float du = dU[pos];
+    float cu = 0.0f, Du = 0.0f;
+    bool first = true;
+#pragma unroll
+    for (int term = 0; term < 2; ++term) {
+        const FlowTerm &t = term == 0 ? t1 : t2;
+        for (int c = 0; c < t.C; ++c) {
+            const size_t p = (size_t)c * n + pos;
+            const float It = t.It[p], Ix = t.Ix[p];
+            const float r = It - Ix * du;
+            const float gD = t.b / (alpha * sqrtf(r * r + 0.00001f));
+            const float a = (It * Ix) * gD, b = (Ix * Ix) * gD;
+            cu = first ? a : cu + a; // sum(cat(3, ...), 3): slices added in order
+            Du = first ? b : Du + b;
+            first = false;
+        }
+    }
+    CuGd[pos] = cu;
+    DuGd[pos] = Du;
+}
+
+// out = A + B (single): DdiffWeights(single(U+dU), ...) takes the sum as its input (:283)
+__global__ void k_add2(float *out, const float *A, const float *B, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    out[pos] = A[pos] + B[pos];
+}
+
 // OPdiffWeights (:389-433) on (U+dU, V+dV): 6-point discretisation, evaluated in double like the MATLAB
 // function (it casts its inputs), circshift wrap-around at the frame edges included, cast to single on
 // the way into the solver call.  ver = imfilter(.,[0.25 0 -0.25]','replicate') = 0.25*(north) - 0.25*(south),

@@ -207,3 +207,24 @@ def median3(A, B, out):
     _chk(A, out) if B is None else _chk(A, B, out)
     nrows, ncols, _ = _dims(A)
     capi.call("pdeip_median3_dev", _stream(), A.data_ptr(), None if B is None else B.data_ptr(), nrows, ncols, out.data_ptr())
+
+
+def disp_assemble(term1, term2, dU, alpha, CuGd, DuGd):
+    """term = (It, Ix, b); term2 may be None (DispEminND_llin_2D.m:258-293)."""
+    It1, Ix1, b1 = term1
+    _chk(It1, Ix1, dU, CuGd, DuGd)
+    nrows, ncols, C1 = _dims(It1)
+    if term2 is None:
+        p2, C2, b2 = [None, None], 0, 0.0
+    else:
+        It2, Ix2, b2 = term2
+        _chk(It2, Ix2)
+        p2, C2 = _p(It2, Ix2), _dims(It2)[2]
+    capi.call("pdeip_disp_assemble_dev", _stream(), *_p(It1, Ix1), C1, float(b1), *p2, C2, float(b2), dU.data_ptr(), float(alpha),
+              nrows, ncols, *_p(CuGd, DuGd))
+
+
+def add(A, B, out):
+    _chk(A, B, out)
+    nrows, ncols, _ = _dims(A)
+    capi.call("pdeip_add_dev", _stream(), *_p(A, B), nrows, ncols, out.data_ptr())

@@ -1,4 +1,4 @@
-"""One pyramid level of the late-linearisation optical flow, resident in HBM.
+"""One pyramid level of the late-linearisation optical flow / stereo disparity, resident in HBM.
 
 Mirror of the body of the coarse-to-fine loop of matlab/optical_flow/FlowEminND_llin_2D_v10.m:208-356
 (firstLoop x [warp, derivatives, secondLoop x (robust assembly, diffusion weights, Oflow_sor_llin4_2d)],
@@ -53,3 +53,41 @@ class FlowLlinLevel:
             U, Un = Un, U
             V, Vn = Vn, V
         return U, V
+
+
+class DispLlinLevel:
+    """The same for stereo disparity: body of the coarse-to-fine loop of matlab/disparity/DispEminND_llin_2D.m:202-316
+    (warp along x only, one unknown, DdiffWeights, Disp_sor_llin4_2d).
+    param: firstLoop, secondLoop, iter, omega, solver, alpha, b1, b2."""
+
+    def __init__(self, param, mode=capi.MODE_EXACT_ORDER):
+        self.p, self.mode = dict(param), mode
+
+    def run(self, I1t0, I1t1, U, I2t0=None, I2t1=None):
+        p = self.p
+        new = lambda like: torch.empty_like(like)
+        X, Y, zero = new(U), new(U), torch.zeros_like(U)
+        w1, d1 = new(I1t1), [new(I1t1) for _ in range(3)]
+        w2, d2 = (new(I2t1), [new(I2t1) for _ in range(3)]) if I2t1 is not None else (None, None)
+        CuGd, DuGd, S = new(U), new(U), new(U)
+        wts = [new(U) for _ in range(4)]  # wW, wN, wE, wS
+        U, Un = U.clone(), new(U)
+        solve = dev.disp_sor_llin4 if int(p["solver"]) == 1 else dev.disp_alr_llin4
+        for _ in range(int(p["firstLoop"])):
+            dev.flow_coords(U, zero, X, Y)                           # single(X+U), single(Y)
+            dev.warp_bilinear(I1t1, X, Y, w1)
+            dev.fst_derivatives5(I1t0, w1, *d1)
+            t1, t2 = (d1[0], d1[1], p["b1"]), None
+            if I2t1 is not None:
+                dev.warp_bilinear(I2t1, X, Y, w2)
+                dev.fst_derivatives5(I2t0, w2, *d2)
+                t2 = (d2[0], d2[1], p["b2"])
+            dU = torch.zeros_like(U)
+            for _ in range(int(p["secondLoop"])):
+                dev.disp_assemble(t1, t2, dU, p["alpha"], CuGd, DuGd)
+                dev.add(U, dU, S)
+                dev.diffweights6(S, 0.00001, *wts)
+                solve(U, dU, CuGd, DuGd, *wts, int(p["iter"]), float(p["omega"]), self.mode)
+            dev.median3(U, dU, Un)
+            U, Un = Un, U
+        return U

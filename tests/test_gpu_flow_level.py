@@ -104,3 +104,20 @@ def test_resident_level_equals_the_stage_by_stage_statement(pdeip, oracle, solve
                                                                      dev.to_device(I0[:, :, :2]), dev.to_device(I1[:, :, :2]))
     same(dev.to_matlab(gU), wantU, "two-term level U")
     same(dev.to_matlab(gV), wantV, "two-term level V")
+
+
+@pytest.mark.parametrize("solver,mode,order", [(1, 0, 0), (1, 1, 1), (2, 0, 0), (2, 1, 1)])
+def test_resident_disparity_level(pdeip, oracle, solver, mode, order):
+    """DispEminND_llin_2D's level on the device == its stage-by-stage statement, bit for bit (incl. NaN from the warp)."""
+    ms, dev = matlab_side(), sub("device")
+    nrows, ncols, C = 44, 72, 3
+    I0, I1 = frames(9, nrows, ncols, C)
+    param = dict(firstLoop=2, secondLoop=2, iter=3, omega=1.5, solver=solver, alpha=0.4, b1=0.7, b2=0.3, order=order)
+    U0 = np.full((nrows, ncols), 1.5, dtype=np.float32, order="F")   # warps leave the frame on the east side -> NaN data terms
+    want = ms.disp_level(oracle, I0, I1, U0, param)
+    got = sub("flow_level").DispLlinLevel(param, mode=mode).run(dev.to_device(I0), dev.to_device(I1), dev.to_device(U0))
+    same(dev.to_matlab(got), want, "disparity level (solver %d mode %d)" % (solver, mode))
+    want = ms.disp_level(oracle, I0, I1, U0, dict(param, firstLoop=1), I2t0=I0[:, :, :1].copy(order="F"), I2t1=I1[:, :, :1].copy(order="F"))
+    got = sub("flow_level").DispLlinLevel(dict(param, firstLoop=1), mode=mode).run(
+        dev.to_device(I0), dev.to_device(I1), dev.to_device(U0), dev.to_device(I0[:, :, :1]), dev.to_device(I1[:, :, :1]))
+    same(dev.to_matlab(got), want, "two-term disparity level")
