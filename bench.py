@@ -151,7 +151,10 @@ def main():
     # per launch: this rank's pixels (owned + halo columns are all relaxed by the launch; count owned only)
     own_px = (dom.c1 - dom.c0) * NROWS
     launch_s = ms * 1e-3 / max(nl, 1)
-    achieved = BYTES_PER_PIXEL_SWEEP * own_px / launch_s / 1e9
+    # the library fuses two sweeps into one launch where it can: algorithmic bytes per launch follow
+    sweeps_per_launch = args.steps * ITER / max(nl, 1)
+    bytes_per_launch = BYTES_PER_PIXEL_SWEEP * own_px * sweeps_per_launch
+    achieved = bytes_per_launch / launch_s / 1e9
 
     out = {
         "metric": "SOR iterations/sec (3840x2160 flow)", "value": round(value, 2), "unit": "iterations/s",
@@ -160,14 +163,17 @@ def main():
         "config": {"workload": "Oflow_sor_elin4_2d point SOR, 2160x3840 f32 frame, iter=4/call, omega=1.9, resident in HBM",
                    "ordering": "red_black", "decomposition": "column slabs, %d-column halo, 1 RCCL exchange/step" % (2 * ITER)
                    if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": "k_sor_rb<ModelElin4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_sor_rb<ModelElin4, TWO=%s>" % ("true" if sweeps_per_launch > 1.5 else "false"),
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "launch_us": round(launch_s * 1e6, 2), "algorithmic_bytes_per_launch": BYTES_PER_PIXEL_SWEEP * own_px},
+                     "launch_us": round(launch_s * 1e6, 2), "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "sweeps_per_launch": round(sweeps_per_launch, 3)},
     }
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if world == 1 and os.path.exists(tr):
         try:
-            out["roofline"]["traffic"] = json.load(open(tr)).get("k_sor_rb_elin4_2160x3840_bytes_per_launch")
+            key = "k_sor_rb2_elin4_2160x3840_bytes_per_launch" if sweeps_per_launch > 1.5 else "k_sor_rb_elin4_2160x3840_bytes_per_launch"
+            out["roofline"]["traffic"] = json.load(open(tr)).get(key)
         except (ValueError, OSError):
             pass
 

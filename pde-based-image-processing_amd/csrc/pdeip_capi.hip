@@ -273,27 +273,40 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     const int nunits = ntiles_r * nstrips;
     const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);
     const dim3 block(64 * RB_WAVES_PER_BLOCK);
+    // Two sweeps per launch where the model allows it (pdeip_sor_rb.hpp, rb_march2): same results, about
+    // two thirds of the traffic per sweep.  PDEIP_RB_FUSE=0 keeps one sweep per launch.
+    static const bool fuse_enabled = env_int("PDEIP_RB_FUSE", 1) != 0;
+    const bool fuse = fuse_enabled && Mdl::NRO == 0;
     SweepTimer timer(s);
-    for (int it = 0; it < iter; it++) {
+    int nlaunch = 0, flips = 0; // flips: how many times the iterate changed buffers
+    for (int it = 0; it < iter;) {
+        const bool two = fuse && it + 2 <= iter;
         for (int f = 0; f < NIT; f++) {
-            P.it_in[f] = (it & 1) ? bufB[f] : bufA[f];
-            P.it_out[f] = (it & 1) ? bufA[f] : bufB[f];
+            P.it_in[f] = (flips & 1) ? bufB[f] : bufA[f];
+            P.it_out[f] = (flips & 1) ? bufA[f] : bufB[f];
         }
-        if (it == 0) { // sweep 0 also builds the divisor planes
-            if (vec)
-                hipLaunchKernelGGL((k_sor_rb<Mdl, true, true>), grid, block, 0, s, P, aux0, aux1, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
-            else
-                hipLaunchKernelGGL((k_sor_rb<Mdl, false, true>), grid, block, 0, s, P, aux0, aux1, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+        const bool first = it == 0; // sweep 0 also builds the divisor planes
+        float *d0 = first ? aux0 : nullptr, *d1 = first ? aux1 : nullptr;
+#define PDEIP_RB_LAUNCH(V, F, T) hipLaunchKernelGGL((k_sor_rb<Mdl, V, F, T>), grid, block, 0, s, P, d0, d1, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n)
+        if (two) {
+            if (vec) { if (first) PDEIP_RB_LAUNCH(true, true, true); else PDEIP_RB_LAUNCH(true, false, true); }
+            else     { if (first) PDEIP_RB_LAUNCH(false, true, true); else PDEIP_RB_LAUNCH(false, false, true); }
+        } else {
+            if (vec) { if (first) PDEIP_RB_LAUNCH(true, true, false); else PDEIP_RB_LAUNCH(true, false, false); }
+            else     { if (first) PDEIP_RB_LAUNCH(false, true, false); else PDEIP_RB_LAUNCH(false, false, false); }
+        }
+#undef PDEIP_RB_LAUNCH
+        if (first) {
             P.cf[Mdl::D0] = aux0;
             P.cf[Mdl::D1] = aux1;
-        } else if (vec)
-            hipLaunchKernelGGL((k_sor_rb<Mdl, true, false>), grid, block, 0, s, P, nullptr, nullptr, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
-        else
-            hipLaunchKernelGGL((k_sor_rb<Mdl, false, false>), grid, block, 0, s, P, nullptr, nullptr, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+        }
+        it += two ? 2 : 1;
+        flips++;
+        nlaunch++;
         g.last_launches++;
     }
-    timer.stop(iter);
-    if (iter & 1) // the last sweep wrote the scratch copy
+    timer.stop(nlaunch);
+    if (flips & 1) // the last launch wrote the scratch copy
         for (int f = 0; f < NIT; f++)
             HIPCHK(hipMemcpyAsync(bufA[f], bufB[f], n * nframes * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());

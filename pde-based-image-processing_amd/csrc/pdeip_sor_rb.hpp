@@ -295,12 +295,219 @@ __device__ __forceinline__ void rb_march(const SweepPlanes<Mdl> &P, float *dout0
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two sweeps per launch (models without read-only neighbour fields).
+//
+// One sweep moves every plane through HBM once; the arithmetic of a sweep keeps the VALUs less than half
+// busy.  Two consecutive sweeps share all nine coefficient planes and the iterate never has to leave the
+// registers between them, so fusing them nearly halves the traffic per sweep.  The march keeps four
+// stages in flight, all on the same element set {p, p+2} of their column:
+//     red 1 on column c, black 1 on c-D, red 2 on c-2D, black 2 on c-3D (then stored)
+// with windows O (old), A (after red 1), B (after sweep 1), C (after red 2).  A unit therefore loads
+// four halo columns per side instead of two and its halo lanes (4 rows above and below) are used up
+// exactly: each half-sweep invalidates one more halo row.  Between the sweeps the reference replicates
+// the border (rows, then columns; opticalflowSolvers.c:161-179): the rows are replicated in the B column as
+// soon as black 1 has produced it, and "column 0 = column 1 after sweep 1" is substituted where sweep 2
+// reads it (the west operand of column 1 is B(1); same on the east side).  Results are bit-identical to
+// two launches of k_sor_rb.
+// ------------------------------------------------------------------------------------------------
+template <class Mdl, bool VEC>
+__device__ __forceinline__ void rb_replicate_rows(float (&F)[Mdl::NIT][4], int r, int nrows)
+{
+#pragma unroll
+    for (int f = 0; f < Mdl::NIT; f++) {
+        const float prev3 = VEC ? 0.0f : __shfl_up(F[f][3], 1);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = r + e;
+            if (i == 0) F[f][e] = F[f][e == 3 ? 3 : e + 1];
+            if (i == nrows - 1) F[f][e] = (e == 0) ? prev3 : F[f][e == 0 ? 0 : e - 1];
+        }
+    }
+}
+
+template <class Mdl, bool VEC, bool FIRST, int DIR>
+__device__ __forceinline__ void rb_march2(const SweepPlanes<Mdl> &P, float *dout0, float *dout1, const RbGeom &gm)
+{
+    static_assert(Mdl::NRO == 0, "the fused march keeps no window of read-only neighbour fields");
+    constexpr int NIT = Mdl::NIT, NCF = Mdl::NCF;
+    const int r = gm.r, j0 = gm.j0, j1 = gm.j1, nrows = gm.nrows, ncols = gm.ncols;
+    const float omega = gm.omega, om1 = 1.0f - gm.omega;
+    const float none[1][4] = {{0.0f, 0.0f, 0.0f, 0.0f}};
+
+    // windows, relative to the column c of stage "red 1" (D = DIR); the newest entry of A, B, C is produced
+    // in the step.  (A five-fold unrolled march over register rings removes the window moves below but
+    // quintuples the code: it ran 30 % slower -- instruction fetch, not VALU, was the limit.)
+    float Om[NIT][4], Oc[NIT][4], Op[NIT][4];   // old iterate at c-D, c, c+D
+    float A2[NIT][4], A1[NIT][4];                // after red 1 at c-2D, c-D
+    float B3[NIT][4], B2[NIT][4];                // after sweep 1 at c-3D, c-2D
+    float C4[NIT][4], C3[NIT][4];                // after red 2 at c-4D, c-3D
+    float K0[NCF][4], K1[NCF][4], K2[NCF][4], K3[NCF][4]; // coefficients at c, c-D, c-2D, c-3D
+
+    int c = (DIR > 0) ? j0 - 3 : j1 + 2;
+    const int nsteps = j1 - j0 + 6;
+#pragma unroll
+    for (int f = 0; f < NIT; f++) {
+        rb_load4<VEC>(Om[f], P.it_in[f], c - DIR, r, nrows, ncols);
+        rb_load4<VEC>(Oc[f], P.it_in[f], c, r, nrows, ncols);
+        rb_load4<VEC>(Op[f], P.it_in[f], c + DIR, r, nrows, ncols);
+#pragma unroll
+        for (int e = 0; e < 4; e++) A2[f][e] = A1[f][e] = B3[f][e] = B2[f][e] = C4[f][e] = C3[f][e] = 0.0f;
+    }
+#pragma unroll
+    for (int f = 0; f < NCF; f++) {
+        rb_load4<VEC>(K0[f], P.cf[f], c, r, nrows, ncols);
+#pragma unroll
+        for (int e = 0; e < 4; e++) K1[f][e] = K2[f][e] = K3[f][e] = 0.0f;
+    }
+
+#define PDEIP_RB2_PHASE(CEN, PREV, NEXT, KK)                                                                       \
+    do {                                                                                                           \
+        if (DIR > 0) {                                                                                             \
+            if (p == 0) rb_phase<Mdl, 0>(CEN, PREV, NEXT, none, none, none, KK, r, nrows, omega, om1);             \
+            else        rb_phase<Mdl, 1>(CEN, PREV, NEXT, none, none, none, KK, r, nrows, omega, om1);             \
+        } else {                                                                                                   \
+            if (p == 0) rb_phase<Mdl, 0>(CEN, NEXT, PREV, none, none, none, KK, r, nrows, omega, om1);             \
+            else        rb_phase<Mdl, 1>(CEN, NEXT, PREV, none, none, none, KK, r, nrows, omega, om1);             \
+        }                                                                                                          \
+    } while (0)
+
+    auto inner = [&](int col) { return col >= 1 && col <= ncols - 2; };
+    for (int step = 0; step < nsteps; step++, c += DIR) {
+        float On[NIT][4], Kn[NCF][4]; // prefetch for the next step
+#pragma unroll
+        for (int f = 0; f < NIT; f++) rb_load4<VEC>(On[f], P.it_in[f], c + 2 * DIR, r, nrows, ncols);
+#pragma unroll
+        for (int f = 0; f < NCF; f++) rb_load4<VEC, RB_NT_COEF>(Kn[f], P.cf[f], c + DIR, r, nrows, ncols);
+
+        const int p = (c + gm.col0) & 1;
+        const int c1 = c - DIR, c2 = c - 2 * DIR, c3 = c - 3 * DIR;
+
+        if (FIRST) { // column c becomes current: build its divisors, keep them for the later sweeps
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float k[NCF];
+#pragma unroll
+                for (int f = 0; f < NCF; f++) k[f] = K0[f][e];
+                Mdl::derive(k);
+                K0[Mdl::D0][e] = k[Mdl::D0];
+                K0[Mdl::D1][e] = k[Mdl::D1];
+            }
+            if (gm.store_lane && c >= j0 && c < j1) {
+                rb_store4<VEC>(K0[Mdl::D0], dout0, c, r, nrows);
+                rb_store4<VEC>(K0[Mdl::D1], dout1, c, r, nrows);
+            }
+        }
+
+        // stage 1: red 1 on column c from O(c-D), O(c+D)
+        float A0[NIT][4];
+#pragma unroll
+        for (int f = 0; f < NIT; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) A0[f][e] = Oc[f][e];
+        if (inner(c)) PDEIP_RB2_PHASE(A0, Om, Op, K0);
+
+        // stage 2: black 1 on column c1 from A(c1-D), A(c1+D); afterwards it is "column c1 after sweep 1"
+        float B1[NIT][4];
+#pragma unroll
+        for (int f = 0; f < NIT; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) B1[f][e] = A1[f][e];
+        if (inner(c1)) {
+            PDEIP_RB2_PHASE(B1, A2, A0, K1);
+            rb_replicate_rows<Mdl, VEC>(B1, r, nrows); // rows first (:161-170); the column replicate is substituted below
+        }
+
+        // stage 3: red 2 on column c2 from B(c2-D), B(c2+D); sweep 2 sees a border column as the replicate of
+        // its inner neighbour after sweep 1 (:172-179), i.e. as B(c2) itself
+        float C2[NIT][4];
+#pragma unroll
+        for (int f = 0; f < NIT; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) C2[f][e] = B2[f][e];
+        if (inner(c2)) {
+            const bool prev_is_border = !inner(c2 - DIR), next_is_border = !inner(c2 + DIR);
+            if (prev_is_border || next_is_border) { // only the units that touch the first / last inner column
+                float Pv[NIT][4], Nx[NIT][4];
+#pragma unroll
+                for (int f = 0; f < NIT; f++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        Pv[f][e] = prev_is_border ? B2[f][e] : B3[f][e];
+                        Nx[f][e] = next_is_border ? B2[f][e] : B1[f][e];
+                    }
+                PDEIP_RB2_PHASE(C2, Pv, Nx, K2);
+            } else {
+                PDEIP_RB2_PHASE(C2, B3, B1, K2);
+            }
+        }
+
+        // stage 4: black 2 on column c3 from C(c3-D), C(c3+D); a border column is B(c3)
+        if (c3 >= j0 && c3 < j1 && inner(c3)) {
+            float F[NIT][4];
+#pragma unroll
+            for (int f = 0; f < NIT; f++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) F[f][e] = C3[f][e];
+            const bool prev_is_border = !inner(c3 - DIR), next_is_border = !inner(c3 + DIR);
+            if (prev_is_border || next_is_border) {
+                float Pv[NIT][4], Nx[NIT][4];
+#pragma unroll
+                for (int f = 0; f < NIT; f++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        Pv[f][e] = prev_is_border ? B3[f][e] : C4[f][e];
+                        Nx[f][e] = next_is_border ? B3[f][e] : C2[f][e];
+                    }
+                PDEIP_RB2_PHASE(F, Pv, Nx, K3);
+            } else {
+                PDEIP_RB2_PHASE(F, C4, C2, K3);
+            }
+            rb_replicate_rows<Mdl, VEC>(F, r, nrows);
+            if (gm.store_lane) {
+#pragma unroll
+                for (int f = 0; f < NIT; f++) {
+                    rb_store4<VEC>(F[f], P.it_out[f], c3, r, nrows);
+                    if (c3 == 1) rb_store4<VEC>(F[f], P.it_out[f], 0, r, nrows);
+                    if (c3 == ncols - 2) rb_store4<VEC>(F[f], P.it_out[f], ncols - 1, r, nrows);
+                }
+            }
+        }
+
+        // advance one column
+#pragma unroll
+        for (int f = 0; f < NIT; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                C4[f][e] = C3[f][e];
+                C3[f][e] = C2[f][e];
+                B3[f][e] = B2[f][e];
+                B2[f][e] = B1[f][e];
+                A2[f][e] = A1[f][e];
+                A1[f][e] = A0[f][e];
+                Om[f][e] = Oc[f][e];
+                Oc[f][e] = Op[f][e];
+                Op[f][e] = On[f][e];
+            }
+#pragma unroll
+        for (int f = 0; f < NCF; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                K3[f][e] = K2[f][e];
+                K2[f][e] = K1[f][e];
+                K1[f][e] = K0[f][e];
+                K0[f][e] = Kn[f][e];
+            }
+    }
+#undef PDEIP_RB2_PHASE
+}
+
 // FIRST: this is sweep 0 of a call.  The two derived coefficient planes (divisors) do not exist
 // yet: their slots in P.cf point at the raw planes (e.g. Du, Dv), every column is passed through
 // Mdl::derive() as it becomes current, and the owning unit stores the derived planes to
 // dout0/dout1 for the later sweeps -- what the reference does inside its first sweep
 // (opticalflowSolvers.c:111-127), at the cost of two plane writes instead of a separate pass.
-template <class Mdl, bool VEC, bool FIRST>
+template <class Mdl, bool VEC, bool FIRST, bool TWO = false>
 __global__ void __launch_bounds__(64 * RB_WAVES_PER_BLOCK)
 k_sor_rb(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, int TJ, int ntiles_r,
          int nunits, float omega, int col0, size_t frame_stride)
@@ -349,8 +556,15 @@ k_sor_rb(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, i
     // Alternate the marching direction from strip to strip: strips 2k and 2k+1 finish at their common
     // boundary together and strips 2k+1 and 2k+2 start at theirs together, so the halo columns both
     // sides need are touched at about the same time and the second toucher hits L1/L2 instead of HBM.
-    if (b & 1) rb_march<Mdl, VEC, FIRST, -1>(P, dout0, dout1, gm);
-    else rb_march<Mdl, VEC, FIRST, +1>(P, dout0, dout1, gm);
+    if (TWO) {
+        if constexpr (Mdl::NRO == 0) {
+            if (b & 1) rb_march2<Mdl, VEC, FIRST, -1>(P, dout0, dout1, gm);
+            else rb_march2<Mdl, VEC, FIRST, +1>(P, dout0, dout1, gm);
+        }
+    } else {
+        if (b & 1) rb_march<Mdl, VEC, FIRST, -1>(P, dout0, dout1, gm);
+        else rb_march<Mdl, VEC, FIRST, +1>(P, dout0, dout1, gm);
+    }
 }
 
 } // namespace pdeip
