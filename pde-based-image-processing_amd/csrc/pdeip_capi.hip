@@ -152,6 +152,39 @@ int pick_rb_tj(int nrows, int ncols)
     return forced > 0 ? (forced < 2 ? 2 : forced) : 12;
 }
 
+// Strip width of the two-sweeps-per-launch kernel.  That kernel holds four column stages in registers
+// (one wave per SIMD) and is bound by its instruction stream, not by HBM: a launch takes
+// ceil(units / resident waves) rounds of (TJ + 6) steps, so the best TJ is the one that fills the last
+// round (4K: 12 -> 3 rounds of 18 steps, 133 us; 34 -> 1 round of 40 steps, 113 us; 33 -> 2 rounds, 182 us).
+template <class Mdl>
+int pick_rb2_tj(int nrows, int ncols, int nframes, int ntiles_r)
+{
+    (void)nrows;
+    const int forced = g.rb_tj > 0 ? g.rb_tj : env_int("PDEIP_RB_TJ", 0);
+    if (forced > 0) return forced < 2 ? 2 : forced;
+    static int slots = 0; // waves of this kernel the device holds at once
+    if (slots == 0) {
+        int blocks = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if constexpr (Mdl::NRO == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_sor_rb<Mdl, true, false, true>, 64 * RB_WAVES_PER_BLOCK, 0) != hipSuccess) blocks = 1;
+        }
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        slots = (blocks > 0 ? blocks : 1) * RB_WAVES_PER_BLOCK * prop.multiProcessorCount;
+    }
+    int best = 12;
+    long best_cost = -1;
+    for (int tj = 4; tj <= 64; tj++) {
+        const long units = (long)ntiles_r * ((ncols + tj - 1) / tj) * nframes;
+        const long cost = ((units + slots - 1) / slots) * (tj + 6);
+        if (best_cost < 0 || cost <= best_cost) { // ties: the wider strip re-reads fewer halo columns
+            best_cost = cost;
+            best = tj;
+        }
+    }
+    return best;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sweep drivers (5-point models)
 // ------------------------------------------------------------------------------------------------
@@ -267,20 +300,20 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     vec = vec && aligned16(aux0) && aligned16(aux1);
     for (int f = 0; f < Mdl::NRO; f++) vec = vec && aligned16(P.ro[f]);
 
-    const int TJ = pick_rb_tj(nrows, ncols);
     const int ntiles_r = (nrows + RB_OWN_ROWS - 1) / RB_OWN_ROWS;
-    const int nstrips = (ncols + TJ - 1) / TJ;
-    const int nunits = ntiles_r * nstrips;
-    const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);
     const dim3 block(64 * RB_WAVES_PER_BLOCK);
     // Two sweeps per launch where the model allows it (pdeip_sor_rb.hpp, rb_march2): same results, about
     // two thirds of the traffic per sweep.  PDEIP_RB_FUSE=0 keeps one sweep per launch.
     static const bool fuse_enabled = env_int("PDEIP_RB_FUSE", 1) != 0;
     const bool fuse = fuse_enabled && Mdl::NRO == 0;
+    const int TJ1 = pick_rb_tj(nrows, ncols), TJ2 = fuse ? pick_rb2_tj<Mdl>(nrows, ncols, nframes, ntiles_r) : TJ1;
     SweepTimer timer(s);
     int nlaunch = 0, flips = 0; // flips: how many times the iterate changed buffers
     for (int it = 0; it < iter;) {
         const bool two = fuse && it + 2 <= iter;
+        const int TJ = two ? TJ2 : TJ1;
+        const int nunits = ntiles_r * ((ncols + TJ - 1) / TJ);
+        const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);
         for (int f = 0; f < NIT; f++) {
             P.it_in[f] = (flips & 1) ? bufB[f] : bufA[f];
             P.it_out[f] = (flips & 1) ? bufA[f] : bufB[f];
