@@ -166,9 +166,7 @@ int pick_rb2_tj(int nrows, int ncols, int nframes, int ntiles_r)
     if (slots == 0) {
         int blocks = 0, dev = 0;
         hipDeviceProp_t prop;
-        if constexpr (Mdl::NRO == 0) {
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_sor_rb<Mdl, true, false, true>, 64 * RB_WAVES_PER_BLOCK, 0) != hipSuccess) blocks = 1;
-        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_sor_rb<Mdl, true, false, true>, 64 * RB_WAVES_PER_BLOCK, 0) != hipSuccess) blocks = 1;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         slots = (blocks > 0 ? blocks : 1) * RB_WAVES_PER_BLOCK * prop.multiProcessorCount;
     }
@@ -305,7 +303,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     // Two sweeps per launch where the model allows it (pdeip_sor_rb.hpp, rb_march2): same results, about
     // two thirds of the traffic per sweep.  PDEIP_RB_FUSE=0 keeps one sweep per launch.
     static const bool fuse_enabled = env_int("PDEIP_RB_FUSE", 1) != 0;
-    const bool fuse = fuse_enabled && Mdl::NRO == 0;
+    const bool fuse = fuse_enabled;
     const int TJ1 = pick_rb_tj(nrows, ncols), TJ2 = fuse ? pick_rb2_tj<Mdl>(nrows, ncols, nframes, ntiles_r) : TJ1;
     SweepTimer timer(s);
     int nlaunch = 0, flips = 0; // flips: how many times the iterate changed buffers

@@ -296,7 +296,7 @@ __device__ __forceinline__ void rb_march(const SweepPlanes<Mdl> &P, float *dout0
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two sweeps per launch (models without read-only neighbour fields).
+// Two sweeps per launch.
 //
 // One sweep moves every plane through HBM once; the arithmetic of a sweep keeps the VALUs less than half
 // busy.  Two consecutive sweeps share all nine coefficient planes and the iterate never has to leave the
@@ -329,11 +329,9 @@ __device__ __forceinline__ void rb_replicate_rows(float (&F)[Mdl::NIT][4], int r
 template <class Mdl, bool VEC, bool FIRST, int DIR>
 __device__ __forceinline__ void rb_march2(const SweepPlanes<Mdl> &P, float *dout0, float *dout1, const RbGeom &gm)
 {
-    static_assert(Mdl::NRO == 0, "the fused march keeps no window of read-only neighbour fields");
-    constexpr int NIT = Mdl::NIT, NCF = Mdl::NCF;
+    constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NRO1 = at_least_one<NRO>::value, NCF = Mdl::NCF;
     const int r = gm.r, j0 = gm.j0, j1 = gm.j1, nrows = gm.nrows, ncols = gm.ncols;
     const float omega = gm.omega, om1 = 1.0f - gm.omega;
-    const float none[1][4] = {{0.0f, 0.0f, 0.0f, 0.0f}};
 
     // windows, relative to the column c of stage "red 1" (D = DIR); the newest entry of A, B, C is produced
     // in the step.  (A five-fold unrolled march over register rings removes the window moves below but
@@ -343,6 +341,9 @@ __device__ __forceinline__ void rb_march2(const SweepPlanes<Mdl> &P, float *dout
     float B3[NIT][4], B2[NIT][4];                // after sweep 1 at c-3D, c-2D
     float C4[NIT][4], C3[NIT][4];                // after red 2 at c-4D, c-3D
     float K0[NCF][4], K1[NCF][4], K2[NCF][4], K3[NCF][4]; // coefficients at c, c-D, c-2D, c-3D
+    // read-only neighbour fields (the base flow of the late-linearisation models) at c+D .. c-4D; they do not
+    // change between the sweeps, so their border columns are read as stored
+    float Rp[NRO1][4], R0[NRO1][4], R1[NRO1][4], R2[NRO1][4], R3[NRO1][4], R4[NRO1][4];
 
     int c = (DIR > 0) ? j0 - 3 : j1 + 2;
     const int nsteps = j1 - j0 + 6;
@@ -360,23 +361,38 @@ __device__ __forceinline__ void rb_march2(const SweepPlanes<Mdl> &P, float *dout
 #pragma unroll
         for (int e = 0; e < 4; e++) K1[f][e] = K2[f][e] = K3[f][e] = 0.0f;
     }
+#pragma unroll
+    for (int f = 0; f < NRO1; f++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) Rp[f][e] = R0[f][e] = R1[f][e] = R2[f][e] = R3[f][e] = R4[f][e] = 0.0f;
+        if (NRO > 0) {
+            rb_load4<VEC>(R1[f], P.ro[f], c - DIR, r, nrows, ncols);
+            rb_load4<VEC>(R0[f], P.ro[f], c, r, nrows, ncols);
+            rb_load4<VEC>(Rp[f], P.ro[f], c + DIR, r, nrows, ncols);
+        }
+    }
 
-#define PDEIP_RB2_PHASE(CEN, PREV, NEXT, KK)                                                                       \
+#define PDEIP_RB2_PHASE(CEN, PREV, NEXT, RC, RPREV, RNEXT, KK)                                                      \
     do {                                                                                                           \
         if (DIR > 0) {                                                                                             \
-            if (p == 0) rb_phase<Mdl, 0>(CEN, PREV, NEXT, none, none, none, KK, r, nrows, omega, om1);             \
-            else        rb_phase<Mdl, 1>(CEN, PREV, NEXT, none, none, none, KK, r, nrows, omega, om1);             \
+            if (p == 0) rb_phase<Mdl, 0>(CEN, PREV, NEXT, RC, RPREV, RNEXT, KK, r, nrows, omega, om1);             \
+            else        rb_phase<Mdl, 1>(CEN, PREV, NEXT, RC, RPREV, RNEXT, KK, r, nrows, omega, om1);             \
         } else {                                                                                                   \
-            if (p == 0) rb_phase<Mdl, 0>(CEN, NEXT, PREV, none, none, none, KK, r, nrows, omega, om1);             \
-            else        rb_phase<Mdl, 1>(CEN, NEXT, PREV, none, none, none, KK, r, nrows, omega, om1);             \
+            if (p == 0) rb_phase<Mdl, 0>(CEN, NEXT, PREV, RC, RNEXT, RPREV, KK, r, nrows, omega, om1);             \
+            else        rb_phase<Mdl, 1>(CEN, NEXT, PREV, RC, RNEXT, RPREV, KK, r, nrows, omega, om1);             \
         }                                                                                                          \
     } while (0)
 
     auto inner = [&](int col) { return col >= 1 && col <= ncols - 2; };
     for (int step = 0; step < nsteps; step++, c += DIR) {
-        float On[NIT][4], Kn[NCF][4]; // prefetch for the next step
+        float On[NIT][4], Kn[NCF][4], Rn[NRO1][4]; // prefetch for the next step
 #pragma unroll
         for (int f = 0; f < NIT; f++) rb_load4<VEC>(On[f], P.it_in[f], c + 2 * DIR, r, nrows, ncols);
+#pragma unroll
+        for (int f = 0; f < NRO1; f++) {
+            if (NRO > 0) rb_load4<VEC>(Rn[f], P.ro[f], c + 2 * DIR, r, nrows, ncols);
+            else Rn[f][0] = Rn[f][1] = Rn[f][2] = Rn[f][3] = 0.0f;
+        }
 #pragma unroll
         for (int f = 0; f < NCF; f++) rb_load4<VEC, RB_NT_COEF>(Kn[f], P.cf[f], c + DIR, r, nrows, ncols);
 
@@ -405,7 +421,7 @@ __device__ __forceinline__ void rb_march2(const SweepPlanes<Mdl> &P, float *dout
         for (int f = 0; f < NIT; f++)
 #pragma unroll
             for (int e = 0; e < 4; e++) A0[f][e] = Oc[f][e];
-        if (inner(c)) PDEIP_RB2_PHASE(A0, Om, Op, K0);
+        if (inner(c)) PDEIP_RB2_PHASE(A0, Om, Op, R0, R1, Rp, K0);
 
         // stage 2: black 1 on column c1 from A(c1-D), A(c1+D); afterwards it is "column c1 after sweep 1"
         float B1[NIT][4];
@@ -414,7 +430,7 @@ __device__ __forceinline__ void rb_march2(const SweepPlanes<Mdl> &P, float *dout
 #pragma unroll
             for (int e = 0; e < 4; e++) B1[f][e] = A1[f][e];
         if (inner(c1)) {
-            PDEIP_RB2_PHASE(B1, A2, A0, K1);
+            PDEIP_RB2_PHASE(B1, A2, A0, R1, R2, R0, K1);
             rb_replicate_rows<Mdl, VEC>(B1, r, nrows); // rows first (:161-170); the column replicate is substituted below
         }
 
@@ -436,9 +452,9 @@ __device__ __forceinline__ void rb_march2(const SweepPlanes<Mdl> &P, float *dout
                         Pv[f][e] = prev_is_border ? B2[f][e] : B3[f][e];
                         Nx[f][e] = next_is_border ? B2[f][e] : B1[f][e];
                     }
-                PDEIP_RB2_PHASE(C2, Pv, Nx, K2);
+                PDEIP_RB2_PHASE(C2, Pv, Nx, R2, R3, R1, K2);
             } else {
-                PDEIP_RB2_PHASE(C2, B3, B1, K2);
+                PDEIP_RB2_PHASE(C2, B3, B1, R2, R3, R1, K2);
             }
         }
 
@@ -459,9 +475,9 @@ __device__ __forceinline__ void rb_march2(const SweepPlanes<Mdl> &P, float *dout
                         Pv[f][e] = prev_is_border ? B3[f][e] : C4[f][e];
                         Nx[f][e] = next_is_border ? B3[f][e] : C2[f][e];
                     }
-                PDEIP_RB2_PHASE(F, Pv, Nx, K3);
+                PDEIP_RB2_PHASE(F, Pv, Nx, R3, R4, R2, K3);
             } else {
-                PDEIP_RB2_PHASE(F, C4, C2, K3);
+                PDEIP_RB2_PHASE(F, C4, C2, R3, R4, R2, K3);
             }
             rb_replicate_rows<Mdl, VEC>(F, r, nrows);
             if (gm.store_lane) {
@@ -497,6 +513,17 @@ __device__ __forceinline__ void rb_march2(const SweepPlanes<Mdl> &P, float *dout
                 K2[f][e] = K1[f][e];
                 K1[f][e] = K0[f][e];
                 K0[f][e] = Kn[f][e];
+            }
+#pragma unroll
+        for (int f = 0; f < NRO1; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                R4[f][e] = R3[f][e];
+                R3[f][e] = R2[f][e];
+                R2[f][e] = R1[f][e];
+                R1[f][e] = R0[f][e];
+                R0[f][e] = Rp[f][e];
+                Rp[f][e] = Rn[f][e];
             }
     }
 #undef PDEIP_RB2_PHASE
@@ -557,10 +584,8 @@ k_sor_rb(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, i
     // boundary together and strips 2k+1 and 2k+2 start at theirs together, so the halo columns both
     // sides need are touched at about the same time and the second toucher hits L1/L2 instead of HBM.
     if (TWO) {
-        if constexpr (Mdl::NRO == 0) {
-            if (b & 1) rb_march2<Mdl, VEC, FIRST, -1>(P, dout0, dout1, gm);
-            else rb_march2<Mdl, VEC, FIRST, +1>(P, dout0, dout1, gm);
-        }
+        if (b & 1) rb_march2<Mdl, VEC, FIRST, -1>(P, dout0, dout1, gm);
+        else rb_march2<Mdl, VEC, FIRST, +1>(P, dout0, dout1, gm);
     } else {
         if (b & 1) rb_march<Mdl, VEC, FIRST, -1>(P, dout0, dout1, gm);
         else rb_march<Mdl, VEC, FIRST, +1>(P, dout0, dout1, gm);
