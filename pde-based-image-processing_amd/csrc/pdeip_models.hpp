@@ -21,6 +21,18 @@ __device__ __forceinline__ bool is_nan(float x) { return x != x; }
 
 template <int N> struct at_least_one { static constexpr int value = N > 0 ? N : 1; };
 
+// Value of the neighbouring lane in one VALU instruction (DPP wave_shr:1 / wave_shl:1 across the whole
+// 64-lane wave); the first / last lane keeps its own value, like __shfl_up(v, 1) / __shfl_down(v, 1) --
+// which compile to an LDS-crossbar ds_bpermute with a round trip that nothing hides at one wave per SIMD.
+__device__ __forceinline__ float lane_above(float v) // lane l <- lane l-1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_below(float v) // lane l <- lane l+1
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
 // ---- Horn-Schunck / early linearization: GS_SOR_elin4_2d (opticalflowSolvers.c:41-186)
 struct ModelElin4 {
     static constexpr int NIT = 2, NRO = 0, NCF = 9;

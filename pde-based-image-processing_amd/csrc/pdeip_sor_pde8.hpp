@@ -43,9 +43,9 @@ template <int E0>
 __device__ __forceinline__ void p8_phase(float (&C)[4], const float (&W)[4], const float (&E)[4],
                                          const float (&cf)[ModelPde8::NCF][4], int r, int nrows, float omega, float om1)
 {
-    const float ce = (E0 == 0) ? __shfl_up(C[3], 1) : __shfl_down(C[0], 1);
-    const float we = (E0 == 0) ? __shfl_up(W[3], 1) : __shfl_down(W[0], 1);
-    const float ee = (E0 == 0) ? __shfl_up(E[3], 1) : __shfl_down(E[0], 1);
+    const float ce = (E0 == 0) ? lane_above(C[3]) : lane_below(C[0]);
+    const float we = (E0 == 0) ? lane_above(W[3]) : lane_below(W[0]);
+    const float ee = (E0 == 0) ? lane_above(E[3]) : lane_below(E[0]);
 #pragma unroll
     for (int e = E0; e < 4; e += 2) {
         const int i = r + e;
@@ -166,7 +166,7 @@ k_pde8_colour(Pde8SweepPlanes P, float *dout0, float *dout1, int nrows, int ncol
                 p8_phase<0>(F, Rmm, Rc, CFm, r, nrows, omega, om1);
                 p8_phase<1>(F, Rmm, Rc, CFm, r, nrows, omega, om1);
             }
-            const float prev3 = VEC ? 0.0f : __shfl_up(F[3], 1);
+            const float prev3 = VEC ? 0.0f : lane_above(F[3]);
 #pragma unroll
             for (int e = 0; e < 4; e++) { // border rows replicate (pdeSolvers.c:249-255)
                 const int i = r + e;

@@ -94,10 +94,10 @@ __device__ __forceinline__ void rb_phase(float (&C)[Mdl::NIT][4], const float (&
     float edge[NIT], redge[NRO1];
 #pragma unroll
     for (int f = 0; f < NIT; f++)
-        edge[f] = (E0 == 0) ? __shfl_up(C[f][3], 1) : __shfl_down(C[f][0], 1);
+        edge[f] = (E0 == 0) ? lane_above(C[f][3]) : lane_below(C[f][0]);
 #pragma unroll
     for (int f = 0; f < NRO1; f++)
-        redge[f] = (NRO == 0) ? 0.0f : ((E0 == 0) ? __shfl_up(rC[f][3], 1) : __shfl_down(rC[f][0], 1));
+        redge[f] = (NRO == 0) ? 0.0f : ((E0 == 0) ? lane_above(rC[f][3]) : lane_below(rC[f][0]));
 
 #pragma unroll
     for (int e = E0; e < 4; e += 2) {
@@ -249,7 +249,7 @@ __device__ __forceinline__ void rb_march(const SweepPlanes<Mdl> &P, float *dout0
             // replicate into the border rows 0 and nrows-1 (rows first, opticalflowSolvers.c:161-170)
 #pragma unroll
             for (int f = 0; f < NIT; f++) {
-                const float prev3 = VEC ? 0.0f : __shfl_up(F[f][3], 1);
+                const float prev3 = VEC ? 0.0f : lane_above(F[f][3]);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int i = r + e;
@@ -316,7 +316,7 @@ __device__ __forceinline__ void rb_replicate_rows(float (&F)[Mdl::NIT][4], int r
 {
 #pragma unroll
     for (int f = 0; f < Mdl::NIT; f++) {
-        const float prev3 = VEC ? 0.0f : __shfl_up(F[f][3], 1);
+        const float prev3 = VEC ? 0.0f : lane_above(F[f][3]);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int i = r + e;
