@@ -142,6 +142,16 @@ int pdeip_disp_sor_llin4(const float *U, const float *dU, const float *Cu, const
                          int nrows, int ncols, int iter, float omega, int solver, float *dU_out,
                          float *RU);
 
+/* [dU0 dU1] = Disp_sor_llin_sym4_2d(U0,dU0,Cu0,Du0,wW0,wN0,wE0,wS0, U1,dU1,Cu1,Du1,wW1,wN1,wE1,wS1, iter,omega,solver)
+ * replaces mex/source/Disp_sor_llin_sym4_2d.c:82-440 -> GS_SOR_llinsym4_2d / GS_ALR_SOR_llinsym4_2d
+ * (disparitySolvers.c:301,462): two disparity fields relaxed side by side that never read each other (the
+ * symmetry constraint lives in the MATLAB driver).  The gateway solves unconditionally: iter<=0 returns copies. */
+int pdeip_disp_sor_llin_sym4(const float *U0, const float *dU0, const float *Cu0, const float *Du0, const float *wW0,
+                             const float *wN0, const float *wE0, const float *wS0, const float *U1, const float *dU1,
+                             const float *Cu1, const float *Du1, const float *wW1, const float *wN1, const float *wE1,
+                             const float *wS1, int nrows, int ncols, int iter, float omega, int solver,
+                             float *dU_out0, float *dU_out1);
+
 /* X = PDEsolver4(X,TRACE,B,wW,wN,wE,wS,iter,omega,solver)
  * replaces mex/source/PDEsolver4.c:54-249 -> GS_SOR_4_2d (pdeSolvers.c:44).  Every plane is
  * [nrows x ncols x nframes].  iter<=0 returns a copy (PDEsolver4.c:239).  solver 3 (unbound
@@ -201,6 +211,11 @@ int pdeip_disp_sor_llin4_dev(void *stream, const float *U, float *dU, const floa
                              const float *Du, const float *wW, const float *wN, const float *wE,
                              const float *wS, int nrows, int ncols, int iter, float omega,
                              int mode, int col0);
+int pdeip_disp_sor_llin_sym4_dev(void *stream, const float *U0, float *dU0, const float *Cu0, const float *Du0,
+                                 const float *wW0, const float *wN0, const float *wE0, const float *wS0,
+                                 const float *U1, float *dU1, const float *Cu1, const float *Du1,
+                                 const float *wW1, const float *wN1, const float *wE1, const float *wS1,
+                                 int nrows, int ncols, int iter, float omega, int solver, int mode, int col0);
 int pdeip_pde_sor4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
                        const float *wN, const float *wE, const float *wS, int nrows, int ncols,
                        int nframes, int iter, float omega, int mode, int col0);

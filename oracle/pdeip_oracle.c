@@ -466,6 +466,65 @@ void orc_disp_sor_llin4(const float *U, float *dU, const float *Cu, const float 
     free(dividend);
 }
 
+/* disparitySolvers.c:301-460 (GS_SOR_llinsym4_2d): the two fields never read each other; per pixel field 0 then
+ * field 1.  Same neighbour sum and divisors as above, but omega multiplies the finished quotient (:425-429). */
+void orc_disp_sor_llinsym4(const float *U0, float *dU0, const float *Cu0, const float *Du0, const float *wW0,
+                           const float *wN0, const float *wE0, const float *wS0, const float *U1, float *dU1,
+                           const float *Cu1, const float *Du1, const float *wW1, const float *wN1, const float *wE1,
+                           const float *wS1, int nrows, int ncols, int iter, float omega, int order)
+{
+    size_t n = (size_t)nrows * ncols;
+    const float *U[2], *Cu[2], *Du[2], *wW[2], *wN[2], *wE[2], *wS[2];
+    float *dU[2], *div[2], *dividend[2];
+    int it, k;
+    U[0] = U0; U[1] = U1; dU[0] = dU0; dU[1] = dU1; Cu[0] = Cu0; Cu[1] = Cu1; Du[0] = Du0; Du[1] = Du1;
+    wW[0] = wW0; wW[1] = wW1; wN[0] = wN0; wN[1] = wN1; wE[0] = wE0; wE[1] = wE1; wS[0] = wS0; wS[1] = wS1;
+    if (iter <= 0) return;
+    for (k = 0; k < 2; k++) {
+        div[k] = (float *)calloc(n, sizeof(float));
+        dividend[k] = (float *)calloc(n, sizeof(float)); /* stays 0 where Cu is NaN (:357, :386) */
+    }
+    if (div[0] && div[1] && dividend[0] && dividend[1]) {
+        int i, j;
+        for (k = 0; k < 2; k++) /* :381-412, built by the reference during sweep 0 */
+            for (j = 1; j < ncols - 1; j++)
+                for (i = 1; i < nrows - 1; i++) {
+                    size_t pos = (size_t)j * nrows + i;
+                    float t;
+                    if (!ORC_ISNAN(Cu[k][pos])) {
+                        dividend[k][pos] = Cu[k][pos];
+                        t = Du[k][pos] + wE[k][pos];
+                    } else {
+                        t = wE[k][pos];
+                    }
+                    t = t + wW[k][pos];
+                    t = t + wS[k][pos];
+                    t = t + wN[k][pos];
+                    div[k][pos] = 1.0f / t;
+                }
+        for (it = 0; it < iter; it++) {
+            FOR_INTERIOR(order, 2, ((i + j + ORC_CPAR(order)) & 1), {
+                size_t pos = (size_t)j * nrows + i;
+                for (k = 0; k < 2; k++) {
+                    float nb = disp_neigh(U[k], dU[k], pos, nrows, wW[k], wN[k], wE[k], wS[k]);
+                    float approx = nb + dividend[k][pos];
+                    float A, B;
+                    approx = approx * div[k][pos];
+                    A = (1.0f - omega) * dU[k][pos];
+                    B = omega * approx;
+                    dU[k][pos] = A + B;
+                }
+            });
+            fill_borders(dU[0], nrows, ncols);
+            fill_borders(dU[1], nrows, ncols);
+        }
+    }
+    for (k = 0; k < 2; k++) {
+        free(div[k]);
+        free(dividend[k]);
+    }
+}
+
 void orc_disp_res_llin4(float *RU, const float *U, const float *dU, const float *Cu,
                         const float *Du, const float *wW, const float *wN, const float *wE,
                         const float *wS, int nrows, int ncols)

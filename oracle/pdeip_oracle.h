@@ -77,6 +77,12 @@ void orc_disp_sor_llin4(const float *U, float *dU, const float *Cu, const float 
                         const float *wW, const float *wN, const float *wE, const float *wS,
                         int nrows, int ncols, int iter, float omega, int order);
 
+/* disparitySolvers.c:301-460 (GS_SOR_llinsym4_2d): two disparity fields side by side; dU0,dU1 in place. */
+void orc_disp_sor_llinsym4(const float *U0, float *dU0, const float *Cu0, const float *Du0, const float *wW0,
+                           const float *wN0, const float *wE0, const float *wS0, const float *U1, float *dU1,
+                           const float *Cu1, const float *Du1, const float *wW1, const float *wN1, const float *wE1,
+                           const float *wS1, int nrows, int ncols, int iter, float omega, int order);
+
 /* disparitySolvers.c:218-293 (Residuals_llin4_2d). */
 void orc_disp_res_llin4(float *RU, const float *U, const float *dU, const float *Cu,
                         const float *Du, const float *wW, const float *wN, const float *wE,

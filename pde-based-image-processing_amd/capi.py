@@ -44,6 +44,7 @@ SIGNATURES = {
     "pdeip_oflow_lhs_elin4": _sig(9, [_I, _I, _I, _P, _P]),
     "pdeip_oflow_lhs_llin4": _sig(11, [_I, _I, _I, _P, _P]),
     "pdeip_disp_sor_llin4": _sig(8, [_I, _I, _I, _F, _I, _P, _P]),
+    "pdeip_disp_sor_llin_sym4": _sig(16, [_I, _I, _I, _F, _I, _P, _P]),
     "pdeip_pde_sor4": _sig(7, [_I, _I, _I, _I, _F, _I, _P]),
     "pdeip_pde_sor8": _sig(11, [_I, _I, _I, _I, _F, _I, _P]),
     "pdeip_diffweights6": [_P, _I, _I, _I, _F, _P, _P, _P, _P],
@@ -54,6 +55,7 @@ SIGNATURES = {
     "pdeip_oflow_sor_elin4_dev": _sig(1 + 11, [_I, _I, _I, _F, _I, _I]),
     "pdeip_oflow_sor_llin4_dev": _sig(1 + 13, [_I, _I, _I, _F, _I, _I]),
     "pdeip_disp_sor_llin4_dev": _sig(1 + 8, [_I, _I, _I, _F, _I, _I]),
+    "pdeip_disp_sor_llin_sym4_dev": _sig(1 + 16, [_I, _I, _I, _F, _I, _I, _I]),
     "pdeip_pde_sor4_dev": _sig(1 + 7, [_I, _I, _I, _I, _F, _I, _I]),
     "pdeip_pde_sor8_dev": _sig(1 + 11, [_I, _I, _I, _I, _F, _I, _I]),
     "pdeip_oflow_alr_elin4_dev": _sig(1 + 11, [_I, _I, _I, _F, _I]),

@@ -525,6 +525,39 @@ extern "C" int pdeip_disp_sor_llin4_dev(void *stream, const float *U, float *dU,
     return PDEIP_OK;
 }
 
+// Disp_sor_llin_sym4_2d: two disparity fields that do not read each other (disparitySolvers.c:301-548).
+// solver 1: ModelDispSym4 on each; solver 2: the line solvers are the plain disparity ones (:503-540).
+extern "C" int pdeip_disp_sor_llin_sym4_dev(void *stream, const float *U0, float *dU0, const float *Cu0, const float *Du0,
+                                            const float *wW0, const float *wN0, const float *wE0, const float *wS0,
+                                            const float *U1, float *dU1, const float *Cu1, const float *Du1,
+                                            const float *wW1, const float *wN1, const float *wE1, const float *wS1,
+                                            int nrows, int ncols, int iter, float omega, int solver, int mode, int col0)
+{
+    const char *who = "pdeip_disp_sor_llin_sym4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    RC(check_solver(who, solver));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (iter <= 0) return PDEIP_OK;
+    const float *U[2] = {U0, U1}, *cf[2][6] = {{Cu0, Du0, wW0, wN0, wE0, wS0}, {Cu1, Du1, wW1, wN1, wE1, wS1}};
+    float *dU[2] = {dU0, dU1};
+    int launches = 0;
+    for (int k = 0; k < 2; k++) {
+        if (solver == PDEIP_SOLVER_ALR) {
+            RC(pdeip_disp_alr_llin4_dev(stream, U[k], dU[k], cf[k][0], cf[k][1], cf[k][2], cf[k][3], cf[k][4], cf[k][5], nrows, ncols, iter, omega, mode));
+        } else {
+            SweepPlanes<ModelDispSym4> P{};
+            P.it_out[0] = dU[k];
+            P.ro[0] = U[k];
+            for (int f = 0; f < 6; f++) P.cf[f] = cf[k][f];
+            RC(run_sweeps<ModelDispSym4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
+        }
+        launches += g.last_launches;
+    }
+    g.last_launches = launches;
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_pde_sor4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
                                   const float *wN, const float *wE, const float *wS, int nrows, int ncols,
                                   int nframes, int iter, float omega, int mode, int col0)
@@ -1257,6 +1290,43 @@ extern "C" int pdeip_disp_sor_llin4(const float *U, const float *dU, const float
     else
         RC(pdeip_disp_sor_llin4_dev(nullptr, dUin, ddU, dCu, dDu, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
     RC(download(dU_out, ddU, n));
+    RC(pdeip_persist_error());
+    return PDEIP_OK;
+}
+
+// [dU0 dU1] = Disp_sor_llin_sym4_2d(U0,dU0,Cu0,Du0,wW0,wN0,wE0,wS0, U1,dU1,Cu1,Du1,wW1,wN1,wE1,wS1, iter,omega,solver)
+// The gateway copies both increments in and solves unconditionally (Disp_sor_llin_sym4_2d.c:418-440): iter <= 0 returns copies.
+extern "C" int pdeip_disp_sor_llin_sym4(const float *U0, const float *dU0, const float *Cu0, const float *Du0, const float *wW0,
+                                        const float *wN0, const float *wE0, const float *wS0, const float *U1, const float *dU1,
+                                        const float *Cu1, const float *Du1, const float *wW1, const float *wN1, const float *wE1,
+                                        const float *wS1, int nrows, int ncols, int iter, float omega, int solver,
+                                        float *dU_out0, float *dU_out1)
+{
+    const char *who = "Disp_sor_llin_sym4_2d";
+    const float *in[16] = {U0, dU0, Cu0, Du0, wW0, wN0, wE0, wS0, U1, dU1, Cu1, Du1, wW1, wN1, wE1, wS1};
+    for (int k = 0; k < 16; k++)
+        if (!in[k]) return set_err(PDEIP_ERR_ARG, "%s: input %d is NULL", who, k + 1);
+    NONNULL(who, dU_out0); NONNULL(who, dU_out1);
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_solver(who, solver));
+    RC(use_device());
+    const size_t n = (size_t)nrows * ncols;
+    if (iter <= 0) {
+        memcpy(dU_out0, dU0, n * sizeof(float));
+        memcpy(dU_out1, dU1, n * sizeof(float));
+        return PDEIP_OK;
+    }
+    Arena ar;
+    RC(ar.init(pad4(n) * 16));
+    float *d[16];
+    for (int k = 0; k < 16; k++) {
+        d[k] = ar.take(n);
+        RC(upload(d[k], in[k], n));
+    }
+    RC(pdeip_disp_sor_llin_sym4_dev(nullptr, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11], d[12], d[13],
+                                    d[14], d[15], nrows, ncols, iter, omega, solver, g.mode, 0));
+    RC(download(dU_out0, d[1], n));
+    RC(download(dU_out1, d[9], n));
     RC(pdeip_persist_error());
     return PDEIP_OK;
 }

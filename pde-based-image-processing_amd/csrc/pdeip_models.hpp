@@ -189,6 +189,26 @@ struct ModelDisp4 {
     }
 };
 
+// ---- symmetric stereo: GS_SOR_llinsym4_2d (disparitySolvers.c:301-460) relaxes two disparity fields that do not
+// read each other; per field it is the solver above except for the association of the last line:
+// omega * ((nb + dividend) * div) instead of (omega * (nb + dividend)) * div (:425-429 vs :116-118).
+struct ModelDispSym4 : ModelDisp4 {
+    __device__ __forceinline__ static void update(float (&c)[1], const float (&W)[1],
+                                                  const float (&E)[1], const float (&N)[1],
+                                                  const float (&S)[1], const float (&rc)[1],
+                                                  const float (&rW)[1], const float (&rE)[1],
+                                                  const float (&rN)[1], const float (&rS)[1],
+                                                  const float (&cf)[6], float omega, float om1)
+    {
+        const float nb = neigh(W[0], E[0], N[0], S[0], rW[0], rE[0], rN[0], rS[0], rc[0], cf);
+        float approx = nb + cf[cDividend];
+        approx = approx * cf[cDiv];
+        const float A = om1 * c[0];
+        const float B = omega * approx;
+        c[0] = A + B;
+    }
+};
+
 // ---- scalar PDE, 4 neighbours: GS_SOR_4_2d (pdeSolvers.c:44-146)
 struct ModelPde4 {
     static constexpr int NIT = 1, NRO = 0, NCF = 6;

@@ -164,6 +164,22 @@ def Disp_sor_llin4_2d(U, dU, Cu, Du, wW, wN, wE, wS, iter, omega, solver, nargou
     return out if nargout < 2 else (out, RU)
 
 
+def Disp_sor_llin_sym4_2d(U0, dU0, Cu0, Du0, wW0, wN0, wE0, wS0, U1, dU1, Cu1, Du1, wW1, wN1, wE1, wS1, iter, omega, solver,
+                          nargout=2):
+    """[dU0 dU1] = Disp_sor_llin_sym4_2d(...)  -- mex/source/Disp_sor_llin_sym4_2d.c:82-440."""
+    who = "Disp_sor_llin_sym4_2d"
+    if nargout < 2:
+        raise MexError(capi.PDEIP_ERR_ARG, "%s insufficient number of outputs." % who)
+    names = ["U_in0", "dU_in0", "Cu0", "Du0", "wW0", "wN0", "wE0", "wS0", "U_in1", "dU_in1", "Cu1", "Du1", "wW1", "wN1", "wE1", "wS1"]
+    arrs = [_single(n, who, a) for n, a in zip(names, [U0, dU0, Cu0, Du0, wW0, wN0, wE0, wS0, U1, dU1, Cu1, Du1, wW1, wN1, wE1, wS1])]
+    it, omega, solver = _scalar("iter", who, iter), _scalar("omega", who, omega), int(_scalar("solver", who, solver))
+    _same_plane(who, arrs[0], **dict(zip(names, arrs)))
+    o0, o1 = _out_like(arrs[1]), _out_like(arrs[9])
+    nrows, ncols = arrs[0].shape[:2]
+    _run("pdeip_disp_sor_llin_sym4", *[_ptr(a) for a in arrs], nrows, ncols, int(it), omega, solver, _ptr(o0), _ptr(o1))
+    return o0, o1
+
+
 def _pde(who, fn, names, arrays, it, omega, solver, nargout):
     if nargout < 1:
         raise MexError(capi.PDEIP_ERR_ARG, "%s: error insufficient number of outputs." % who)

@@ -30,6 +30,8 @@ CASES = [
     ("llin8_a", "Oflow_sor_llin8_2d", lambda: pb.llin8(121, 33, 29, nan_frac=0.03), dict(it=4, omega=1.9, nargout=4)),
     ("disp4_a", "Disp_sor_llin4_2d", lambda: pb.disp4(131, 24, 40), dict(it=4, omega=1.9, nargout=2)),
     ("disp4_nan", "Disp_sor_llin4_2d", lambda: pb.disp4(132, 33, 29, nan_frac=0.06), dict(it=6, omega=1.9, nargout=1)),
+    ("dispsym4_nan", "Disp_sor_llin_sym4_2d", lambda: pb.dispsym4(133, 33, 29, nan_frac=0.05), dict(it=4, omega=1.9, nargout=2)),
+    ("alr_dispsym4", "Disp_sor_llin_sym4_2d", lambda: pb.dispsym4(207, 24, 40, nan_frac=0.03), dict(it=2, omega=1.4, nargout=2, solver=2)),
     ("pde4_a", "PDEsolver4", lambda: pb.pde4(141, 24, 40), dict(it=4, omega=1.75)),
     ("pde4_frames_nan", "PDEsolver4", lambda: pb.pde4(142, 33, 29, nframes=3, nan_frac=0.06), dict(it=5, omega=1.75)),
     ("pde8_a", "PDEsolver8", lambda: pb.pde8(151, 24, 40), dict(it=4, omega=1.75)),
@@ -55,7 +57,8 @@ LHS_CASES = [
     ("lhs_llin4_frames", "oflow_lhs_llin4", lambda: pb.llin4(182, 33, 29, nframes=3, nan_frac=0.05, nan_mode="D"),
      ("U", "V", "dU", "dV", "M", "Du", "Dv", "wW", "wN", "wE", "wS")),
 ]
-ORDERED = {"Oflow_sor_elin4_2d", "Oflow_sor_llin4_2d", "Oflow_sor_llin8_2d", "Disp_sor_llin4_2d", "PDEsolver4", "PDEsolver8"}
+ORDERED = {"Oflow_sor_elin4_2d", "Oflow_sor_llin4_2d", "Oflow_sor_llin8_2d", "Disp_sor_llin4_2d", "Disp_sor_llin_sym4_2d", "PDEsolver4",
+           "PDEsolver8"}
 
 
 def run_case(gateway, p, kw, order):

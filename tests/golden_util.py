@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ORDERED = {"Oflow_sor_elin4_2d", "Oflow_sor_llin4_2d", "Oflow_sor_llin8_2d", "Disp_sor_llin4_2d", "PDEsolver4", "PDEsolver8"}
+ORDERED = {"Oflow_sor_elin4_2d", "Oflow_sor_llin4_2d", "Oflow_sor_llin8_2d", "Disp_sor_llin4_2d", "Disp_sor_llin_sym4_2d", "PDEsolver4",
+           "PDEsolver8"}
 
 
 def names():

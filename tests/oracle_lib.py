@@ -28,6 +28,7 @@ _SIGS = {
     "orc_oflow_lhs_llin4": [_P] * 13 + [_I, _I, _I],
     "orc_disp_sor_llin4": [_P] * 8 + [_I, _I, _I, _F, _I],
     "orc_disp_res_llin4": [_P] * 9 + [_I, _I],
+    "orc_disp_sor_llinsym4": [_P] * 16 + [_I, _I, _I, _F, _I],
     "orc_pde_sor4": [_P] * 7 + [_I, _I, _I, _I, _F, _I],
     "orc_pde_sor8": [_P] * 11 + [_I, _I, _I, _I, _F, _I],
     "orc_diffweights6": [_P] * 5 + [_I, _I, _I, _F],
@@ -262,6 +263,21 @@ def Disp_sor_llin4_2d(U, dU, Cu, Du, wW, wN, wE, wS, it, omega, solver=1, nargou
     fn = disp_sor_llin4 if solver == 1 else disp_alr_llin4
     out = fn(U, dU, Cu, Du, wW, wN, wE, wS, it, omega, order) if it > 0 else np.zeros_like(F(dU))
     return out if nargout < 2 else (out, np.zeros_like(F(U)))  # RU allocated, never computed
+
+
+def Disp_sor_llin_sym4_2d(U0, dU0, Cu0, Du0, wW0, wN0, wE0, wS0, U1, dU1, Cu1, Du1, wW1, wN1, wE1, wS1, it, omega, solver=1, nargout=2,
+                          order=LEX):
+    """Gateway semantics of Disp_sor_llin_sym4_2d.c: copy-in, solve unconditionally."""
+    assert solver in (1, 2)
+    a = [F(x) for x in (U0, dU0, Cu0, Du0, wW0, wN0, wE0, wS0, U1, dU1, Cu1, Du1, wW1, wN1, wE1, wS1)]
+    if solver == 1:
+        lib().orc_disp_sor_llinsym4(*[_p(x) for x in a], a[0].shape[0], a[0].shape[1], max(int(it), 0), float(omega), order)
+        return a[1], a[9]
+    # GS_ALR_SOR_llinsym4_2d (disparitySolvers.c:503-540): per iteration the plain line solvers on field 0, then on field 1;
+    # the fields never read each other, so all iterations of one field first is the same computation
+    o0 = disp_alr_llin4(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], max(int(it), 0), omega, order)
+    o1 = disp_alr_llin4(a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], max(int(it), 0), omega, order)
+    return o0, o1
 
 
 def PDEsolver4(X, TRACE, B, wW, wN, wE, wS, it, omega, solver=1, order=LEX):

@@ -81,6 +81,14 @@ def disp4(seed, nrows, ncols, nan_frac=0.0):
     return dict(U=U, dU=dU, Cu=Cu, Du=Du, wW=wW, wN=wN, wE=wE, wS=wS)
 
 
+def dispsym4(seed, nrows, ncols, nan_frac=0.0):
+    """Inputs of Disp_sor_llin_sym4_2d: two independent disparity problems (left->right, right->left)."""
+    a, b = disp4(seed, nrows, ncols, nan_frac), disp4(seed + 500, nrows, ncols, nan_frac)
+    out = {k + "0": v for k, v in a.items()}
+    out.update({k + "1": v for k, v in b.items()})
+    return out
+
+
 def pde4(seed, nrows, ncols, nframes=1, nan_frac=0.0):
     rng = np.random.default_rng(seed)
     shape = (nrows, ncols) if nframes == 1 else (nrows, ncols, nframes)

@@ -145,6 +145,22 @@ def test_simoncelli_derivatives(pdeip, oracle, shape, F):
     check(pdeip.mex_api.SndDerivatives5(p["It0"], p["It1"]), oracle.SndDerivatives5(p["It0"], p["It1"]), "snd %s F=%d" % (shape, F))
 
 
+@pytest.mark.parametrize("mode,order", MODES)
+@pytest.mark.parametrize("shape", [(32, 48), (97, 131), (3, 3), (260, 7), (388, 584)])
+def test_disp_sor_llin_sym4(pdeip, oracle, mode, order, shape):
+    pdeip.mex_api.set_mode(mode)
+    for it, nan_frac, solver in ((1, 0.0, 1), (5, 0.04, 1), (0, 0.0, 1), (2, 0.03, 2)):
+        p = pb.dispsym4(61, *shape, nan_frac=nan_frac)
+        got = pdeip.mex_api.Disp_sor_llin_sym4_2d(*p.values(), np.float32(it), np.float32(1.7), np.float32(solver))
+        want = oracle.Disp_sor_llin_sym4_2d(*p.values(), it, 1.7, solver=solver, order=order)
+        check(got, want, "dispsym4 %s it=%d solver=%d mode=%d" % (shape, it, solver, mode))
+    # not the plain disparity solver: omega multiplies the finished quotient here
+    p = pb.dispsym4(62, *shape)
+    a = pdeip.mex_api.Disp_sor_llin_sym4_2d(*p.values(), np.float32(3), np.float32(1.7), np.float32(1))[0]
+    b = pdeip.mex_api.Disp_sor_llin4_2d(*list(p.values())[:8], np.float32(3), np.float32(1.7), np.float32(1))
+    assert np.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
 def test_solver_errors(pdeip):
     p = pb.elin4(91, 16, 16)
     with pytest.raises(pdeip.mex_api.MexError, match="no such solver"):

@@ -72,7 +72,7 @@ def call(lib, nlhs, args):
 
 def test_all_gateways_have_a_stub():
     assert STUBS == sorted(["Oflow_sor_elin4_2d", "Oflow_sor_llin4_2d", "Oflow_sor_llin8_2d", "Oflow_lhs_elin4_2d",
-                            "Oflow_lhs_llin4_2d", "Disp_sor_llin4_2d", "PDEsolver4", "PDEsolver8", "DdiffWeights",
+                            "Oflow_lhs_llin4_2d", "Disp_sor_llin4_2d", "Disp_sor_llin_sym4_2d", "PDEsolver4", "PDEsolver8", "DdiffWeights",
                             "BilinInterp_2d", "FstDerivatives5", "SndDerivatives5"])
 
 

@@ -24,6 +24,6 @@ def test_oracle_matches_golden(oracle, name):
 def test_fixture_inventory():
     have = set(m["gateway"] for m, _, _ in (gu.load(n) for n in gu.names()))
     want = {"Oflow_sor_elin4_2d", "Oflow_sor_llin4_2d", "Oflow_sor_llin8_2d", "Oflow_lhs_elin4_2d", "Oflow_lhs_llin4_2d",
-            "Disp_sor_llin4_2d", "PDEsolver4", "PDEsolver8", "DdiffWeights", "BilinInterp_2d", "FstDerivatives5",
+            "Disp_sor_llin4_2d", "Disp_sor_llin_sym4_2d", "PDEsolver4", "PDEsolver8", "DdiffWeights", "BilinInterp_2d", "FstDerivatives5",
             "SndDerivatives5"}
     assert want <= have, "gateways without a golden fixture: %s" % (want - have)
