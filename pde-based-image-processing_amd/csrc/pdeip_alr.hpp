@@ -419,45 +419,69 @@ struct AlrPde8 {
         }
     };
     static constexpr bool INTERIOR_LINES = true; // interior columns, then interior rows (pdeSolvers.c:1153, :1290)
-    static constexpr bool HAS_COEF4 = false;
-    template <bool vertical>
-    __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
+    static constexpr bool HAS_COEF4 = true;
+    // X on the two neighbouring lines: same element (P, N) and the elements before / after it (Pb, Pa, Nb, Na).
+    // On a column the previous line is the west column (P = W, Pb = NW, Pa = SW, N = E, Nb = NE, Na = SE); on a row
+    // it is the north row (P = N, Pb = NW, Pa = NE, N = S, Nb = SW, Na = SE).
+    struct In {
+        float wW, wNW, wN, wNE, wE, wSE, wS, wSW, xP, xPb, xPa, xN, xNb, xNa, T, B;
+    };
+    template <bool vertical> __device__ __forceinline__ static Tri math(const In &v, bool hasBefore, bool hasAfter)
     {
-        const size_t pos = AlrGeo<vertical>::pos(i, j, nrows, ncols);
-        const long dS = AlrGeo<vertical>::dS(nrows, ncols), dE = AlrGeo<vertical>::dE(nrows, ncols);
-        const bool hasN = i > 0, hasS = i < nrows - 1, hasW = j > 0, hasE = j < ncols - 1;
-        // clamped one-step offsets: every load below is unconditional
-        const long oN = hasN ? -dS : 0, oS = hasS ? dS : 0, oW = hasW ? -dE : 0, oE = hasE ? dE : 0;
-        const float *X = q.X + pos;
-        const float wW = q.wW[pos], wNW = q.wNW[pos], wN = q.wN[pos], wNE = q.wNE[pos];
-        const float wE = q.wE[pos], wSE = q.wSE[pos], wS = q.wS[pos], wSW = q.wSW[pos];
-        const float xSW = X[oS + oW], xSE = X[oS + oE], xNW = X[oN + oW], xNE = X[oN + oE];
         Tri t;
         float d;
         if (vertical) { // interior columns: W and E exist (:1171-1173, :1195-1197, :1227-1228)
-            d = wW * X[oW] + wE * X[oE];
-            if (hasS) d += wSW * xSW + wSE * xSE;
-            if (hasN) d += wNW * xNW + wNE * xNE;
-            t.a = hasN ? -wN : 0.0f;
-            t.c = hasS ? -wS : 0.0f;
+            d = v.wW * v.xP + v.wE * v.xN;
+            if (hasAfter) d += v.wSW * v.xPa + v.wSE * v.xNa;
+            if (hasBefore) d += v.wNW * v.xPb + v.wNE * v.xNb;
+            t.a = hasBefore ? -v.wN : 0.0f;
+            t.c = hasAfter ? -v.wS : 0.0f;
         } else { // interior rows: N and S exist (:1309-1310, :1335-1337, :1364-1365)
-            d = wS * X[oS] + wN * X[oN];
-            if (hasW) d += wSW * xSW + wNW * xNW;
-            if (hasE) d += wSE * xSE + wNE * xNE;
-            t.a = hasW ? -wW : 0.0f;
-            t.c = hasE ? -wE : 0.0f;
+            d = v.wS * v.xN + v.wN * v.xP;
+            if (hasBefore) d += v.wSW * v.xNb + v.wNW * v.xPb;
+            if (hasAfter) d += v.wSE * v.xNa + v.wNE * v.xPa;
+            t.a = hasBefore ? -v.wW : 0.0f;
+            t.c = hasAfter ? -v.wE : 0.0f;
         }
-        const float T = q.T[pos], Bv = q.B[pos];
-        if (!is_nan(T)) {
-            t.b = T;
-            d += Bv;
+        if (!is_nan(v.T)) {
+            t.b = v.T;
+            d += v.B;
         } else { // :1181-1182 as written: wNW twice, wNE never, all eight terms at every position
-            float b = wN + wS + wW + wE;
-            b += wNW + wNW + wSW + wSE;
+            float b = v.wN + v.wS + v.wW + v.wE;
+            b += v.wNW + v.wNW + v.wSW + v.wSE;
             t.b = b;
         }
         t.d = d;
         return t;
+    }
+    template <bool vertical> __device__ __forceinline__ static Tri coef(const Ctx &q, const AlrAt &at)
+    {
+        const size_t p = at.pos;
+        const long ob = at.hasBefore ? -1 : 0, oa = at.hasAfter ? 1 : 0; // clamped: every load is unconditional
+        const float *XP = q.X + at.prev(), *XN = q.X + at.next();
+        const In v{q.wW[p], q.wNW[p], q.wN[p], q.wNE[p], q.wE[p], q.wSE[p], q.wS[p], q.wSW[p],
+                   XP[0], XP[ob], XP[oa], XN[0], XN[ob], XN[oa], q.T[p], q.B[p]};
+        return math<vertical>(v, at.hasBefore, at.hasAfter);
+    }
+    template <bool vertical> __device__ __forceinline__ static void coef4(const Ctx &q, int l, int k, int n, int nlines, Tri (&out)[4])
+    {
+        const AlrAt at(l, k, n, nlines);
+        const size_t p = at.pos;
+        float wW[4], wNW[4], wN[4], wNE[4], wE[4], wSE[4], wS[4], wSW[4], xP[4], xN[4], T[4], B[4];
+        alr_ld4(q.wW + p, wW); alr_ld4(q.wNW + p, wNW); alr_ld4(q.wN + p, wN); alr_ld4(q.wNE + p, wNE);
+        alr_ld4(q.wE + p, wE); alr_ld4(q.wSE + p, wSE); alr_ld4(q.wS + p, wS); alr_ld4(q.wSW + p, wSW);
+        alr_ld4(q.X + at.prev(), xP); alr_ld4(q.X + at.next(), xN);
+        alr_ld4(q.T + p, T); alr_ld4(q.B + p, B);
+        const long ob = at.hasBefore ? -1 : 0, oa = k + 4 <= n - 1 ? 4 : 3; // element k-1 / k+4 (clamped; unused when clamped)
+        const float xPbefore = q.X[at.prev() + ob], xNbefore = q.X[at.next() + ob];
+        const float xPafter = q.X[at.prev() + oa], xNafter = q.X[at.next() + oa];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const In v{wW[e], wNW[e], wN[e], wNE[e], wE[e], wSE[e], wS[e], wSW[e],
+                       xP[e], e == 0 ? xPbefore : xP[e - 1], e == 3 ? xPafter : xP[e + 1],
+                       xN[e], e == 0 ? xNbefore : xN[e - 1], e == 3 ? xNafter : xN[e + 1], T[e], B[e]};
+            out[e] = math<vertical>(v, k + e > 0, k + e < n - 1);
+        }
     }
 };
 
