@@ -277,6 +277,38 @@ def main():
                                                                     np.abs(dev.to_matlab(gV).astype(np.float64) - wV).max()))
             level["workload"] = "FlowEminND_llin_2D_v10 firstLoop body, 1080x1920x3, secondLoop=4, iter=4, solver=1"
             out["flow_level"] = level
+            # ---- the solver call of each BASELINE config at its own frame size (sweeps/s, both orderings) ----------
+            gen = torch.Generator(device=device).manual_seed(7)
+
+            def planes(nr, nc, k, lo=0.5, hi=5.0):
+                return [torch.empty((nc, nr), device=device, dtype=torch.float32).uniform_(lo, hi, generator=gen) for _ in range(k)]
+
+            def rate(fn, it, reps=5):
+                fn(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return round(it * reps / (time.perf_counter() - t0), 1)
+
+            cfgs = {}
+            for mode, tag in ((capi.MODE_RED_BLACK, "red_black"), (capi.MODE_EXACT_ORDER, "exact_order")):
+                nr, nc = 388, 584      # C1 Horn-Schunck, iter = 20
+                a, b, c = planes(nr, nc, 3, -0.5, 0.5); w = planes(nr, nc, 4); Uc, Vc = planes(nr, nc, 2, -1, 1)
+                cfgs.setdefault("C1_elin4_388x584_iter20", {})[tag] = rate(lambda: dev.oflow_sor_elin4(Uc, Vc, a * b, -a * c, -b * c, a * a, b * b, *w, 20, OMEGA, mode), 20)
+                nr, nc = 1080, 1920    # C2 late linearisation, iter = 4
+                a, b, c = planes(nr, nc, 3, -0.5, 0.5); w = planes(nr, nc, 4); Uc, Vc = planes(nr, nc, 2, -1, 1); dUc, dVc = planes(nr, nc, 2, -0.1, 0.1)
+                cfgs.setdefault("C2_llin4_1080x1920_iter4", {})[tag] = rate(lambda: dev.oflow_sor_llin4(Uc, Vc, dUc, dVc, a * b, -a * c, -b * c, a * a, b * b, *w, 4, OMEGA, mode), 4)
+                nr, nc = 2160, 3840    # C3 TV denoising, 8 neighbours, inner_iter = 4
+                w8 = planes(nr, nc, 8); Xc, Bc = planes(nr, nc, 2, 0, 1); TR = 1 + sum(w8)
+                cfgs.setdefault("C3_pde8_2160x3840_iter4", {})[tag] = rate(lambda: dev.pde_sor8(Xc, TR, Bc, *w8, 4, 1.75, mode), 4, reps=3)
+                del w8, TR
+                nr, nc = 1988, 2880    # C5 disparity, iter = 4
+                w = planes(nr, nc, 4); Ud, = planes(nr, nc, 1, -3, 3); dUd, Cud = planes(nr, nc, 2, -0.5, 0.5); Dud, = planes(nr, nc, 1, 0.05, 2)
+                cfgs.setdefault("C5_disp4_1988x2880_iter4", {})[tag] = rate(lambda: dev.disp_sor_llin4(Ud, dUd, Cud, Dud, *w, 4, OMEGA, mode), 4)
+            cfgs["unit"] = "iterations/s"
+            cfgs["note"] = "C4 (elin4 2160x3840 iter=4) is the headline workload above"
+            out["configs"] = cfgs
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
