@@ -86,3 +86,14 @@ def test_alr_c1_size_exact_and_zebra(pdeip, oracle):
         got = pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(4), np.float32(1.9), TWO)
         check(got, oracle.Oflow_sor_elin4_2d(*p.values(), 4, 1.9, solver=2, order=order), "alr C1 mode=%d" % mode)
     pdeip.mex_api.set_mode(0)
+
+
+@pytest.mark.parametrize("mode,order", MODES)
+def test_alr_long_lines(pdeip, oracle, mode, order):
+    """Lines longer than 5120 pixels: the exact-order walker holds one chain at a time (two would not fit in LDS)."""
+    pdeip.mex_api.set_mode(mode)
+    for shape in ((5300, 6), (7, 5200)):
+        p = pb.elin4(551, *shape, nan_frac=0.01)
+        got = pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(2), np.float32(1.5), TWO)
+        check(got, oracle.Oflow_sor_elin4_2d(*p.values(), 2, 1.5, solver=2, order=order), "alr long lines %s mode=%d" % (shape, mode))
+    pdeip.mex_api.set_mode(0)
