@@ -614,28 +614,64 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
         P.cf[f] = cf[f];
         vec = vec && aligned16(cf[f]);
     }
-    const int TJ = pick_rb_tj(nrows, ncols);
-    const int ntiles_r = (nrows + RB_OWN_ROWS - 1) / RB_OWN_ROWS;
-    const int nunits = ntiles_r * ((ncols + TJ - 1) / TJ);
-    const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);
     const dim3 block(64 * RB_WAVES_PER_BLOCK);
+    static const bool fuse = env_int("PDEIP_RB_FUSE", 1) != 0; // two sweeps per launch (k_pde8_colour2), same results
+    const int TJ1 = pick_rb_tj(nrows, ncols);
+    int TJ2 = TJ1;
+    const int ntiles1 = (nrows + RB_OWN_ROWS - 1) / RB_OWN_ROWS, ntiles2 = (nrows + P8_OWN_ROWS2 - 1) / P8_OWN_ROWS2;
+    if (fuse && iter >= 2) {
+        static int slots = 0; // resident waves of the fused kernel (see pick_rb2_tj)
+        if (slots == 0) {
+            int blocks = 0, dev = 0;
+            hipDeviceProp_t prop;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_pde8_colour2<true, false>, 64 * RB_WAVES_PER_BLOCK, 0) != hipSuccess) blocks = 1;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+            slots = (blocks > 0 ? blocks : 1) * RB_WAVES_PER_BLOCK * prop.multiProcessorCount;
+        }
+        const int forced = g.rb_tj > 0 ? g.rb_tj : env_int("PDEIP_RB_TJ", 0);
+        if (forced > 0) TJ2 = forced < 2 ? 2 : forced;
+        else {
+            long best_cost = -1;
+            for (int tj = 4; tj <= 64; tj++) {
+                const long units = (long)ntiles2 * ((ncols + tj - 1) / tj) * nframes;
+                const long cost = ((units + slots - 1) / slots) * (tj + 6);
+                if (best_cost < 0 || cost <= best_cost) {
+                    best_cost = cost;
+                    TJ2 = tj;
+                }
+            }
+        }
+    }
     SweepTimer timer(s);
-    for (int it = 0; it < iter; it++) {
-        P.x_in = (it & 1) ? scratch : X;
-        P.x_out = (it & 1) ? X : scratch;
-        if (it == 0) {
-            if (vec) hipLaunchKernelGGL((k_pde8_colour<true, true>), grid, block, 0, s, P, bt, inv, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
-            else hipLaunchKernelGGL((k_pde8_colour<false, true>), grid, block, 0, s, P, bt, inv, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+    int nlaunch = 0, flips = 0;
+    for (int it = 0; it < iter;) {
+        const bool two = fuse && it + 2 <= iter, first = it == 0;
+        const int TJ = two ? TJ2 : TJ1, ntiles_r = two ? ntiles2 : ntiles1;
+        const int nunits = ntiles_r * ((ncols + TJ - 1) / TJ);
+        const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);
+        P.x_in = (flips & 1) ? scratch : X;
+        P.x_out = (flips & 1) ? X : scratch;
+        float *d0 = first ? bt : nullptr, *d1 = first ? inv : nullptr;
+#define PDEIP_P8_LAUNCH(KERNEL, V, F) hipLaunchKernelGGL((KERNEL<V, F>), grid, block, 0, s, P, d0, d1, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n)
+        if (two) {
+            if (vec) { if (first) PDEIP_P8_LAUNCH(k_pde8_colour2, true, true); else PDEIP_P8_LAUNCH(k_pde8_colour2, true, false); }
+            else     { if (first) PDEIP_P8_LAUNCH(k_pde8_colour2, false, true); else PDEIP_P8_LAUNCH(k_pde8_colour2, false, false); }
+        } else {
+            if (vec) { if (first) PDEIP_P8_LAUNCH(k_pde8_colour, true, true); else PDEIP_P8_LAUNCH(k_pde8_colour, true, false); }
+            else     { if (first) PDEIP_P8_LAUNCH(k_pde8_colour, false, true); else PDEIP_P8_LAUNCH(k_pde8_colour, false, false); }
+        }
+#undef PDEIP_P8_LAUNCH
+        if (first) { // sweep 0 built B_temp / INV_TRACE
             P.cf[ModelPde8::cB] = bt;
             P.cf[ModelPde8::cInv] = inv;
-        } else if (vec)
-            hipLaunchKernelGGL((k_pde8_colour<true, false>), grid, block, 0, s, P, nullptr, nullptr, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
-        else
-            hipLaunchKernelGGL((k_pde8_colour<false, false>), grid, block, 0, s, P, nullptr, nullptr, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n);
+        }
+        it += two ? 2 : 1;
+        flips++;
+        nlaunch++;
         g.last_launches++;
     }
-    timer.stop(iter);
-    if (iter & 1) HIPCHK(hipMemcpyAsync(X, scratch, nf * sizeof(float), hipMemcpyDeviceToDevice, s));
+    timer.stop(nlaunch);
+    if (flips & 1) HIPCHK(hipMemcpyAsync(X, scratch, nf * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

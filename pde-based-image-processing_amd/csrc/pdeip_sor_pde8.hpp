@@ -197,6 +197,176 @@ k_pde8_colour(Pde8SweepPlanes P, float *dout0, float *dout1, int nrows, int ncol
     }
 }
 
+// Two four-colour sweeps per launch: the four-stage pipeline of rb_march2 (pdeip_sor_rb.hpp) with the 9-point
+// phases.  A column of even class is relaxed in stages 1 and 3 (colours 0,1 of sweeps 1 and 2), a column of odd
+// class in stages 2 and 4 (colours 2,3); the other stages pass it through.  One 9-point sweep uses up four halo
+// rows, so this kernel has two halo lanes per side (240 owned rows per wave).  The border replicate between
+// the sweeps (pdeSolvers.c:249-262) is reproduced as in rb_march2.  Bit-identical to two launches of k_pde8_colour.
+constexpr int P8_OWN_ROWS2 = 240; // 60 storing lanes x 4 rows
+
+__device__ __forceinline__ void p8_replicate_rows(float (&F)[4], int r, int nrows, bool vec)
+{
+    const float prev3 = vec ? 0.0f : lane_above(F[3]);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int i = r + e;
+        if (i == 0) F[e] = F[e == 3 ? 3 : e + 1];
+        if (i == nrows - 1) F[e] = (e == 0) ? prev3 : F[e == 0 ? 0 : e - 1];
+    }
+}
+
+template <bool VEC, bool FIRST>
+__global__ void __launch_bounds__(64 * RB_WAVES_PER_BLOCK)
+k_pde8_colour2(Pde8SweepPlanes P, float *dout0, float *dout1, int nrows, int ncols, int TJ, int ntiles_r,
+               int nunits, float omega, int col0, size_t frame_stride)
+{
+    constexpr int NCF = ModelPde8::NCF;
+    const int lane = threadIdx.x & 63;
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, per = nb >> 3; // XCD-aware unit order (speed only)
+        if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
+    }
+    const int unit = bid * RB_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (unit >= nunits) return;
+    const size_t fo = (size_t)blockIdx.y * frame_stride;
+    P.x_in += fo;
+    P.x_out += fo;
+#pragma unroll
+    for (int f = 0; f < NCF; f++) P.cf[f] += fo;
+    if (FIRST) {
+        dout0 += fo;
+        dout1 += fo;
+    }
+    const int nstrips = nunits / ntiles_r;
+    const int a = unit / nstrips, b = unit % nstrips;
+    const int r = a * P8_OWN_ROWS2 - 8 + 4 * lane;
+    const int j0 = b * TJ, j1 = (j0 + TJ < ncols) ? j0 + TJ : ncols;
+    const float om1 = 1.0f - omega;
+    const bool store_lane = (lane >= 2) && (lane <= 61);
+
+    // windows relative to the column c of stage 1: O old at c-1,c,c+1; A after stage 1 at c-2,c-1; B after
+    // sweep 1 at c-3,c-2; C after stage 3 at c-4,c-3; K coefficients at c..c-3
+    float Om[4], Oc[4], Op[4], A2[4], A1[4], B3[4], B2[4], C4[4], C3[4];
+    float K0[NCF][4], K1[NCF][4], K2[NCF][4], K3[NCF][4];
+    int c = j0 - 3;
+    rb_load4<VEC>(Om, P.x_in, c - 1, r, nrows, ncols);
+    rb_load4<VEC>(Oc, P.x_in, c, r, nrows, ncols);
+    rb_load4<VEC>(Op, P.x_in, c + 1, r, nrows, ncols);
+#pragma unroll
+    for (int e = 0; e < 4; e++) A2[e] = A1[e] = B3[e] = B2[e] = C4[e] = C3[e] = 0.0f;
+#pragma unroll
+    for (int f = 0; f < NCF; f++) {
+        rb_load4<VEC>(K0[f], P.cf[f], c, r, nrows, ncols);
+#pragma unroll
+        for (int e = 0; e < 4; e++) K1[f][e] = K2[f][e] = K3[f][e] = 0.0f;
+    }
+    auto inner = [&](int col) { return col >= 1 && col <= ncols - 2; };
+    for (; c <= j1 + 2; c++) {
+        float On[4], Kn[NCF][4];
+        rb_load4<VEC>(On, P.x_in, c + 2, r, nrows, ncols);
+#pragma unroll
+        for (int f = 0; f < NCF; f++) rb_load4<VEC>(Kn[f], P.cf[f], c + 1, r, nrows, ncols);
+
+        if (FIRST) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float k[NCF];
+#pragma unroll
+                for (int f = 0; f < NCF; f++) k[f] = K0[f][e];
+                p8_derive(k);
+                K0[ModelPde8::cB][e] = k[ModelPde8::cB];
+                K0[ModelPde8::cInv][e] = k[ModelPde8::cInv];
+            }
+            if (store_lane && c >= j0 && c < j1) {
+                rb_store4<VEC>(K0[ModelPde8::cB], dout0, c, r, nrows);
+                rb_store4<VEC>(K0[ModelPde8::cInv], dout1, c, r, nrows);
+            }
+        }
+        const bool c_even = ((c + col0) & 1) == 0; // class of columns c and c-2; c-1 and c-3 are of the other class
+        const int c1 = c - 1, c2 = c - 2, c3 = c - 3;
+
+        // stage 1: colours 0,1 of sweep 1 on column c (even class), from the old columns on both sides
+        float A0[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) A0[e] = Oc[e];
+        if (c_even && inner(c)) {
+            p8_phase<0>(A0, Om, Op, K0, r, nrows, omega, om1);
+            p8_phase<1>(A0, Om, Op, K0, r, nrows, omega, om1);
+        }
+        // stage 2: colours 2,3 of sweep 1 on column c-1 (odd class), from the finished even columns; then it is
+        // "column c-1 after sweep 1" whatever its class: replicate its border rows (pdeSolvers.c:249-255)
+        float B1[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) B1[e] = A1[e];
+        if (inner(c1)) {
+            if (c_even) {
+                p8_phase<0>(B1, A2, A0, K1, r, nrows, omega, om1);
+                p8_phase<1>(B1, A2, A0, K1, r, nrows, omega, om1);
+            }
+            p8_replicate_rows(B1, r, nrows, VEC);
+        }
+        // stage 3: colours 0,1 of sweep 2 on column c-2 (even class); a border column is the replicate of its
+        // inner neighbour after sweep 1 (:256-262), i.e. B(c-2) itself
+        float C2[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) C2[e] = B2[e];
+        if (c_even && inner(c2)) {
+            float Pv[4], Nx[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                Pv[e] = inner(c2 - 1) ? B3[e] : B2[e];
+                Nx[e] = inner(c2 + 1) ? B1[e] : B2[e];
+            }
+            p8_phase<0>(C2, Pv, Nx, K2, r, nrows, omega, om1);
+            p8_phase<1>(C2, Pv, Nx, K2, r, nrows, omega, om1);
+        }
+        // stage 4: colours 2,3 of sweep 2 on column c-3 (odd class); store column c-3
+        if (c3 >= j0 && c3 < j1 && inner(c3)) {
+            float F[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) F[e] = C3[e];
+            if (c_even) {
+                float Pv[4], Nx[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    Pv[e] = inner(c3 - 1) ? C4[e] : B3[e];
+                    Nx[e] = inner(c3 + 1) ? C2[e] : B3[e];
+                }
+                p8_phase<0>(F, Pv, Nx, K3, r, nrows, omega, om1);
+                p8_phase<1>(F, Pv, Nx, K3, r, nrows, omega, om1);
+            }
+            p8_replicate_rows(F, r, nrows, VEC);
+            if (store_lane) {
+                rb_store4<VEC>(F, P.x_out, c3, r, nrows);
+                if (c3 == 1) rb_store4<VEC>(F, P.x_out, 0, r, nrows);
+                if (c3 == ncols - 2) rb_store4<VEC>(F, P.x_out, ncols - 1, r, nrows);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            C4[e] = C3[e];
+            C3[e] = C2[e];
+            B3[e] = B2[e];
+            B2[e] = B1[e];
+            A2[e] = A1[e];
+            A1[e] = A0[e];
+            Om[e] = Oc[e];
+            Oc[e] = Op[e];
+            Op[e] = On[e];
+        }
+#pragma unroll
+        for (int f = 0; f < NCF; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                K3[f][e] = K2[f][e];
+                K2[f][e] = K1[f][e];
+                K1[f][e] = K0[f][e];
+                K0[f][e] = Kn[f][e];
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // exact (lexicographic) ordering
 // ---------------------------------------------------------------------------------------------
