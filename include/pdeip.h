@@ -303,6 +303,13 @@ int pdeip_add_dev(void *stream, const float *A, const float *B, int nrows, int n
 /* [wW wN wS wE] = OPdiffWeights(U+dU, V+dV) (:389-433), evaluated in double, returned as single */
 int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, const float *dU, const float *dV, int nrows,
                                  int ncols, float *wW, float *wN, float *wS, float *wE);
+/* TVdenoise8's work between two PDEsolver8 calls (matlab/denoising/TVdenoise8.m:80-86 with ADdiffWeights :119-231):
+ * the anisotropic weights of Iout (double; Alvarez derivative, strongest frame per pixel, lambda = median of the
+ * non-zero squared gradient norms), then TRACE = PsiData + alpha*sum(w), B = PsiData.*Iin with
+ * PsiData = 1./sqrt((Iout-Iin).^2 + eps), and single(alpha*w) for the eight weights; all [nrows x ncols x nframes]. */
+int pdeip_tv_assemble_dev(void *stream, const float *Iout, const float *Iin, int nrows, int ncols, int nframes,
+                          float alpha, float *TRACE, float *B, float *aW, float *aNW, float *aN, float *aNE,
+                          float *aE, float *aSE, float *aS, float *aSW);
 /* out = medfilt2(A + B, [3 3], 'symmetric') (:352); B may be NULL (out = medfilt2(A)); out must not alias A or B */
 int pdeip_median3_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out);
 

@@ -154,3 +154,81 @@ def disp_level(orc, I1t0, I1t1, U, param, I2t0=None, I2t1=None):
                                        order=param["order"])
         U = median3_sum(U, dU)
     return U
+
+
+# ---- TV denoising: matlab/denoising/TVdenoise8.m ---------------------------------------------------------------------
+
+def _pad_edge(A):
+    return np.pad(A, 1, mode="edge")
+
+
+def ad_diff_weights(D):
+    """[W NW N NE E SE S SW] = ADdiffWeights(D) (TVdenoise8.m:119-231), double; D is [nrows, ncols(, F)] single."""
+    D = D.astype(np.float64)
+    if D.ndim == 2:
+        D = D[:, :, None]
+    nrows, ncols, F = D.shape
+    s = 4.0 + np.sqrt(8.0)
+    k1, k2 = 1.0 / s, np.sqrt(2.0) / s
+    gxs, gys = [], []
+    for f in range(F):
+        P = _pad_edge(D[:, :, f])
+        at = lambda di, dj: P[1 + di:1 + di + nrows, 1 + dj:1 + dj + ncols]
+        dx = k1 * at(1, 1)
+        dx = dx + (-k1) * at(1, -1)
+        dx = dx + k2 * at(0, 1)
+        dx = dx + (-k2) * at(0, -1)
+        dx = dx + k1 * at(-1, 1)
+        dx = dx + (-k1) * at(-1, -1)
+        dy = k1 * at(1, 1)
+        dy = dy + k2 * at(1, 0)
+        dy = dy + k1 * at(1, -1)
+        dy = dy + (-k1) * at(-1, 1)
+        dy = dy + (-k2) * at(-1, 0)
+        dy = dy + (-k1) * at(-1, -1)
+        gxs.append(dx); gys.append(dy)
+    gx, gy = np.stack(gxs, 2), np.stack(gys, 2)
+    nn = gx * gx + gy * gy
+    best = np.argmax(nn, axis=2)                       # first maximal frame, like MATLAB's max
+    ii, jj = np.meshgrid(np.arange(nrows), np.arange(ncols), indexing="ij")
+    mx, my = gx[ii, jj, best], gy[ii, jj, best]
+    norm = mx * mx + my * my
+    srt = np.sort(norm.ravel())
+    srt = srt[srt != 0]
+    lam = srt[(srt.size + 1) // 2 - 1] if srt.size else 1.0   # sorted(round(numel*0.5 + eps))
+    multip = 1.0 / (norm + 2.0 * lam)
+    dyy, dxx, dxy = multip * (my * my + lam), multip * (mx * mx + lam), -multip * (mx * my)
+    sh = lambda A, di, dj: np.roll(np.roll(A, di, axis=0), dj, axis=1)
+    W = 0.5 * (dyy + sh(dyy, 0, 1)); W[:, 0] = 0
+    NW = 0.25 * (dxy + sh(dxy, 1, 1)); NW[:, 0] = 0; NW[0, :] = 0
+    N = 0.5 * (dxx + sh(dxx, 1, 0)); N[0, :] = 0
+    NE = -0.25 * (dxy + sh(dxy, 1, -1)); NE[:, -1] = 0; NE[0, :] = 0
+    E = 0.5 * (dyy + sh(dyy, 0, -1)); E[:, -1] = 0
+    SE = 0.25 * (dxy + sh(dxy, -1, -1)); SE[:, -1] = 0; SE[-1, :] = 0
+    S = 0.5 * (dxx + sh(dxx, -1, 0)); S[-1, :] = 0
+    SW = -0.25 * (dxy + sh(dxy, -1, 1)); SW[-1, :] = 0; SW[:, 0] = 0
+    return [W, NW, N, NE, E, SE, S, SW], lam
+
+
+def tv_assemble(Iout, Iin, alpha):
+    """TRACE, B and single(alpha*w) of one outer iteration (TVdenoise8.m:82-86); arrays [nrows, ncols(, F)] single."""
+    w, _ = ad_diff_weights(Iout)
+    shape3 = Iout.shape if Iout.ndim == 3 else Iout.shape + (1,)
+    tot = w[0] + w[1]
+    for k in range(2, 8):
+        tot = tot + w[k]
+    diff = (Iout.astype(F32) - Iin.astype(F32)).reshape(shape3)
+    psi = F32(1.0) / np.sqrt(diff * diff + F32(2.220446049250313e-16))
+    TRACE = (psi + (alpha * tot).astype(F32)[:, :, None]).astype(F32)
+    B = (psi * Iin.astype(F32).reshape(shape3)).astype(F32)
+    ws = [np.repeat((alpha * a).astype(F32)[:, :, None], shape3[2], axis=2).reshape(Iout.shape) for a in w]
+    return TRACE.reshape(Iout.shape), B.reshape(Iout.shape), ws
+
+
+def tv_level(orc, Iin, Iout, param):
+    """The lagged-diffusivity loop of one scale (TVdenoise8.m:78-100)."""
+    X = Iout.astype(F32)
+    for _ in range(param["outer_iter"] + 1):
+        TRACE, B, w = tv_assemble(X, Iin, param["alpha"])
+        X = orc.PDEsolver8(X, TRACE, B, *w, param["inner_iter"], param["omega"], solver=param["solver"], order=param["order"])
+    return X

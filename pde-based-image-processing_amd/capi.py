@@ -69,6 +69,7 @@ SIGNATURES = {
     "pdeip_disp_assemble_dev": [_P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _F, _I, _I, _P, _P],
     "pdeip_add_dev": [_P, _P, _P, _I, _I, _P],
     "pdeip_flow_opdiffweights_dev": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "pdeip_tv_assemble_dev": [_P, _P, _P, _I, _I, _I, _F] + [_P] * 10,
     "pdeip_median3_dev": [_P, _P, _P, _I, _I, _P],
     "pdeip_oflow_res_elin4_dev": _sig(1 + 13, [_I, _I, _I]),
     "pdeip_oflow_lhs_elin4_dev": _sig(1 + 11, [_I, _I, _I]),

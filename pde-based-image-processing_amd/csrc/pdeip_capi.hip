@@ -12,8 +12,11 @@
 #include <cstring>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>
+
 #include "pdeip_alr.hpp"
 #include "pdeip_flow.hpp"
+#include "pdeip_tv.hpp"
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
 #include "pdeip_sor_exact.hpp"
@@ -27,7 +30,7 @@ using namespace pdeip;
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_CTL, WS_ORDER, WS_ALR, WS_ALR_T, WS_NSLOT };
+enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_CTL, WS_ORDER, WS_ALR, WS_ALR_T, WS_TV, WS_NSLOT };
 
 struct Context {
     int device = 0;
@@ -1135,6 +1138,33 @@ extern "C" int pdeip_median3_dev(void *stream, const float *A, const float *B, i
     RC(check_dims("pdeip_median3_dev", nrows, ncols, 1));
     if (out == A || out == B) return set_err(PDEIP_ERR_ARG, "pdeip_median3_dev: output must not alias an input");
     hipLaunchKernelGGL(k_median3_sum, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), out, A, B, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+// One lagged-diffusivity iteration's MATLAB-side work of TVdenoise8 (pdeip_tv.hpp): ADdiffWeights(Iout) incl. the
+// quantile lambda, PsiData, TRACE, B and the alpha-scaled weights, ready for pdeip_pde_sor8_dev / pdeip_pde_alr8_dev.
+extern "C" int pdeip_tv_assemble_dev(void *stream, const float *Iout, const float *Iin, int nrows, int ncols, int nframes,
+                                     float alpha, float *TRACE, float *B, float *aW, float *aNW, float *aN, float *aNE,
+                                     float *aE, float *aSE, float *aS, float *aSW)
+{
+    const char *who = "pdeip_tv_assemble_dev";
+    RC(check_dims(who, nrows, ncols, nframes));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = (size_t)nrows * ncols;
+    size_t temp_bytes = 0;
+    double *nul = nullptr;
+    HIPCHK(rocprim::radix_sort_keys(nullptr, temp_bytes, nul, nul, n, 0, 64, s));
+    const size_t doubles = 4 * n + 2 + (temp_bytes + 7) / 8; // gx, gy, norm, sorted, lambda, sort workspace
+    float *basef;
+    RC(ws_get(WS_TV, doubles * sizeof(double), &basef));
+    double *gx = reinterpret_cast<double *>(basef), *gy = gx + n, *nrm = gy + n, *sorted = nrm + n, *lambda = sorted + n;
+    void *temp = lambda + 2;
+    hipLaunchKernelGGL(k_tv_gradient, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, gx, gy, nrm, Iout, nrows, ncols, nframes);
+    HIPCHK(rocprim::radix_sort_keys(temp, temp_bytes, nrm, sorted, n, 0, 64, s));
+    hipLaunchKernelGGL(k_tv_lambda, dim3(1), dim3(64), 0, s, lambda, sorted, n);
+    hipLaunchKernelGGL(k_tv_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, TRACE, B, aW, aNW, aN, aNE, aE, aSE, aS, aSW, gx, gy,
+                       nrm, lambda, Iout, Iin, alpha, nrows, ncols, nframes);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

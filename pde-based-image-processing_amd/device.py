@@ -228,3 +228,10 @@ def add(A, B, out):
     _chk(A, B, out)
     nrows, ncols, _ = _dims(A)
     capi.call("pdeip_add_dev", _stream(), *_p(A, B), nrows, ncols, out.data_ptr())
+
+
+def tv_assemble(Iout, Iin, alpha, TRACE, B, w8):
+    """TVdenoise8.m:80-86: ADdiffWeights(Iout), PsiData, TRACE, B; w8 = [aW, aNW, aN, aNE, aE, aSE, aS, aSW] (alpha-scaled)."""
+    _chk(Iout, Iin, TRACE, B, *w8)
+    nrows, ncols, F = _dims(Iout)
+    capi.call("pdeip_tv_assemble_dev", _stream(), *_p(Iout, Iin), nrows, ncols, F, float(alpha), *_p(TRACE, B, *w8))

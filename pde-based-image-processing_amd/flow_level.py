@@ -91,3 +91,23 @@ class DispLlinLevel:
             dev.median3(U, dU, Un)
             U, Un = Un, U
         return U
+
+
+class TvLevel:
+    """One scale of the TV denoiser: the lagged-diffusivity loop of matlab/denoising/TVdenoise8.m:78-100
+    (outer_iter + 1 times: ADdiffWeights, PsiData/TRACE/B, PDEsolver8) on device planes [F, ncols, nrows] or [ncols, nrows].
+    param: alpha, omega, outer_iter, inner_iter, solver (1 point SOR, 2 line relaxation)."""
+
+    def __init__(self, param, mode=capi.MODE_EXACT_ORDER):
+        self.p, self.mode = dict(param), mode
+
+    def run(self, Iin, Iout):
+        p = self.p
+        X = Iout.clone()
+        TRACE, B = torch.empty_like(X), torch.empty_like(X)
+        w8 = [torch.empty_like(X) for _ in range(8)]  # aW, aNW, aN, aNE, aE, aSE, aS, aSW
+        solve = dev.pde_sor8 if int(p["solver"]) == 1 else dev.pde_alr8
+        for _ in range(int(p["outer_iter"]) + 1):      # for iter=0:param.outer_iter
+            dev.tv_assemble(X, Iin, p["alpha"], TRACE, B, w8)
+            solve(X, TRACE, B, *w8, int(p["inner_iter"]), float(p["omega"]), self.mode)
+        return X

@@ -121,3 +121,37 @@ def test_resident_disparity_level(pdeip, oracle, solver, mode, order):
     got = sub("flow_level").DispLlinLevel(dict(param, firstLoop=1), mode=mode).run(
         dev.to_device(I0), dev.to_device(I1), dev.to_device(U0), dev.to_device(I0[:, :, :1]), dev.to_device(I1[:, :, :1]))
     same(dev.to_matlab(got), want, "two-term disparity level")
+
+
+@pytest.mark.parametrize("shape,F", [((37, 53), 1), ((64, 80), 3), ((9, 120), 2)])
+def test_tv_assembly(pdeip, shape, F):
+    """ADdiffWeights (incl. the quantile lambda), PsiData, TRACE, B against the numpy statement, bit for bit."""
+    import torch
+    ms, dev = matlab_side(), sub("device")
+    rng = np.random.default_rng(shape[0] + F)
+    shp = shape if F == 1 else shape + (F,)
+    Iin = np.asfortranarray(rng.uniform(0, 1, shp).astype(np.float32))
+    Iout = np.asfortranarray((Iin + rng.normal(0, 0.05, shp)).astype(np.float32))
+    Iout[2:5, 3:9] = Iout[2, 3] if F == 1 else Iout[2, 3, 0]       # a flat patch: zero gradients are left out of the median
+    d_in, d_out = dev.to_device(Iin), dev.to_device(Iout)
+    TRACE, B = torch.empty_like(d_out), torch.empty_like(d_out)
+    w8 = [torch.empty_like(d_out) for _ in range(8)]
+    dev.tv_assemble(d_out, d_in, 500.0, TRACE, B, w8)
+    wT, wB, ww = ms.tv_assemble(Iout, Iin, 500.0)
+    same(dev.to_matlab(TRACE), wT, "TRACE"); same(dev.to_matlab(B), wB, "B")
+    for k, (g, w) in enumerate(zip(w8, ww)):
+        same(dev.to_matlab(g), w, "alpha*w %d" % k)
+
+
+@pytest.mark.parametrize("solver,mode,order", [(1, 0, 0), (1, 1, 1), (2, 0, 0), (2, 1, 1)])
+def test_resident_tv_level(pdeip, oracle, solver, mode, order):
+    ms, dev = matlab_side(), sub("device")
+    rng = np.random.default_rng(21)
+    jj, ii = np.meshgrid(np.arange(72), np.arange(56))
+    clean = (0.5 + 0.4 * np.sin(0.2 * ii) * np.cos(0.15 * jj) + 0.3 * (ii > 28)).astype(np.float32)
+    noisy = np.asfortranarray(np.clip(clean + rng.normal(0, 0.1, clean.shape), 0, 1).astype(np.float32))
+    param = dict(alpha=500.0, omega=1.75, outer_iter=3, inner_iter=4, solver=solver, order=order)
+    want = ms.tv_level(oracle, noisy, noisy, param)
+    got = sub("flow_level").TvLevel(param, mode=mode).run(dev.to_device(noisy), dev.to_device(noisy))
+    same(dev.to_matlab(got), want, "TV level (solver %d mode %d)" % (solver, mode))
+    assert np.isfinite(want).all()

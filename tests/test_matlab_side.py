@@ -59,3 +59,38 @@ def test_coords_are_one_based():
     U = np.zeros((3, 4), dtype=np.float32)
     X, Y = ms.flow_coords(U, U)
     assert X[0, 0] == 1 and X[0, 3] == 4 and Y[2, 0] == 3 and X.dtype == np.float32
+
+
+def test_anisotropic_weights_known_cases():
+    # zero image: no gradient anywhere -> lambda = 1, tensor = 0.5*I: axis weights 0.5 inside, diagonals 0, outer rows/columns zeroed
+    w, lam = ms.ad_diff_weights(np.zeros((9, 11), dtype=np.float32))
+    W, NW, N, NE, E, SE, S, SW = w
+    assert lam == 1.0
+    assert np.allclose(W[:, 1:], 0.5) and np.all(W[:, 0] == 0) and np.allclose(E[:, :-1], 0.5) and np.all(E[:, -1] == 0)
+    assert np.allclose(N[1:, :], 0.5) and np.all(N[0, :] == 0) and np.allclose(S[:-1, :], 0.5) and np.all(S[-1, :] == 0)
+    assert not NW.any() and not NE.any() and not SE.any() and not SW.any()
+    # ramp along the columns with slope a: Ddx = 2a (Alvarez operator has unit gain on a ramp: (2 + sqrt2)*2a/(4+sqrt8)), Ddy = 0
+    a = 0.125
+    jj, ii = np.meshgrid(np.arange(16), np.arange(12))
+    w, lam = ms.ad_diff_weights((a * jj).astype(np.float32))
+    W, NW, N, NE, E, SE, S, SW = w
+    g2 = (2 * a * (2 + np.sqrt(2)) / (4 + np.sqrt(8))) ** 2
+    assert np.isclose(lam, g2)                                    # every interior pixel has the same norm: the median
+    dyy, dxx = lam / (g2 + 2 * lam), (g2 + lam) / (g2 + 2 * lam)  # smoothing across the gradient is damped (W/E), along it is not (N/S)
+    assert np.allclose(W[3:-3, 3:-3], dyy) and np.allclose(N[3:-3, 3:-3], dxx) and dyy < dxx
+    # strongest frame wins
+    two = np.stack([(a * jj).astype(np.float32), (3 * a * ii).astype(np.float32)], axis=2)
+    w2, _ = ms.ad_diff_weights(two)
+    w1, _ = ms.ad_diff_weights((3 * a * ii).astype(np.float32))
+    assert np.allclose(w2[0][3:-3, 3:-3], w1[0][3:-3, 3:-3])
+
+
+def test_tv_assembly_shapes_and_trace():
+    rng = np.random.default_rng(5)
+    Iin = rng.uniform(0, 1, (10, 12, 2)).astype(np.float32)
+    Iout = (Iin + 0.01).astype(np.float32)
+    TRACE, B, w = ms.tv_assemble(Iout, Iin, 2.0)
+    assert TRACE.shape == Iin.shape and len(w) == 8 and w[0].shape == Iin.shape and TRACE.dtype == np.float32
+    psi = 1.0 / np.sqrt((Iout.astype(np.float64) - Iin) ** 2 + 2.220446049250313e-16)
+    assert np.allclose(B, psi * Iin, rtol=1e-5) and np.allclose(TRACE, psi + sum(w), rtol=1e-5)
+    assert np.array_equal(w[2][:, :, 0], w[2][:, :, 1])          # repmat over frames
