@@ -277,6 +277,20 @@ def main():
                                                                     np.abs(dev.to_matlab(gV).astype(np.float64) - wV).max()))
             level["workload"] = "FlowEminND_llin_2D_v10 firstLoop body, 1080x1920x3, secondLoop=4, iter=4, solver=1"
             out["flow_level"] = level
+            # ---- the lagged-diffusivity loop of the TV denoiser resident in HBM (BASELINE config C3: 2160x3840 gray) ----
+            tvp = dict(alpha=500.0, omega=1.75, outer_iter=20, inner_iter=4, solver=1)
+            gI = torch.empty((NCOLS, NROWS), device=device, dtype=torch.float32).uniform_(0, 1)
+            tv = {"workload": "TVdenoise8 loop, 2160x3840, outer_iter=20 (21 x [ADdiffWeights+quantile, PsiData/TRACE/B, PDEsolver8 inner_iter=4])"}
+            for name, mode in (("exact_order", capi.MODE_EXACT_ORDER), ("red_black", capi.MODE_RED_BLACK)):
+                lv = fl.TvLevel(tvp, mode=mode)
+                lv.run(gI, gI)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                lv.run(gI, gI)
+                torch.cuda.synchronize()
+                tv[name + "_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+            out["tv_level"] = tv
+            del gI
             # ---- the solver call of each BASELINE config at its own frame size (sweeps/s, both orderings) ----------
             gen = torch.Generator(device=device).manual_seed(7)
 
