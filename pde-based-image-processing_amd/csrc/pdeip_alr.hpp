@@ -32,12 +32,7 @@ struct Tri {
 // j*nrows + i: a column is contiguous).  The row pass works on TRANSPOSED copies (element (i,j) at
 // i*ncols + j: a row is contiguous) that the host keeps in step -- a line is then contiguous in both
 // passes, and the strided walk along image rows (one cache line and one address translation per pixel
-// and plane) never happens.
-template <bool vertical> struct AlrGeo {
-    __device__ __forceinline__ static size_t pos(int i, int j, int nrows, int ncols) { return vertical ? (size_t)j * nrows + i : (size_t)i * ncols + j; }
-    __device__ __forceinline__ static long dS(int nrows, int ncols) { return vertical ? 1 : ncols; }  // to the south neighbour
-    __device__ __forceinline__ static long dE(int nrows, int ncols) { return vertical ? nrows : 1; }  // to the east neighbour
-};
+// and plane) never happens.  AlrAt (below) is the only place that knows where a pixel sits.
 
 // out[f][a][b] = in[f][b][a]: `in` is [F][nb][na] with a fastest; 32x32 tiles through LDS, coalesced both ways.
 __global__ void __launch_bounds__(256) k_alr_transpose(float *__restrict__ out, const float *__restrict__ in, int na, int nb)
@@ -101,7 +96,6 @@ struct AlrElin4 {
         __device__ void shift(size_t) {}
     };
     static constexpr bool INTERIOR_LINES = false;
-    static constexpr bool HAS_COEF4 = true;
     struct In { // x1, x2: the two off-line neighbours of X in the order they enter d: W,E on a column; S,N on a row
         float wN, wS, wE, wW, x1, x2, C, D, M, O;
     };
@@ -171,7 +165,6 @@ template <bool COUPLED> struct AlrLlin4T {
         __device__ void shift(size_t) {}
     };
     static constexpr bool INTERIOR_LINES = false;
-    static constexpr bool HAS_COEF4 = true;
     struct In { // d1, d2: the increments of the two off-line neighbours: W,E on a column; S,N on a row
         float wN, wS, wE, wW, Uc, Uw, Ue, Us, Un, d1, d2, C, D, M, O;
     };
@@ -297,46 +290,150 @@ struct AlrLlin8 {
         __device__ void shift(size_t) {}
     };
     static constexpr bool INTERIOR_LINES = false;
-    static constexpr bool HAS_COEF4 = false;
     __device__ __forceinline__ static int third(int k, int n) { return k == 0 ? 0 : (k == n - 1 ? 2 : 1); }
-    template <bool vertical>
-    __device__ __forceinline__ static Tri coef(const Ctx &q, int i, int j, int nrows, int ncols)
+    // everything one pixel needs, by direction (DN..DSE): weight, base-flow difference U_nb - U_c, increment of the neighbour
+    struct In {
+        float w[8], g[8], dx[8], C, D, M, O;
+    };
+    __device__ __forceinline__ static float pick8(const float (&a)[8], int k) // a[k] without indexing registers dynamically
     {
-        const size_t pos = AlrGeo<vertical>::pos(i, j, nrows, ncols);
-        const long dS = AlrGeo<vertical>::dS(nrows, ncols), dE = AlrGeo<vertical>::dE(nrows, ncols);
-        const long off[8] = {-dS, dS, dE, -dE, -dE - dS, dE - dS, -dE + dS, dE + dS}; // N,S,E,W,NW,NE,SW,SE
-        const signed char(*cs)[9] = vertical ? ALR_L8[0][third(j, ncols)][third(i, nrows)] : ALR_L8[1][third(i, nrows)][third(j, ncols)];
-        const float Uc = q.U[pos];
-        float b = 0.0f, d = 0.0f;
-        for (int k = 0; cs[0][k] != DEND; ++k) {
-            const float w = q.w[cs[0][k]][pos];
-            b = k ? b + w : w;
-        }
-        for (int k = 0; cs[1][k] != DEND; ++k) {
-            const int dir = cs[1][k];
-            const size_t nb = pos + off[dir];
-            const bool on_line = vertical ? (dir == DN || dir == DS) : (dir == DW || dir == DE);
-            const float w = q.w[dir][pos];
-            const float term = on_line ? w * (q.U[nb] - Uc) : w * (q.U[nb] - Uc + q.X[nb]);
-            d = k ? d + term : term;
+        float r = a[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) r = (k == q) ? a[q] : r;
+        return r;
+    }
+    template <bool vertical>
+    __device__ __forceinline__ static Tri math(const In &v, int line_third, int elem_third, bool hasBefore, bool hasAfter)
+    {
+        float b, d;
+        if (line_third == 1 && elem_third == 1) { // the interior case, term orders of :3308-3318 (columns) / :3717-3727 (rows)
+            b = v.w[DN] + v.w[DS];
+            b = b + v.w[DE];
+            b = b + v.w[DW];
+            b = b + v.w[DNW];
+            b = b + v.w[DNE];
+            b = b + v.w[DSW];
+            b = b + v.w[DSE];
+            if (vertical) { // N, S, W, NW, NE, E, SW, SE; N and S are the unknowns' own line: no increment
+                d = v.w[DN] * v.g[DN] + v.w[DS] * v.g[DS];
+                d = d + v.w[DW] * (v.g[DW] + v.dx[DW]);
+                d = d + v.w[DNW] * (v.g[DNW] + v.dx[DNW]);
+                d = d + v.w[DNE] * (v.g[DNE] + v.dx[DNE]);
+                d = d + v.w[DE] * (v.g[DE] + v.dx[DE]);
+                d = d + v.w[DSW] * (v.g[DSW] + v.dx[DSW]);
+                d = d + v.w[DSE] * (v.g[DSE] + v.dx[DSE]);
+            } else { // W, E, NW, NE, SW, SE, S, N
+                d = v.w[DW] * v.g[DW] + v.w[DE] * v.g[DE];
+                d = d + v.w[DNW] * (v.g[DNW] + v.dx[DNW]);
+                d = d + v.w[DNE] * (v.g[DNE] + v.dx[DNE]);
+                d = d + v.w[DSW] * (v.g[DSW] + v.dx[DSW]);
+                d = d + v.w[DSE] * (v.g[DSE] + v.dx[DSE]);
+                d = d + v.w[DS] * (v.g[DS] + v.dx[DS]);
+                d = d + v.w[DN] * (v.g[DN] + v.dx[DN]);
+            }
+        } else { // the 17 edge cases: table-driven
+            const signed char(*cs)[9] = ALR_L8[vertical ? 0 : 1][line_third][elem_third];
+            b = 0.0f;
+            d = 0.0f;
+            bool more_b = true, more_d = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int db = cs[0][k], dd = cs[1][k];
+                more_b = more_b && db != DEND;
+                more_d = more_d && dd != DEND;
+                if (more_b) {
+                    const float w = pick8(v.w, db);
+                    b = k ? b + w : w;
+                }
+                if (more_d) {
+                    const bool on_line = vertical ? (dd == DN || dd == DS) : (dd == DW || dd == DE);
+                    const float w = pick8(v.w, dd), g = pick8(v.g, dd), x = pick8(v.dx, dd);
+                    const float term = on_line ? w * g : w * (g + x);
+                    d = k ? d + term : term;
+                }
+            }
         }
         Tri t;
-        if (vertical) {
-            t.a = i > 0 ? -q.w[DN][pos] : 0.0f;
-            t.c = i < nrows - 1 ? -q.w[DS][pos] : 0.0f;
-        } else {
-            t.a = j > 0 ? -q.w[DW][pos] : 0.0f;
-            t.c = j < ncols - 1 ? -q.w[DE][pos] : 0.0f;
-        }
-        const float C = q.C[pos];
-        if (!is_nan(C)) {
-            b += q.D[pos];
-            d += C;
-            d -= q.M[pos] * q.O[pos];
+        t.a = hasBefore ? -(vertical ? v.w[DN] : v.w[DW]) : 0.0f;
+        t.c = hasAfter ? -(vertical ? v.w[DS] : v.w[DE]) : 0.0f;
+        const float MO = v.M * v.O;
+        if (!is_nan(v.C)) {
+            b += v.D;
+            d += v.C;
+            d -= MO;
         }
         t.b = b;
         t.d = d;
         return t;
+    }
+    // direction -> (line offset, element offset) in line terms: on a column before/after = N/S and prev/next = W/E;
+    // on a row before/after = W/E and prev/next = N/S
+    template <bool vertical> __device__ __forceinline__ static void where(int dir, int &dl, int &dk)
+    {
+        const int dj = (dir == DE || dir == DNE || dir == DSE) ? 1 : ((dir == DW || dir == DNW || dir == DSW) ? -1 : 0);
+        const int di = (dir == DS || dir == DSW || dir == DSE) ? 1 : ((dir == DN || dir == DNW || dir == DNE) ? -1 : 0);
+        dl = vertical ? dj : di;
+        dk = vertical ? di : dj;
+    }
+    template <bool vertical> __device__ __forceinline__ static Tri coef(const Ctx &q, const AlrAt &at)
+    {
+        const size_t p = at.pos;
+        In v;
+        const float Uc = q.U[p];
+#pragma unroll
+        for (int dir = 0; dir < 8; ++dir) {
+            int dl, dk;
+            where<vertical>(dir, dl, dk);
+            // clamped neighbour: a direction that leaves the image is in no term list of its case
+            const size_t line = dl < 0 ? at.prev() : (dl > 0 ? at.next() : p);
+            const long ek = dk < 0 ? (at.hasBefore ? -1 : 0) : (dk > 0 ? (at.hasAfter ? 1 : 0) : 0);
+            v.w[dir] = q.w[dir][p];
+            v.g[dir] = q.U[line + ek] - Uc;
+            v.dx[dir] = q.X[line + ek];
+        }
+        v.C = q.C[p]; v.D = q.D[p]; v.M = q.M[p]; v.O = q.O[p];
+        const int lt = at.hasPrev ? (at.hasNext ? 1 : 2) : 0, et = at.hasBefore ? (at.hasAfter ? 1 : 2) : 0;
+        return math<vertical>(v, lt, et, at.hasBefore, at.hasAfter);
+    }
+    template <bool vertical> __device__ __forceinline__ static void coef4(const Ctx &q, int l, int k, int n, int nlines, Tri (&out)[4])
+    {
+        const AlrAt at(l, k, n, nlines);
+        const size_t p = at.pos;
+        float w[8][4], Uc[4], Up[4], Un[4], Xp[4], Xn[4], C[4], D[4], M[4], O[4];
+#pragma unroll
+        for (int dir = 0; dir < 8; ++dir) alr_ld4(q.w[dir] + p, w[dir]);
+        alr_ld4(q.U + p, Uc); alr_ld4(q.U + at.prev(), Up); alr_ld4(q.U + at.next(), Un);
+        alr_ld4(q.X + at.prev(), Xp); alr_ld4(q.X + at.next(), Xn);
+        alr_ld4(q.C + p, C); alr_ld4(q.D + p, D); alr_ld4(q.M + p, M); alr_ld4(q.O + p, O);
+        const long ob = at.hasBefore ? -1 : 0, oa = k + 4 <= n - 1 ? 4 : 3; // element k-1 / k+4, clamped (unused when clamped)
+        const float Uc_b = q.U[p + ob], Uc_a = q.U[p + oa];
+        const float Up_b = q.U[at.prev() + ob], Up_a = q.U[at.prev() + oa], Un_b = q.U[at.next() + ob], Un_a = q.U[at.next() + oa];
+        const float Xp_b = q.X[at.prev() + ob], Xp_a = q.X[at.prev() + oa], Xn_b = q.X[at.next() + ob], Xn_a = q.X[at.next() + oa];
+        const int lt = at.hasPrev ? (at.hasNext ? 1 : 2) : 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // values of the three lines at elements e-1, e, e+1
+            const float uc[3] = {e == 0 ? Uc_b : Uc[e - 1], Uc[e], e == 3 ? Uc_a : Uc[e + 1]};
+            const float up[3] = {e == 0 ? Up_b : Up[e - 1], Up[e], e == 3 ? Up_a : Up[e + 1]};
+            const float un[3] = {e == 0 ? Un_b : Un[e - 1], Un[e], e == 3 ? Un_a : Un[e + 1]};
+            const float xp[3] = {e == 0 ? Xp_b : Xp[e - 1], Xp[e], e == 3 ? Xp_a : Xp[e + 1]};
+            const float xn[3] = {e == 0 ? Xn_b : Xn[e - 1], Xn[e], e == 3 ? Xn_a : Xn[e + 1]};
+            const bool hasBefore = k + e > 0, hasAfter = k + e < n - 1;
+            In v;
+#pragma unroll
+            for (int dir = 0; dir < 8; ++dir) {
+                int dl, dk;
+                where<vertical>(dir, dl, dk);
+                // a direction that leaves the line at its ends is in no term list there: read the centre element instead
+                const int kk = (dk < 0 && !hasBefore) || (dk > 0 && !hasAfter) ? 1 : 1 + dk;
+                v.w[dir] = w[dir][e];
+                v.g[dir] = (dl < 0 ? up[kk] : (dl > 0 ? un[kk] : uc[kk])) - uc[1];
+                v.dx[dir] = dl < 0 ? xp[kk] : (dl > 0 ? xn[kk] : 0.0f);
+            }
+            v.C = C[e]; v.D = D[e]; v.M = M[e]; v.O = O[e];
+            const int et = hasBefore ? (hasAfter ? 1 : 2) : 0;
+            out[e] = math<vertical>(v, lt, et, hasBefore, hasAfter);
+        }
     }
 };
 
@@ -350,7 +447,6 @@ struct AlrPde4 {
         }
     };
     static constexpr bool INTERIOR_LINES = false;
-    static constexpr bool HAS_COEF4 = true;
     struct In { // x1, x2: the two off-line neighbours in the order they enter d: W,E on a column; S,N on a row
         float wN, wS, wE, wW, x1, x2, T, B;
     };
@@ -419,7 +515,6 @@ struct AlrPde8 {
         }
     };
     static constexpr bool INTERIOR_LINES = true; // interior columns, then interior rows (pdeSolvers.c:1153, :1290)
-    static constexpr bool HAS_COEF4 = true;
     // X on the two neighbouring lines: same element (P, N) and the elements before / after it (Pb, Pa, Nb, Na).
     // On a column the previous line is the west column (P = W, Pb = NW, Pa = SW, N = E, Nb = NE, Na = SE); on a row
     // it is the north row (P = N, Pb = NW, Pa = NE, N = S, Nb = SW, Na = SE).
@@ -489,10 +584,7 @@ struct AlrPde8 {
 template <class Mdl, bool VERT>
 __device__ __forceinline__ Tri line_coef(const typename Mdl::Ctx &q, int l, int k, int nrows, int ncols)
 {
-    if constexpr (Mdl::HAS_COEF4)
-        return Mdl::template coef<VERT>(q, AlrAt(l, k, VERT ? nrows : ncols, VERT ? ncols : nrows));
-    else
-        return VERT ? Mdl::template coef<true>(q, k, l, nrows, ncols) : Mdl::template coef<false>(q, l, k, nrows, ncols);
+    return Mdl::template coef<VERT>(q, AlrAt(l, k, VERT ? nrows : ncols, VERT ? ncols : nrows));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -879,8 +971,8 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra2(typename Mdl::Ctx q, 
 // Reference line order.
 //
 // cp[k] = c/(b - cp[k-1] a) depends on the coefficient planes only, not on the iterate, so it is the same
-// in every iteration of a call: k_alr_factor runs that recurrence once per call for every line in
-// parallel (one lane per line) and stores cp and the per-element divisor (1/(b - cp a); b itself for
+// in every iteration of a call: k_alr_zebra2<ZB_FACTOR> runs that recurrence once per call for every line
+// and stores cp and the per-element divisor (1/(b - cp a); b itself for
 // the first element, the plain denominator for the last -- those two are divided by, as in the
 // reference).  What is left per line and iteration is the right-hand side (parallel along the line)
 // and two short recurrences, dp = (d - dp' a) div and x = dp - cp x', which are serial along the
@@ -889,54 +981,12 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra2(typename Mdl::Ctx q, 
 // recurrences.  For the two-field solvers the second field's pass runs one line behind the first
 // field's in the same workgroup (it only needs the first field's finished line l and its own l-1).
 // ------------------------------------------------------------------------------------------------
-template <class Mdl, bool VERT>
-__global__ void __launch_bounds__(64) k_alr_factor(typename Mdl::Ctx q, float *__restrict__ cp, float *__restrict__ dv,
-                                                   int nrows, int ncols, size_t frame_stride, int lo, int hi)
-{
-    constexpr bool vertical = VERT;
-    const int l = lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (l > hi) return;
-    const size_t fo = (size_t)blockIdx.y * frame_stride;
-    q.shift(fo);
-    cp += fo;
-    dv += fo;
-    const int n = vertical ? nrows : ncols; // line length; line l starts at l * n in either layout
-    constexpr size_t stride = 1;
-    const size_t base = (size_t)l * n;
-    constexpr int ZCH = 8;
-    const Tri c0 = line_coef<Mdl, VERT>(q, l, 0, nrows, ncols);
-    float cpv = c0.c / c0.b;
-    cp[base] = cpv;
-    dv[base] = c0.b;
-    for (int k0 = 1; k0 <= n - 2; k0 += ZCH) {
-        Tri c[ZCH];
-#pragma unroll
-        for (int u = 0; u < ZCH; ++u) {
-            const int k = min(k0 + u, n - 2);
-            c[u] = line_coef<Mdl, VERT>(q, l, k, nrows, ncols);
-        }
-#pragma unroll
-        for (int u = 0; u < ZCH; ++u) {
-            const int k = k0 + u;
-            if (k <= n - 2) {
-                const float div = 1.0f / (c[u].b - cpv * c[u].a);
-                cpv = c[u].c * div;
-                cp[base + k * stride] = cpv;
-                dv[base + k * stride] = div;
-            }
-        }
-    }
-    const Tri cl = line_coef<Mdl, VERT>(q, l, n - 1, nrows, ncols);
-    cp[base + (size_t)(n - 1) * stride] = 0.0f;
-    dv[base + (size_t)(n - 1) * stride] = cl.b - cpv * cl.a;
-}
-
 constexpr int ALR_LEX_THREADS = 1024;
 
 template <class Mdl> struct AlrChain {
     typename Mdl::Ctx q;
     float *x;            // the plane this chain solves (q reads it too)
-    const float *cp, *dv; // k_alr_factor's planes for this field and direction
+    const float *cp, *dv; // the factor planes (k_alr_zebra2<ZB_FACTOR>) of this field and direction
 };
 template <class Mdl, int NCH> struct AlrChains {
     AlrChain<Mdl> c[NCH];

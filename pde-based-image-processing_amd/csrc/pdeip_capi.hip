@@ -693,7 +693,7 @@ static int check_alr_line(const char *who, int mode, int nrows, int ncols)
     return PDEIP_OK;
 }
 
-// Workspace of one exact-order call: per (chain, direction) the cp and divisor planes of k_alr_factor.
+// Workspace of one call: per (chain, direction) the cp and divisor planes (k_alr_zebra2<ZB_FACTOR>).
 struct AlrFactors {
     float *cp[2][2], *dv[2][2]; // [chain][vertical ? 0 : 1]
 };
@@ -730,15 +730,8 @@ static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, const typename 
             f->cp[c][d] = base + plane * (size_t)((c * 2 + d) * 2);
             f->dv[c][d] = f->cp[c][d] + plane;
             const int hi = (d == 0 ? ncols : nrows) - 1 - lo;
-            if constexpr (Mdl::HAS_COEF4) {
-                if (d == 0) RC((zebra2_launch<Mdl, true, ZB_FACTOR>(s, q[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
-                else RC((zebra2_launch<Mdl, false, ZB_FACTOR>(s, qt[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
-            } else {
-                const dim3 grid((unsigned)((hi - lo + 1 + 63) / 64), (unsigned)nframes);
-                if (d == 0) hipLaunchKernelGGL((k_alr_factor<Mdl, true>), grid, dim3(64), 0, s, q[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
-                else hipLaunchKernelGGL((k_alr_factor<Mdl, false>), grid, dim3(64), 0, s, qt[c], f->cp[c][d], f->dv[c][d], nrows, ncols, fs, lo, hi);
-                g.last_launches++;
-            }
+            if (d == 0) RC((zebra2_launch<Mdl, true, ZB_FACTOR>(s, q[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
+            else RC((zebra2_launch<Mdl, false, ZB_FACTOR>(s, qt[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
         }
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
@@ -786,8 +779,8 @@ static int alr_lex_pass(hipStream_t s, const typename Mdl::Ctx *q, float *const 
     return PDEIP_OK;
 }
 
-// One direction of one field in zebra order: even lines, then odd lines.  4-neighbour models: k_alr_zebra2 with
-// the per-call factor planes (cpf, dvf); the others: one lane per line (k_alr_zebra).
+// One direction of one field in zebra order: even lines, then odd lines: k_alr_zebra2 with the per-call factor
+// planes (cpf, dvf); the others: one lane per line (k_alr_zebra).
 template <class Mdl>
 static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, const float *cpf, const float *dvf, int nrows, int ncols,
                           int nframes, bool vertical, float omega)
@@ -802,7 +795,7 @@ static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, c
         const int first = lo + (((lo & 1) != colour) ? 1 : 0);
         if (first > hi) continue;
         const int lastc = hi - (((hi & 1) != colour) ? 1 : 0);
-        if constexpr (Mdl::HAS_COEF4) {
+        {
             if (cpf) {
                 if (vertical) RC((zebra2_launch<Mdl, true, ZB_APPLY>(s, q, x, const_cast<float *>(cpf), const_cast<float *>(dvf), dp, nrows, ncols, nframes, first, lastc, 2, omega)));
                 else RC((zebra2_launch<Mdl, false, ZB_APPLY>(s, q, x, const_cast<float *>(cpf), const_cast<float *>(dvf), dp, nrows, ncols, nframes, first, lastc, 2, omega)));
@@ -819,7 +812,7 @@ static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, c
     return PDEIP_OK;
 }
 
-// The row passes run on transposed copies of every plane (pdeip_alr.hpp, AlrGeo).  A model's Ctx is a plain
+// The row passes run on transposed copies of every plane (pdeip_alr.hpp).  A model's Ctx is a plain
 // struct of plane pointers; each distinct plane gets one transposed twin in the WS_ALR_T workspace.  The
 // coefficient planes are transposed once per call, the iterate planes around every row pass.
 struct AlrTwin {
@@ -895,7 +888,7 @@ static int run_alr(const char *who, hipStream_t s, const typename Mdl::Ctx *q, f
     RC(alr_make_twins(s, q, qt, nch, x, xt, nrows, ncols, nframes, &tw));
     AlrFactors f{};
     static const bool zebra1 = env_int("PDEIP_ALR_ZEBRA1", 0) != 0; // the one-lane-per-line kernel for every model (A/B timing)
-    if (mode == PDEIP_MODE_EXACT_ORDER || (Mdl::HAS_COEF4 && !zebra1)) RC(alr_factor<Mdl>(s, q, qt, nch, nrows, ncols, nframes, &f));
+    if (mode == PDEIP_MODE_EXACT_ORDER || !zebra1) RC(alr_factor<Mdl>(s, q, qt, nch, nrows, ncols, nframes, &f));
     SweepTimer timer(s);
     for (int it = 0; it < iter; it++) {
         if (mode == PDEIP_MODE_EXACT_ORDER)
