@@ -103,6 +103,14 @@ def load():
         raise PdeipError(PDEIP_ERR_DEVICE,
                          "libpdeip.so is not built (%s). Run `python __graft_entry__.py build`; "
                          "there is no CPU fallback." % LIB_PATH)
+    # Load order: the torch wheel carries its own copy of the HIP runtime.  If libpdeip.so (linked against
+    # /opt/rocm's) initialises the GPU first and torch is imported afterwards, torch's runtime finds "No HIP GPUs";
+    # with torch first both share one runtime.  device.py / slab.py need torch anyway; mex_api alone does not, so a
+    # process without torch installed simply skips this.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as exc:  # e.g. libamdhip64 missing
