@@ -1,0 +1,84 @@
+"""Coarse-to-fine pyramid around the resident levels of flow_level.py (host side, numpy).
+
+The MATLAB drivers build their pyramid with Image Processing Toolbox calls (`imresize(...,'bilinear')`,
+`fspecial('gaussian',[5 5],1.25)` + `imfilter(...,'replicate')`, FlowEminND_llin_2D_v10.m:100-127, :360-363).
+There is no IPT here and nothing to compare with, so these are OUR definitions of those calls, written from
+their documentation: bilinear = triangle kernel at MATLAB's pixel-centre convention, widened by 1/scale when
+shrinking (IPT's antialiasing), output size ceil(size*scale).  They are host-side numpy on purpose: the
+pyramid is built once per image pair, everything inside a level stays on the device.
+"""
+import math
+
+import numpy as np
+
+
+def gaussian5(sigma=1.25):
+    """fspecial('gaussian', [5 5], sigma)"""
+    ax = np.arange(-2, 3, dtype=np.float64)
+    g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / (2.0 * sigma * sigma))
+    return g / g.sum()
+
+
+def smooth(I, G=None):
+    """imfilter(I, G, 'replicate') for a 5x5 kernel, per channel."""
+    G = gaussian5() if G is None else G
+    I3 = I if I.ndim == 3 else I[:, :, None]
+    P = np.pad(I3.astype(np.float64), ((2, 2), (2, 2), (0, 0)), mode="edge")
+    out = np.zeros(I3.shape, dtype=np.float64)
+    H, W = I3.shape[:2]
+    for a in range(5):
+        for b in range(5):
+            out += G[a, b] * P[a:a + H, b:b + W, :]
+    return out.astype(np.float32).reshape(I.shape)
+
+
+def _resize_matrix(n_in, n_out):
+    """Row-stochastic [n_out, n_in] matrix of a triangle-kernel resize (antialiased when shrinking)."""
+    scale = n_out / n_in
+    width = 1.0 if scale >= 1 else 1.0 / scale
+    M = np.zeros((n_out, n_in), dtype=np.float64)
+    for o in range(n_out):
+        x = (o + 0.5) / scale - 0.5                       # centre of output pixel o in input coordinates
+        lo, hi = int(math.floor(x - width)), int(math.ceil(x + width))
+        for i in range(lo, hi + 1):
+            w = max(0.0, 1.0 - abs(i - x) / width)
+            if w > 0:
+                M[o, min(max(i, 0), n_in - 1)] += w       # replicate at the ends
+        M[o] /= M[o].sum()
+    return M
+
+
+def resize(I, out_rows, out_cols):
+    """imresize(I, 'bilinear', 'OutputSize', [out_rows out_cols])"""
+    I3 = I if I.ndim == 3 else I[:, :, None]
+    R, C = _resize_matrix(I3.shape[0], out_rows), _resize_matrix(I3.shape[1], out_cols)
+    out = np.einsum("or,rck->ock", R, I3.astype(np.float64))
+    out = np.einsum("pc,ock->opk", C, out)
+    return out.astype(np.float32).reshape((out_rows, out_cols) + I.shape[2:])
+
+
+def build(I0, I1, scl_factor=0.75, min_size=20):
+    """Image pyramids of the two frames (finest first), as the drivers build them (:100-127)."""
+    P0, P1 = [I0.astype(np.float32)], [I1.astype(np.float32)]
+    while True:
+        rows, cols = P0[-1].shape[:2]
+        nr, nc = int(math.ceil(rows * scl_factor)), int(math.ceil(cols * scl_factor))
+        P0.append(resize(P0[-1], nr, nc))
+        P1.append(resize(P1[-1], nr, nc))
+        P0[-2], P1[-2] = smooth(P0[-2]), smooth(P1[-2])    # the level just left is smoothed after it has been resized
+        if nr <= min_size or nc <= min_size:
+            P0[-1], P1[-1] = smooth(P0[-1]), smooth(P1[-1])
+            return P0, P1
+
+
+def coarse_to_fine(P0, P1, run_level, scl_factor=0.75):
+    """`run_level(I0, I1, U, V) -> U, V` on MATLAB-shaped numpy arrays; returns the flow at the finest level."""
+    U = np.zeros(P0[-1].shape[:2], dtype=np.float32)
+    V = np.zeros_like(U)
+    for scl in range(len(P0) - 1, -1, -1):
+        U, V = run_level(P0[scl], P1[scl], U, V)
+        if scl > 0:                                        # :360-363
+            rows, cols = P0[scl - 1].shape[:2]
+            U = resize(U * np.float32(1.0 / scl_factor), rows, cols)
+            V = resize(V * np.float32(1.0 / scl_factor), rows, cols)
+    return U, V

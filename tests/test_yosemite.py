@@ -1,0 +1,83 @@
+"""End-to-end sanity on real data: the late-linearisation flow of the Yosemite pair against its ground truth.
+
+Everything below the MEX boundary is bit-pinned elsewhere; this checks that the chain as a whole -- pyramid,
+warp, derivatives, robust assembly, diffusion weights, line-relaxation solver, median -- estimates the motion
+it should, with the driver's default parameters (FlowEminND_llin_2D_v10.m:40-52; 'rgb' / 'none' terms on the
+gray pair).  The pyramid's resize/smoothing are our definitions of the IPT calls (pyramid.py), and the
+accuracy bound is ours.  CPU: the numpy/oracle statement; GPU: the resident levels, which must reproduce the
+statement bit for bit.
+"""
+import importlib
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import problems as pb
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PARAM = dict(firstLoop=4, secondLoop=4, iter=4, omega=1.9, solver=2, alpha=0.042, b1=1.4843, b2=0.0, order=0)
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, path))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _data():
+    d = np.load(os.path.join(ROOT, "tests", "data", "yosemite.npz"))
+    I = d["I"].astype(np.float32) / np.float32(255.0)
+    return np.asfortranarray(I[:, :, :1]), np.asfortranarray(I[:, :, 1:]), d["Utrue"], d["Vtrue"]
+
+
+def _errors(U, V, Ut, Vt):
+    epe = np.sqrt((U - Ut) ** 2 + (V - Vt) ** 2)
+    return float(epe.mean()), float(epe[90:, :].mean())   # all pixels / below the cloud band
+
+
+def statement_flow(oracle):
+    ms, py = _load("matlab_side", "oracle/matlab_side.py"), _load("pyramid", "pde-based-image-processing_amd/pyramid.py")
+    I0, I1, _, _ = _data()
+    P0, P1 = py.build(I0, I1)
+    F = np.asfortranarray
+    return py.coarse_to_fine(P0, P1, lambda a, b, U, V: ms.flow_level(oracle, F(a), F(b), F(U), F(V), PARAM))
+
+
+def test_statement_estimates_the_yosemite_flow(oracle):
+    U, V = statement_flow(oracle)
+    _, _, Ut, Vt = _data()
+    aee, aee_land = _errors(U, V, Ut, Vt)
+    assert aee_land < 0.2 and aee < 0.5, (aee, aee_land)
+    assert np.corrcoef(U.ravel(), Ut.ravel())[0, 1] > 0.9 and np.corrcoef(V.ravel(), Vt.ravel())[0, 1] > 0.85
+
+
+@pytest.mark.gpu
+def test_resident_levels_reproduce_it(pdeip, oracle):
+    dev = importlib.import_module("pde-based-image-processing_amd.device")
+    fl = importlib.import_module("pde-based-image-processing_amd.flow_level")
+    py = importlib.import_module("pde-based-image-processing_amd.pyramid")
+    I0, I1, Ut, Vt = _data()
+    P0, P1 = py.build(I0, I1)
+    level = fl.FlowLlinLevel(PARAM, mode=pdeip.MODE_EXACT_ORDER)
+
+    def run_level(a, b, U, V):
+        gU, gV = level.run(dev.to_device(a), dev.to_device(b), dev.to_device(U), dev.to_device(V))
+        return dev.to_matlab(gU), dev.to_matlab(gV)
+
+    U, V = py.coarse_to_fine(P0, P1, run_level)
+    wU, wV = statement_flow(oracle)
+    assert pb.bit_equal(U, wU) and pb.bit_equal(V, wV), pb.describe_mismatch(U, wU)
+    aee, aee_land = _errors(U, V, Ut, Vt)
+    assert aee_land < 0.2 and aee < 0.5
+    # the parallel orderings estimate the same motion (not the same bits)
+    fast = fl.FlowLlinLevel(dict(PARAM, solver=1, omega=1.5), mode=pdeip.MODE_RED_BLACK)
+
+    def run_fast(a, b, U, V):
+        gU, gV = fast.run(dev.to_device(a), dev.to_device(b), dev.to_device(U), dev.to_device(V))
+        return dev.to_matlab(gU), dev.to_matlab(gV)
+
+    U2, V2 = py.coarse_to_fine(P0, P1, run_fast)
+    assert _errors(U2, V2, Ut, Vt)[0] < 0.8
