@@ -300,6 +300,10 @@ int pdeip_disp_assemble_dev(void *stream, const float *It1, const float *Ix1, in
                             float *CuGd, float *DuGd);
 /* out = A + B (single); e.g. the argument of DdiffWeights(single(U+dU), eps) (:283) */
 int pdeip_add_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out);
+/* Horn-Schunck, early linearisation: the data terms of one scale (matlab/optical_flow/FlowEminHS_elin_2D_v10.m:133-164) from the
+ * two frames [nrows x ncols x C]: separable 5-tap derivative filters and the b1/b2-weighted motion tensor, summed over channels. */
+int pdeip_hs_assemble_dev(void *stream, const float *It0, const float *It1, int C, float b1, float b2, int nrows, int ncols,
+                          float *MGd, float *CuGd, float *CvGd, float *DuGd, float *DvGd);
 /* [wW wN wS wE] = OPdiffWeights(U+dU, V+dV) (:389-433), evaluated in double, returned as single */
 int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, const float *dU, const float *dV, int nrows,
                                  int ncols, float *wW, float *wN, float *wS, float *wE);

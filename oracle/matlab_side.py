@@ -232,3 +232,61 @@ def tv_level(orc, Iin, Iout, param):
         TRACE, B, w = tv_assemble(X, Iin, param["alpha"])
         X = orc.PDEsolver8(X, TRACE, B, *w, param["inner_iter"], param["omega"], solver=param["solver"], order=param["order"])
     return X
+
+
+# ---- Horn-Schunck, early linearisation: matlab/optical_flow/FlowEminHS_elin_2D_v10.m ------------------------------
+
+HS_PRE = np.array([0.037659, 0.249724, 0.439911, 0.249724, 0.037659], dtype=F32)
+HS_D1F = np.array([-0.104550, -0.292315, 0.0, 0.292315, 0.104550], dtype=F32)   # O_dx flipped by 'conv'
+HS_D2 = np.array([0.232905, 0.002668, -0.471147, 0.002668, 0.232905], dtype=F32)
+
+
+def _conv5(A, k, axis):
+    """imfilter(A, k, 'replicate', 'conv') for a 5-tap kernel already flipped; single arithmetic, taps left to right."""
+    pad = [(0, 0)] * A.ndim
+    pad[axis] = (2, 2)
+    P = np.pad(A.astype(F32), pad, mode="edge")
+    n = A.shape[axis]
+    sl = lambda t: tuple(slice(t, t + n) if ax == axis else slice(None) for ax in range(A.ndim))
+    s = (k[0] * P[sl(0)]).astype(F32)
+    for t in range(1, 5):
+        s = (s + (k[t] * P[sl(t)]).astype(F32)).astype(F32)
+    return s
+
+
+def hs_assemble(It0, It1, b1, b2):
+    """MGd, CuGd, CvGd, DuGd, DvGd of FlowEminHS_elin_2D_v10.m:133-164; frames [nrows, ncols(, C)] single."""
+    It0, It1 = [a.astype(F32) if a.ndim == 3 else a.astype(F32)[:, :, None] for a in (It0, It1)]
+    b1, b2 = F32(b1), F32(b2)
+    Ist = ((It0 + It1) * F32(0.55)).astype(F32)
+    Idt = (It0 - It1).astype(F32)
+    vh = lambda A, kv, kh: _conv5(_conv5(A, kv, 0), kh, 1)   # down the columns first, then along the rows
+    hv = lambda A, kh, kv: _conv5(_conv5(A, kh, 1), kv, 0)
+    Idx, Idy = vh(Ist, HS_PRE, HS_D1F), hv(Ist, HS_PRE, HS_D1F)
+    Idxx, Idyy = vh(Ist, HS_PRE, HS_D2), hv(Ist, HS_PRE, HS_D2)
+    Idxy = hv(Ist, HS_D1F, HS_D1F)
+    Idxt = (vh(It0, HS_PRE, HS_D1F) - vh(It1, HS_PRE, HS_D1F)).astype(F32)
+    Idyt = (hv(It0, HS_PRE, HS_D1F) - hv(It1, HS_PRE, HS_D1F)).astype(F32)
+    M = (b1 * Idy) * Idx + (b2 * Idxy) * (Idxx + Idyy)
+    Cu = (b1 * Idt) * Idx + b2 * (Idxt * Idxx + Idyt * Idxy)
+    Cv = (b1 * Idt) * Idy + b2 * (Idxt * Idxy + Idyt * Idyy)
+    Du = (b1 * Idx) * Idx + b2 * (Idxx * Idxx + Idxy * Idxy)
+    Dv = (b1 * Idy) * Idy + b2 * (Idxy * Idxy + Idyy * Idyy)
+    outs = []
+    for s in (M, Cu, Cv, Du, Dv):
+        acc = s[:, :, 0].astype(F32)
+        for c in range(1, s.shape[2]):
+            acc = (acc + s[:, :, c]).astype(F32)
+        outs.append(acc)
+    return outs
+
+
+def hs_level(orc, It0, It1, U, V, param):
+    """One scale of FlowEminHS_elin_2D_v10.m (:119-196, without the pyramid's resize)."""
+    M, Cu, Cv, Du, Dv = hs_assemble(It0, It1, param["b1"], param["b2"])
+    channels = It0.shape[2] if It0.ndim == 3 else 1
+    W = np.full(U.shape, F32(param["alpha"] * channels), dtype=F32, order="F")
+    if param["iter"] <= 0:
+        return U.astype(F32), V.astype(F32)
+    return orc.Oflow_sor_elin4_2d(U, V, M, Cu, Cv, Du, Dv, W, W, W, W, param["iter"], param["omega"], solver=param["solver"],
+                                  order=param["order"])

@@ -68,6 +68,7 @@ SIGNATURES = {
     "pdeip_flow_assemble_dev": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _I, _F, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
     "pdeip_disp_assemble_dev": [_P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _F, _I, _I, _P, _P],
     "pdeip_add_dev": [_P, _P, _P, _I, _I, _P],
+    "pdeip_hs_assemble_dev": [_P, _P, _P, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P],
     "pdeip_flow_opdiffweights_dev": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "pdeip_tv_assemble_dev": [_P, _P, _P, _I, _I, _I, _F] + [_P] * 10,
     "pdeip_median3_dev": [_P, _P, _P, _I, _I, _P],

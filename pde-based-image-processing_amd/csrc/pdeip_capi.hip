@@ -1116,6 +1116,16 @@ extern "C" int pdeip_add_dev(void *stream, const float *A, const float *B, int n
     return PDEIP_OK;
 }
 
+extern "C" int pdeip_hs_assemble_dev(void *stream, const float *It0, const float *It1, int C, float b1, float b2, int nrows, int ncols,
+                                     float *MGd, float *CuGd, float *CvGd, float *DuGd, float *DvGd)
+{
+    RC(check_dims("pdeip_hs_assemble_dev", nrows, ncols, C));
+    hipLaunchKernelGGL(k_hs_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), MGd, CuGd, CvGd, DuGd, DvGd,
+                       It0, It1, C, b1, b2, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, const float *dU, const float *dV, int nrows,
                                             int ncols, float *wW, float *wN, float *wS, float *wE)
 {

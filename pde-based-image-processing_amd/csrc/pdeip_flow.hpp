@@ -176,4 +176,109 @@ __global__ void k_median3_sum(float *out, const float *A, const float *B, int nr
     out[pos] = v[4];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Horn-Schunck with early linearisation: the per-scale data terms of FlowEminHS_elin_2D_v10.m:133-164.
+// Ist = (It0+It1).*0.55, Idt = It0-It1; separable 5-tap filters (imfilter(...,'replicate','conv'), two passes with
+// the first pass stored as single): Idx, Idy, Idxx, Idyy, Idxy of Ist and Idxt, Idyt as differences of the
+// filtered frames; then per channel
+//   M  = b1*Idy.*Idx + b2*Idxy.*(Idxx+Idyy)        Cu = b1*Idt.*Idx + b2*(Idxt.*Idxx + Idyt.*Idxy)
+//   Cv = b1*Idt.*Idy + b2*(Idxt.*Idxy + Idyt.*Idyy)   Du = b1*Idx.*Idx + b2*(Idxx.*Idxx + Idxy.*Idxy)
+//   Dv = b1*Idy.*Idy + b2*(Idxy.*Idxy + Idyy.*Idyy)
+// summed over the channels.  Taps are summed left to right over the flipped kernel (our definition of imfilter's
+// unspecified order); every pixel re-evaluates the first pass where it needs it, so nothing intermediate touches HBM.
+// ------------------------------------------------------------------------------------------------
+__constant__ float HS_PRE[5] = {0.037659f, 0.249724f, 0.439911f, 0.249724f, 0.037659f};      // prefilter_spa (:77), symmetric
+__constant__ float HS_D1F[5] = {-0.104550f, -0.292315f, 0.0f, 0.292315f, 0.104550f};          // O_dx (:78) flipped by 'conv'
+__constant__ float HS_D2[5] = {0.232905f, 0.002668f, -0.471147f, 0.002668f, 0.232905f};       // O_dxx (:80), symmetric
+
+struct HsImage { // one channel of one "image" the filters run on: a*P0 (+ b*P1)
+    const float *P0, *P1;
+    int mode; // 0: (P0+P1)*0.55   1: P0   2: P1
+    int nrows, ncols;
+    __device__ __forceinline__ float at(int i, int j) const
+    {
+        i = i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i);
+        j = j < 0 ? 0 : (j > ncols - 1 ? ncols - 1 : j);
+        const size_t p = (size_t)j * nrows + i;
+        return mode == 0 ? (P0[p] + P1[p]) * 0.55f : (mode == 1 ? P0[p] : P1[p]);
+    }
+};
+
+// first pass along the rows index i (a column vector kernel), evaluated at (i, j) with j clamped by the caller
+__device__ __forceinline__ float hs_v5(const HsImage &A, const float *k, int i, int j)
+{
+    float s = k[0] * A.at(i - 2, j);
+    s = s + k[1] * A.at(i - 1, j);
+    s = s + k[2] * A.at(i, j);
+    s = s + k[3] * A.at(i + 1, j);
+    s = s + k[4] * A.at(i + 2, j);
+    return s;
+}
+__device__ __forceinline__ float hs_h5(const HsImage &A, const float *k, int i, int j)
+{
+    float s = k[0] * A.at(i, j - 2);
+    s = s + k[1] * A.at(i, j - 1);
+    s = s + k[2] * A.at(i, j);
+    s = s + k[3] * A.at(i, j + 1);
+    s = s + k[4] * A.at(i, j + 2);
+    return s;
+}
+// vertical pass with kv, then horizontal pass with kh over the stored (replicated) first-pass result
+__device__ __forceinline__ float hs_vh(const HsImage &A, const float *kv, const float *kh, int i, int j)
+{
+    auto cj = [&](int v) { return v < 0 ? 0 : (v > A.ncols - 1 ? A.ncols - 1 : v); };
+    float s = kh[0] * hs_v5(A, kv, i, cj(j - 2));
+    s = s + kh[1] * hs_v5(A, kv, i, cj(j - 1));
+    s = s + kh[2] * hs_v5(A, kv, i, j);
+    s = s + kh[3] * hs_v5(A, kv, i, cj(j + 1));
+    s = s + kh[4] * hs_v5(A, kv, i, cj(j + 2));
+    return s;
+}
+// horizontal pass with kh, then vertical pass with kv
+__device__ __forceinline__ float hs_hv(const HsImage &A, const float *kh, const float *kv, int i, int j)
+{
+    auto ci = [&](int v) { return v < 0 ? 0 : (v > A.nrows - 1 ? A.nrows - 1 : v); };
+    float s = kv[0] * hs_h5(A, kh, ci(i - 2), j);
+    s = s + kv[1] * hs_h5(A, kh, ci(i - 1), j);
+    s = s + kv[2] * hs_h5(A, kh, i, j);
+    s = s + kv[3] * hs_h5(A, kh, ci(i + 1), j);
+    s = s + kv[4] * hs_h5(A, kh, ci(i + 2), j);
+    return s;
+}
+
+__global__ void k_hs_assemble(float *MGd, float *CuGd, float *CvGd, float *DuGd, float *DvGd, const float *It0, const float *It1,
+                              int C, float b1, float b2, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t n = (size_t)nrows * ncols;
+    float m = 0.0f, cu = 0.0f, cv = 0.0f, du = 0.0f, dv = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const HsImage S{It0 + c * n, It1 + c * n, 0, nrows, ncols}, A0{It0 + c * n, It1 + c * n, 1, nrows, ncols},
+            A1{It0 + c * n, It1 + c * n, 2, nrows, ncols};
+        const float Idt = It0[c * n + pos] - It1[c * n + pos];
+        const float Idx = hs_vh(S, HS_PRE, HS_D1F, i, j);   // smooth down the column, derive along the row
+        const float Idy = hs_hv(S, HS_PRE, HS_D1F, i, j);   // smooth along the row, derive down the column
+        const float Idxx = hs_vh(S, HS_PRE, HS_D2, i, j);
+        const float Idyy = hs_hv(S, HS_PRE, HS_D2, i, j);
+        const float Idxy = hs_hv(S, HS_D1F, HS_D1F, i, j);  // imfilter(imfilter(Ist,O_dx),O_dy)
+        const float Idxt = hs_vh(A0, HS_PRE, HS_D1F, i, j) - hs_vh(A1, HS_PRE, HS_D1F, i, j);
+        const float Idyt = hs_hv(A0, HS_PRE, HS_D1F, i, j) - hs_hv(A1, HS_PRE, HS_D1F, i, j);
+        const float Mc = (b1 * Idy) * Idx + (b2 * Idxy) * (Idxx + Idyy);
+        const float Cuc = (b1 * Idt) * Idx + b2 * (Idxt * Idxx + Idyt * Idxy);
+        const float Cvc = (b1 * Idt) * Idy + b2 * (Idxt * Idxy + Idyt * Idyy);
+        const float Duc = (b1 * Idx) * Idx + b2 * (Idxx * Idxx + Idxy * Idxy);
+        const float Dvc = (b1 * Idy) * Idy + b2 * (Idxy * Idxy + Idyy * Idyy);
+        m = c ? m + Mc : Mc;   // sum(.,3)
+        cu = c ? cu + Cuc : Cuc;
+        cv = c ? cv + Cvc : Cvc;
+        du = c ? du + Duc : Duc;
+        dv = c ? dv + Dvc : Dvc;
+    }
+    MGd[pos] = m;
+    CuGd[pos] = cu;
+    CvGd[pos] = cv;
+    DuGd[pos] = du;
+    DvGd[pos] = dv;
+}
+
 } // namespace pdeip

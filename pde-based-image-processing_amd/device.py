@@ -235,3 +235,10 @@ def tv_assemble(Iout, Iin, alpha, TRACE, B, w8):
     _chk(Iout, Iin, TRACE, B, *w8)
     nrows, ncols, F = _dims(Iout)
     capi.call("pdeip_tv_assemble_dev", _stream(), *_p(Iout, Iin), nrows, ncols, F, float(alpha), *_p(TRACE, B, *w8))
+
+
+def hs_assemble(It0, It1, b1, b2, MGd, CuGd, CvGd, DuGd, DvGd):
+    """FlowEminHS_elin_2D_v10.m:133-164: data terms of one scale from the frames [C, ncols, nrows] (or [ncols, nrows])."""
+    _chk(It0, It1, MGd, CuGd, CvGd, DuGd, DvGd)
+    nrows, ncols, C = _dims(It0)
+    capi.call("pdeip_hs_assemble_dev", _stream(), *_p(It0, It1), C, float(b1), float(b2), nrows, ncols, *_p(MGd, CuGd, CvGd, DuGd, DvGd))

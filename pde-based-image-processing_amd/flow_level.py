@@ -111,3 +111,24 @@ class TvLevel:
             dev.tv_assemble(X, Iin, p["alpha"], TRACE, B, w8)
             solve(X, TRACE, B, *w8, int(p["inner_iter"]), float(p["omega"]), self.mode)
         return X
+
+
+class FlowHsLevel:
+    """One scale of Horn-Schunck with early linearisation (matlab/optical_flow/FlowEminHS_elin_2D_v10.m:119-196):
+    data terms from the unwarped frames, constant diffusion weight alpha*channels, one Oflow_sor_elin4_2d call.
+    param: alpha, b1, b2, iter, omega, solver."""
+
+    def __init__(self, param, mode=capi.MODE_EXACT_ORDER):
+        self.p, self.mode = dict(param), mode
+
+    def run(self, It0, It1, U, V):
+        p = self.p
+        channels = It0.shape[0] if It0.dim() == 3 else 1
+        coef = [torch.empty_like(U) for _ in range(5)]
+        dev.hs_assemble(It0, It1, p["b1"], p["b2"], *coef)
+        W = torch.full_like(U, float(p["alpha"]) * channels)   # W = param.alpha*channels*ones(rows, cols) (:121)
+        U, V = U.clone(), V.clone()
+        if int(p["iter"]) > 0:
+            fn = dev.oflow_sor_elin4 if int(p["solver"]) == 1 else dev.oflow_alr_elin4
+            fn(U, V, *coef, W, W, W, W, int(p["iter"]), float(p["omega"]), self.mode)
+        return U, V

@@ -71,14 +71,25 @@ def build(I0, I1, scl_factor=0.75, min_size=20):
             return P0, P1
 
 
-def coarse_to_fine(P0, P1, run_level, scl_factor=0.75):
-    """`run_level(I0, I1, U, V) -> U, V` on MATLAB-shaped numpy arrays; returns the flow at the finest level."""
+def median3(A):
+    """medfilt2(A, [3 3], 'symmetric')"""
+    P = np.pad(A.astype(np.float32), 1, mode="symmetric")
+    rows, cols = A.shape
+    return np.sort(np.stack([P[a:a + rows, b:b + cols] for a in range(3) for b in range(3)]), axis=0)[4]
+
+
+def coarse_to_fine(P0, P1, run_level, scl_factor=0.75, median_before_resize=False):
+    """`run_level(I0, I1, U, V) -> U, V` on MATLAB-shaped numpy arrays; returns the flow at the finest level.
+    median_before_resize: FlowEminHS_elin_2D_v10.m:193-194 filters the up-scaled flow before resizing it;
+    FlowEminND_llin_2D_v10.m:360-363 does not (its median is inside the level)."""
     U = np.zeros(P0[-1].shape[:2], dtype=np.float32)
     V = np.zeros_like(U)
     for scl in range(len(P0) - 1, -1, -1):
         U, V = run_level(P0[scl], P1[scl], U, V)
-        if scl > 0:                                        # :360-363
+        if scl > 0:
             rows, cols = P0[scl - 1].shape[:2]
-            U = resize(U * np.float32(1.0 / scl_factor), rows, cols)
-            V = resize(V * np.float32(1.0 / scl_factor), rows, cols)
+            U, V = U * np.float32(1.0 / scl_factor), V * np.float32(1.0 / scl_factor)
+            if median_before_resize:
+                U, V = median3(U), median3(V)
+            U, V = resize(U, rows, cols), resize(V, rows, cols)
     return U, V

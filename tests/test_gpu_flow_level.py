@@ -155,3 +155,30 @@ def test_resident_tv_level(pdeip, oracle, solver, mode, order):
     got = sub("flow_level").TvLevel(param, mode=mode).run(dev.to_device(noisy), dev.to_device(noisy))
     same(dev.to_matlab(got), want, "TV level (solver %d mode %d)" % (solver, mode))
     assert np.isfinite(want).all()
+
+
+@pytest.mark.parametrize("shape,C", [((37, 53), 1), ((64, 80), 3), ((6, 120), 2), ((131, 5), 1)])
+def test_horn_schunck_data_terms(pdeip, shape, C):
+    import torch
+    ms, dev = matlab_side(), sub("device")
+    I0, I1 = frames(31 + C, shape[0], shape[1], C)
+    if C == 1:
+        I0, I1 = np.asfortranarray(I0[:, :, 0]), np.asfortranarray(I1[:, :, 0])
+    d0, d1 = dev.to_device(I0), dev.to_device(I1)
+    outs = [torch.empty((shape[1], shape[0]), device="cuda") for _ in range(5)]
+    dev.hs_assemble(d0, d1, 0.25, 0.75, *outs)
+    for k, (g, w) in enumerate(zip(outs, ms.hs_assemble(I0, I1, 0.25, 0.75))):
+        same(dev.to_matlab(g), w, "H&S term %d %s C=%d" % (k, shape, C))
+
+
+@pytest.mark.parametrize("solver,mode,order", [(1, 0, 0), (1, 1, 1), (2, 0, 0), (2, 1, 1)])
+def test_resident_horn_schunck_scale(pdeip, oracle, solver, mode, order):
+    ms, dev = matlab_side(), sub("device")
+    I0, I1 = frames(41, 50, 66, 3)
+    rng = np.random.default_rng(3)
+    U0 = np.asfortranarray(rng.uniform(-0.5, 0.5, (50, 66)).astype(np.float32))
+    param = dict(alpha=0.2, b1=0.25, b2=0.75, iter=20, omega=1.9, solver=solver, order=order)
+    wU, wV = ms.hs_level(oracle, I0, I1, U0, U0, param)
+    gU, gV = sub("flow_level").FlowHsLevel(param, mode=mode).run(dev.to_device(I0), dev.to_device(I1), dev.to_device(U0), dev.to_device(U0))
+    same(dev.to_matlab(gU), wU, "H&S scale U (solver %d mode %d)" % (solver, mode))
+    same(dev.to_matlab(gV), wV, "H&S scale V (solver %d mode %d)" % (solver, mode))

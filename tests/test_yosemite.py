@@ -54,6 +54,43 @@ def test_statement_estimates_the_yosemite_flow(oracle):
     assert np.corrcoef(U.ravel(), Ut.ravel())[0, 1] > 0.9 and np.corrcoef(V.ravel(), Vt.ravel())[0, 1] > 0.85
 
 
+HS_PARAM = dict(alpha=0.2, b1=0.25, b2=0.75, iter=20, omega=1.9, solver=2, order=0)   # FlowEminHS_elin_2D_v10.m:40-47
+
+
+def statement_hs_flow(oracle):
+    ms, py = _load("matlab_side", "oracle/matlab_side.py"), _load("pyramid", "pde-based-image-processing_amd/pyramid.py")
+    I0, I1, _, _ = _data()
+    P0, P1 = py.build(I0, I1)
+    F = np.asfortranarray
+    return py.coarse_to_fine(P0, P1, lambda a, b, U, V: ms.hs_level(oracle, F(a), F(b), F(U), F(V), HS_PARAM), median_before_resize=True)
+
+
+def test_horn_schunck_statement_on_yosemite(oracle):
+    """Early linearisation without warping cannot follow the 4-5 px motions of the lower left corner: a loose bound."""
+    U, V = statement_hs_flow(oracle)
+    _, _, Ut, Vt = _data()
+    assert _errors(U, V, Ut, Vt)[0] < 1.2
+    assert np.corrcoef(U.ravel(), Ut.ravel())[0, 1] > 0.85 and np.corrcoef(V.ravel(), Vt.ravel())[0, 1] > 0.7
+
+
+@pytest.mark.gpu
+def test_resident_horn_schunck_reproduces_it(pdeip, oracle):
+    dev = importlib.import_module("pde-based-image-processing_amd.device")
+    fl = importlib.import_module("pde-based-image-processing_amd.flow_level")
+    py = importlib.import_module("pde-based-image-processing_amd.pyramid")
+    I0, I1, _, _ = _data()
+    P0, P1 = py.build(I0, I1)
+    level = fl.FlowHsLevel(HS_PARAM, mode=pdeip.MODE_EXACT_ORDER)
+
+    def run_level(a, b, U, V):
+        gU, gV = level.run(dev.to_device(a), dev.to_device(b), dev.to_device(U), dev.to_device(V))
+        return dev.to_matlab(gU), dev.to_matlab(gV)
+
+    U, V = py.coarse_to_fine(P0, P1, run_level, median_before_resize=True)
+    wU, wV = statement_hs_flow(oracle)
+    assert pb.bit_equal(U, wU) and pb.bit_equal(V, wV), pb.describe_mismatch(U, wU)
+
+
 @pytest.mark.gpu
 def test_resident_levels_reproduce_it(pdeip, oracle):
     dev = importlib.import_module("pde-based-image-processing_amd.device")
