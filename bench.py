@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-calls", type=int, default=5, help="solver calls timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed red-black workload (what the rocprofv3 summary under profiles/ is taken from)")
     args = ap.parse_args()
 
     import torch
@@ -182,7 +184,7 @@ def main():
         except (ValueError, OSError):
             pass
 
-    if world == 1:
+    if world == 1 and not args.headline_only:
         # ---- exact (reference) ordering on the same workload -------------------------------------
         Ue, Ve = U0.clone(), V0.clone()
 
