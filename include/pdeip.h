@@ -307,6 +307,32 @@ int pdeip_hs_assemble_dev(void *stream, const float *It0, const float *It1, int 
 /* [wW wN wS wE] = OPdiffWeights(U+dU, V+dV) (:389-433), evaluated in double, returned as single */
 int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, const float *dU, const float *dV, int nrows,
                                  int ncols, float *wW, float *wN, float *wS, float *wE);
+/* dU, dV may both be NULL: OPdiffWeights(U, V) of the early-linearisation drivers (FlowEminNDFASFMG_elin_2D_v10.m:392). */
+
+/* ---- FAS full-multigrid flow (matlab/optical_flow/FlowEminNDFASFMG_elin_2D_v10.m): the stages between its MEX calls ----
+ * Planes are [nrows x ncols x frames], column-major, as everywhere.  Output dimensions of the two halving stages are
+ * ceil(nrows/2) x ceil(ncols/2) (MATLAB's 1:2:end). */
+/* imfilter(I, G, 'replicate', 'conv') with a 5x5 kernel (:104-105); g25 = the kernel G itself, column-major (host memory) */
+int pdeip_fas_gauss5_dev(void *stream, const float *in, int nrows, int ncols, int frames, const float *g25, float *out);
+/* one pyramid step (:108-111): [1 4 6 4 1]/16 along both axes, then (1:2:end, 1:2:end, :) */
+int pdeip_fas_down_dev(void *stream, const float *in, int nrows, int ncols, int frames, float *out);
+/* the per-scale constants (:125-153) from the frames (0..255 range): planes = [13][frames][ncols][nrows] in the order
+ * Idt, Idx, Idy, Idxx, Idyy, Idxy, Idxt, Idyt, M, Cu, Cv, Du, Dv */
+int pdeip_fas_prepare_dev(void *stream, const float *It0, const float *It1, int nrows, int ncols, int frames, float b1, float b2,
+                          float *planes);
+/* gd = 1./(k*sqrt(OPnorm+0.00001)) at (U,V) and the solver's planes (:377-397 summed over the frames when per_frame = 0,
+ * one plane each; :425-445 / :228-237 per frame when per_frame = 1, [.. x frames] each, plus gd).  Cu/Cv: the right-hand
+ * side [.. x frames] (the scale's own or the cycle's fu/fv); they, their outputs and gd may be NULL. */
+int pdeip_fas_assemble_dev(void *stream, const float *planes, const float *Cu, const float *Cv, const float *U, const float *V,
+                           int nrows, int ncols, int frames, float b1, float b2, float k, int per_frame, float *MGd, float *CuGd,
+                           float *CvGd, float *DuGd, float *DvGd, float *gd);
+/* imfilter(in*scale, [1 2 1;2 4 2;1 2 1]/16, 'replicate', 'conv')(1:2:end, 1:2:end, :) (:200, :212-217) */
+int pdeip_fas_restrict_dev(void *stream, const float *in, int nrows, int ncols, int frames, float scale, float *out);
+/* out = (R + A)./gd (:250-251) */
+int pdeip_fas_rhs_dev(void *stream, const float *R, const float *A, const float *gd, int nrows, int ncols, int frames, float *out);
+/* U = U + imresize((Uc-Ures)*inv_scale, size(U), 'bilinear') (:256-257); Uc, Ures are [nrows_c x ncols_c] */
+int pdeip_fas_prolong_add_dev(void *stream, float *U, int nrows, int ncols, const float *Uc, const float *Ures, int nrows_c,
+                              int ncols_c, float inv_scale);
 /* TVdenoise8's work between two PDEsolver8 calls (matlab/denoising/TVdenoise8.m:80-86 with ADdiffWeights :119-231):
  * the anisotropic weights of Iout (double; Alvarez derivative, strongest frame per pixel, lambda = median of the
  * non-zero squared gradient norms), then TRACE = PsiData + alpha*sum(w), B = PsiData.*Iin with

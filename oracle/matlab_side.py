@@ -290,3 +290,178 @@ def hs_level(orc, It0, It1, U, V, param):
         return U.astype(F32), V.astype(F32)
     return orc.Oflow_sor_elin4_2d(U, V, M, Cu, Cv, Du, Dv, W, W, W, W, param["iter"], param["omega"], solver=param["solver"],
                                   order=param["order"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# FAS full multigrid flow with early linearisation (matlab/optical_flow/FlowEminNDFASFMG_elin_2D_v10.m)
+# ---------------------------------------------------------------------------------------------------------
+FAS_LPF = np.array([1, 4, 6, 4, 1], dtype=np.float64) / 16                                     # lpf (:99)
+FAS_D1F_SCL = (np.array([-0.104550, -0.292315, 0.0, 0.292315, 0.104550]) / 255).astype(F32)     # O_dx_scl (:87) flipped
+FAS_PLANES = ("Idt", "Idx", "Idy", "Idxx", "Idyy", "Idxy", "Idxt", "Idyt", "M", "Cu", "Cv", "Du", "Dv")
+
+
+def _c3(A):
+    return A.astype(F32) if A.ndim == 3 else A.astype(F32)[:, :, None]
+
+
+def fas_gaussian5(sigma=1.0):
+    """fspecial('gaussian', [5 5], sigma) as single taps (:98)"""
+    ax = np.arange(-2, 3, dtype=np.float64)
+    g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / (2.0 * sigma * sigma))
+    g[g < np.finfo(np.float64).eps * g.max()] = 0
+    return (g / g.sum()).astype(F32)
+
+
+def fas_gauss5(I, G):
+    """imfilter(I, G, 'replicate', 'conv') for a 5x5 kernel (:104): single arithmetic, taps in column-major order of the
+    flipped kernel (our definition of the unspecified order)."""
+    I3 = _c3(I)
+    P = np.pad(I3, ((2, 2), (2, 2), (0, 0)), mode="edge")
+    H, W = I3.shape[:2]
+    Gf = G[::-1, ::-1]
+    acc = None
+    for b in range(5):
+        for a in range(5):
+            t = (Gf[a, b] * P[a:a + H, b:b + W, :]).astype(F32)
+            acc = t if acc is None else (acc + t).astype(F32)
+    return acc
+
+
+def fas_down(I):
+    """One pyramid step (:108-111): lpf along the rows of the image, then lpf', then (1:2:end, 1:2:end, :)."""
+    k = FAS_LPF.astype(F32)
+    return np.ascontiguousarray(_conv5(_conv5(_c3(I), k, 1), k, 0)[::2, ::2, :])
+
+
+def fas_pyramid(I0, I1, max_scales=None):
+    """It0{scl}, It1{scl} (:104-120), finest first; stops after the first scale with a side <= 10."""
+    G = fas_gaussian5(1.0)
+    P0, P1 = [fas_gauss5(I0, G)], [fas_gauss5(I1, G)]
+    while max_scales is None or len(P0) < max_scales:
+        P0.append(fas_down(P0[-1]))
+        P1.append(fas_down(P1[-1]))
+        if P0[-1].shape[0] <= 10 or P0[-1].shape[1] <= 10:
+            break
+    return P0, P1
+
+
+def fas_prepare(It0, It1, b1, b2):
+    """The per-scale constants (:125-153) as a dict of [nrows, ncols, C] single arrays (FAS_PLANES)."""
+    It0, It1 = _c3(It0), _c3(It1)
+    b1, b2 = F32(b1), F32(b2)
+    Ist = (((It0 + It1) * F32(0.55)).astype(F32) / F32(255)).astype(F32)
+    Idt = ((It0 - It1) / F32(255)).astype(F32)
+    vh = lambda A, kv, kh: _conv5(_conv5(A, kv, 0), kh, 1)
+    hv = lambda A, kh, kv: _conv5(_conv5(A, kh, 1), kv, 0)
+    Idx, Idy = vh(Ist, HS_PRE, HS_D1F), hv(Ist, HS_PRE, HS_D1F)
+    Idxx, Idyy = vh(Ist, HS_PRE, HS_D2), hv(Ist, HS_PRE, HS_D2)
+    Idxy = hv(Ist, HS_D1F, HS_D1F)
+    Idxt = (vh(It0, HS_PRE, FAS_D1F_SCL) - vh(It1, HS_PRE, FAS_D1F_SCL)).astype(F32)
+    Idyt = (hv(It0, HS_PRE, FAS_D1F_SCL) - hv(It1, HS_PRE, FAS_D1F_SCL)).astype(F32)
+    M = (b1 * Idy) * Idx + (b2 * Idxy) * (Idxx + Idyy)
+    Cu = (b1 * Idt) * Idx + b2 * (Idxt * Idxx + Idyt * Idxy)
+    Cv = (b1 * Idt) * Idy + b2 * (Idxt * Idxy + Idyt * Idyy)
+    Du = (b1 * Idx) * Idx + b2 * (Idxx * Idxx + Idxy * Idxy)
+    Dv = (b1 * Idy) * Idy + b2 * (Idxy * Idxy + Idyy * Idyy)
+    vals = (Idt, Idx, Idy, Idxx, Idyy, Idxy, Idxt, Idyt, M, Cu, Cv, Du, Dv)
+    return {k: np.asfortranarray(v.astype(F32)) for k, v in zip(FAS_PLANES, vals)}
+
+
+def fas_gd(pl, U, V, b1, b2, k):
+    """gd = 1./(k*sqrt(OPnorm+0.00001)) with OPnorm of :382-385 (k = channels*alpha in the smoother, alpha for residuals)"""
+    u, v = U.astype(F32)[:, :, None], V.astype(F32)[:, :, None]
+    r1 = (pl["Idt"] - pl["Idx"] * u) - pl["Idy"] * v
+    r2 = (pl["Idxt"] - pl["Idxx"] * u) - pl["Idxy"] * v
+    r3 = (pl["Idyt"] - pl["Idxy"] * u) - pl["Idyy"] * v
+    opnorm = F32(b1) * (r1 * r1) + F32(b2) * ((r2 * r2) + (r3 * r3))
+    return (F32(1) / (F32(k) * np.sqrt(opnorm + F32(0.00001)))).astype(F32)
+
+
+def _sum3(A):
+    acc = A[:, :, 0].astype(F32)
+    for c in range(1, A.shape[2]):
+        acc = (acc + A[:, :, c]).astype(F32)
+    return np.asfortranarray(acc)
+
+
+def fas_smooth(orc, U, V, pl, Cu, Cv, param, residuals=False):
+    """smooth() (:367-464).  Cu, Cv: [nrows, ncols, C] right-hand sides (the scale's own, or fu/fv of the cycle)."""
+    channels = pl["Idx"].shape[2]
+    U, V = np.asfortranarray(U, dtype=F32), np.asfortranarray(V, dtype=F32)
+    zero = np.zeros_like(U)
+    for _ in range(param["firstLoop"]):
+        gd = fas_gd(pl, U, V, param["b1"], param["b2"], channels * param["alpha"])
+        wW, wN, wS, wE = op_diff_weights(U, V, zero, zero)
+        MGd, CuGd, CvGd, DuGd, DvGd = [_sum3(a * gd) for a in (pl["M"], Cu, Cv, pl["Du"], pl["Dv"])]
+        U, V = orc.Oflow_sor_elin4_2d(U, V, MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wE, wS, param["iter"], param["omega"],
+                                      solver=param["solver"], order=param["order"])
+    if not residuals:
+        return U, V
+    gd = fas_gd(pl, U, V, param["b1"], param["b2"], param["alpha"])
+    wW, wN, wS, wE = op_diff_weights(U, V, zero, zero)
+    MGd, CuGd, CvGd, DuGd, DvGd = [np.asfortranarray((a * gd).astype(F32)) for a in (pl["M"], Cu, Cv, pl["Du"], pl["Dv"])]
+    _, _, RU, RV = orc.Oflow_sor_elin4_2d(U, V, MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wE, wS, 0, param["omega"],
+                                          solver=param["solver"], nargout=4)
+    return U, V, RU, RV
+
+
+def fas_restrict(A, scale):
+    """imfilter(A*scale, fw, 'replicate', 'conv')(1:2:end, 1:2:end, :) with fw = [1 2 1; 2 4 2; 1 2 1]/16 (:200, :212-217);
+    single arithmetic, taps in column-major order."""
+    A3 = (_c3(A) * F32(scale)).astype(F32)
+    P = np.pad(A3, ((1, 1), (1, 1), (0, 0)), mode="edge")
+    H, W = A3.shape[:2]
+    fw = (np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], dtype=np.float64) / 16).astype(F32)
+    acc = None
+    for b in range(3):
+        for a in range(3):
+            t = (fw[a, b] * P[a:a + H, b:b + W, :]).astype(F32)
+            acc = t if acc is None else (acc + t).astype(F32)
+    out = acc[::2, ::2, :]
+    return np.asfortranarray(out if A.ndim == 3 else out[:, :, 0])
+
+
+def _bilin_axis(n_in, n_out):
+    """imresize 'bilinear' when enlarging (no antialiasing): for output index o the two source indices (clamped)
+    and the weight of the second one, pixel centres aligned the MATLAB way."""
+    scale = n_out / n_in
+    x = (np.arange(n_out, dtype=np.float64) + 0.5) / scale - 0.5
+    i0 = np.floor(x)
+    f = x - i0
+    i0 = i0.astype(np.int64)
+    return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), f
+
+
+def fas_prolong_add(U, Uc, Ures, inv_scale):
+    """U + imresize((Uc-Ures)*(1/scl_factor), size(U), 'bilinear') (:256-257): rows first, then columns, in double,
+    rounded to single once; the sum with U in single."""
+    D = ((Uc.astype(F32) - Ures.astype(F32)) * F32(inv_scale)).astype(F32).astype(np.float64)
+    r0, r1, fr = _bilin_axis(D.shape[0], U.shape[0])
+    c0, c1, fc = _bilin_axis(D.shape[1], U.shape[1])
+    T = (1.0 - fr)[:, None] * D[r0, :] + fr[:, None] * D[r1, :]
+    R = (1.0 - fc)[None, :] * T[:, c0] + fc[None, :] * T[:, c1]
+    return np.asfortranarray((U.astype(F32) + R.astype(F32)).astype(F32))
+
+
+def fas_cycle(orc, planes, U, V, Cu, Cv, scl, param):
+    """FAS_CYCLE (:193-273); planes[scl] = fas_prepare of scale scl (0 = finest), Cu/Cv the right-hand side at this scale."""
+    scales = len(planes)
+    pl = planes[scl]
+    if scl == scales - 1:
+        return fas_smooth(orc, U, V, pl, Cu, Cv, param)
+    s = param["scl_factor"]
+    for _ in range(param["cycle_index"]):
+        U, V, RU, RV = fas_smooth(orc, U, V, pl, Cu, Cv, param, residuals=True)
+        RUres, RVres = fas_restrict(RU, s), fas_restrict(RV, s)
+        Ures, Vres = fas_restrict(U, s), fas_restrict(V, s)
+        pc = planes[scl + 1]
+        gd = fas_gd(pc, Ures, Vres, param["b1"], param["b2"], param["alpha"])
+        zero = np.zeros_like(Ures)
+        wW, wN, wS, wE = op_diff_weights(Ures, Vres, zero, zero)
+        MGd, DuGd, DvGd = [np.asfortranarray((a * gd).astype(F32)) for a in (pc["M"], pc["Du"], pc["Dv"])]
+        Au, Av = orc.Oflow_lhs_elin4_2d(Ures, Vres, MGd, DuGd, DvGd, wW, wN, wE, wS)
+        fu = ((_c3(RUres) + _c3(Au)) / gd).astype(F32)
+        fv = ((_c3(RVres) + _c3(Av)) / gd).astype(F32)
+        Uc, Vc = fas_cycle(orc, planes, Ures, Vres, fu, fv, scl + 1, param)
+        U, V = fas_prolong_add(U, Uc, Ures, 1.0 / s), fas_prolong_add(V, Vc, Vres, 1.0 / s)
+    return fas_smooth(orc, U, V, pl, Cu, Cv, param)

@@ -69,6 +69,13 @@ SIGNATURES = {
     "pdeip_disp_assemble_dev": [_P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _F, _I, _I, _P, _P],
     "pdeip_add_dev": [_P, _P, _P, _I, _I, _P],
     "pdeip_hs_assemble_dev": [_P, _P, _P, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P],
+    "pdeip_fas_gauss5_dev": [_P, _P, _I, _I, _I, _P, _P],
+    "pdeip_fas_down_dev": [_P, _P, _I, _I, _I, _P],
+    "pdeip_fas_prepare_dev": [_P, _P, _P, _I, _I, _I, _F, _F, _P],
+    "pdeip_fas_assemble_dev": [_P] * 6 + [_I, _I, _I, _F, _F, _F, _I] + [_P] * 6,
+    "pdeip_fas_restrict_dev": [_P, _P, _I, _I, _I, _F, _P],
+    "pdeip_fas_rhs_dev": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "pdeip_fas_prolong_add_dev": [_P, _P, _I, _I, _P, _P, _I, _I, _F],
     "pdeip_flow_opdiffweights_dev": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "pdeip_tv_assemble_dev": [_P, _P, _P, _I, _I, _I, _F] + [_P] * 10,
     "pdeip_median3_dev": [_P, _P, _P, _I, _I, _P],

@@ -16,6 +16,7 @@
 
 #include "pdeip_alr.hpp"
 #include "pdeip_flow.hpp"
+#include "pdeip_fas.hpp"
 #include "pdeip_tv.hpp"
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
@@ -1122,6 +1123,85 @@ extern "C" int pdeip_hs_assemble_dev(void *stream, const float *It0, const float
     RC(check_dims("pdeip_hs_assemble_dev", nrows, ncols, C));
     hipLaunchKernelGGL(k_hs_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), MGd, CuGd, CvGd, DuGd, DvGd,
                        It0, It1, C, b1, b2, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+// ---- FAS full-multigrid driver stages (pdeip_fas.hpp) ----------------------------------------------
+extern "C" int pdeip_fas_gauss5_dev(void *stream, const float *in, int nrows, int ncols, int frames, const float *g25, float *out)
+{
+    RC(check_dims("pdeip_fas_gauss5_dev", nrows, ncols, frames));
+    if (!g25 || in == out) return set_err(PDEIP_ERR_ARG, "pdeip_fas_gauss5_dev: kernel missing or output aliases the input");
+    FasTaps25 T;
+    for (int b = 0; b < 5; ++b)
+        for (int a = 0; a < 5; ++a) T.g[b * 5 + a] = g25[(4 - b) * 5 + (4 - a)]; // 'conv' flips the kernel
+    hipLaunchKernelGGL(k_fas_gauss5, pixel_grid(nrows, ncols, frames), dim3(256), 0, static_cast<hipStream_t>(stream), out, in, T, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_fas_down_dev(void *stream, const float *in, int nrows, int ncols, int frames, float *out)
+{
+    RC(check_dims("pdeip_fas_down_dev", nrows, ncols, frames));
+    const int nr = (nrows + 1) / 2, nc = (ncols + 1) / 2;
+    hipLaunchKernelGGL(k_fas_down, pixel_grid(nr, nc, frames), dim3(256), 0, static_cast<hipStream_t>(stream), out, in, nrows, ncols, nr, nc);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_fas_prepare_dev(void *stream, const float *It0, const float *It1, int nrows, int ncols, int frames, float b1, float b2,
+                                     float *planes)
+{
+    RC(check_dims("pdeip_fas_prepare_dev", nrows, ncols, frames));
+    hipLaunchKernelGGL(k_fas_prepare, pixel_grid(nrows, ncols, frames), dim3(256), 0, static_cast<hipStream_t>(stream), planes, It0, It1, frames,
+                       b1, b2, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_fas_assemble_dev(void *stream, const float *planes, const float *Cu, const float *Cv, const float *U, const float *V,
+                                      int nrows, int ncols, int frames, float b1, float b2, float k, int per_frame, float *MGd, float *CuGd,
+                                      float *CvGd, float *DuGd, float *DvGd, float *gd)
+{
+    RC(check_dims("pdeip_fas_assemble_dev", nrows, ncols, frames));
+    if (!MGd || !DuGd || !DvGd || (Cu && !CuGd) || (Cv && !CvGd))
+        return set_err(PDEIP_ERR_ARG, "pdeip_fas_assemble_dev: missing output plane");
+    const auto s = static_cast<hipStream_t>(stream);
+    if (per_frame)
+        hipLaunchKernelGGL(k_fas_assemble<true>, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, MGd, CuGd, CvGd, DuGd, DvGd, gd, planes, Cu, Cv, U,
+                           V, frames, b1, b2, k, nrows, ncols);
+    else
+        hipLaunchKernelGGL(k_fas_assemble<false>, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, MGd, CuGd, CvGd, DuGd, DvGd, gd, planes, Cu, Cv, U,
+                           V, frames, b1, b2, k, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_fas_restrict_dev(void *stream, const float *in, int nrows, int ncols, int frames, float scale, float *out)
+{
+    RC(check_dims("pdeip_fas_restrict_dev", nrows, ncols, frames));
+    const int nr = (nrows + 1) / 2, nc = (ncols + 1) / 2;
+    hipLaunchKernelGGL(k_fas_restrict, pixel_grid(nr, nc, frames), dim3(256), 0, static_cast<hipStream_t>(stream), out, in, scale, nrows, ncols,
+                       nr, nc);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_fas_rhs_dev(void *stream, const float *R, const float *A, const float *gd, int nrows, int ncols, int frames, float *out)
+{
+    RC(check_dims("pdeip_fas_rhs_dev", nrows, ncols, frames));
+    hipLaunchKernelGGL(k_fas_rhs, pixel_grid(nrows, ncols, frames), dim3(256), 0, static_cast<hipStream_t>(stream), out, R, A, gd, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_fas_prolong_add_dev(void *stream, float *U, int nrows, int ncols, const float *Uc, const float *Ures, int nrows_c,
+                                         int ncols_c, float inv_scale)
+{
+    RC(check_dims("pdeip_fas_prolong_add_dev", nrows, ncols, 1));
+    RC(check_dims("pdeip_fas_prolong_add_dev", nrows_c, ncols_c, 1));
+    hipLaunchKernelGGL(k_fas_prolong_add, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), U, Uc, Ures, inv_scale,
+                       nrows_c, ncols_c, nrows, ncols);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

@@ -116,6 +116,7 @@ __global__ void k_flow_opdiffweights(float *wW, float *wN, float *wS, float *wE,
     // value of field f (0: U+dU, 1: V+dV) at (ii,jj), double
     auto F = [&](int f, int ii, int jj) -> double {
         const size_t p = (size_t)jj * nrows + ii;
+        if (!dU) return (double)(f == 0 ? U[p] : V[p]);                     // OPdiffWeights(U, V) of the early-linearisation drivers
         const float s = (f == 0 ? U[p] : V[p]) + (f == 0 ? dU[p] : dV[p]); // single(U) + single(dU), then double()
         return (double)s;
     };
@@ -193,13 +194,14 @@ __constant__ float HS_D2[5] = {0.232905f, 0.002668f, -0.471147f, 0.002668f, 0.23
 
 struct HsImage { // one channel of one "image" the filters run on: a*P0 (+ b*P1)
     const float *P0, *P1;
-    int mode; // 0: (P0+P1)*0.55   1: P0   2: P1
+    int mode; // 0: (P0+P1)*0.55   1: P0   2: P1   3: (P0+P1)*0.55/255 (the FAS driver's 0..255 frames)
     int nrows, ncols;
     __device__ __forceinline__ float at(int i, int j) const
     {
         i = i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i);
         j = j < 0 ? 0 : (j > ncols - 1 ? ncols - 1 : j);
         const size_t p = (size_t)j * nrows + i;
+        if (mode == 3) return ((P0[p] + P1[p]) * 0.55f) / 255.0f;
         return mode == 0 ? (P0[p] + P1[p]) * 0.55f : (mode == 1 ? P0[p] : P1[p]);
     }
 };

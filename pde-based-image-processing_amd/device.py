@@ -197,9 +197,11 @@ def flow_assemble(term1, term2, dU, dV, alpha, MGd, CuGd, CvGd, DuGd, DvGd):
 
 
 def flow_opdiffweights(U, V, dU, dV, wW, wN, wS, wE):
-    _chk(U, V, dU, dV, wW, wN, wS, wE)
+    """dU = dV = None: OPdiffWeights(U, V)."""
+    _chk(U, V, wW, wN, wS, wE) if dU is None else _chk(U, V, dU, dV, wW, wN, wS, wE)
     nrows, ncols, _ = _dims(U)
-    capi.call("pdeip_flow_opdiffweights_dev", _stream(), *_p(U, V, dU, dV), nrows, ncols, *_p(wW, wN, wS, wE))
+    d = [None, None] if dU is None else _p(dU, dV)
+    capi.call("pdeip_flow_opdiffweights_dev", _stream(), *_p(U, V), *d, nrows, ncols, *_p(wW, wN, wS, wE))
 
 
 def median3(A, B, out):
@@ -242,3 +244,71 @@ def hs_assemble(It0, It1, b1, b2, MGd, CuGd, CvGd, DuGd, DvGd):
     _chk(It0, It1, MGd, CuGd, CvGd, DuGd, DvGd)
     nrows, ncols, C = _dims(It0)
     capi.call("pdeip_hs_assemble_dev", _stream(), *_p(It0, It1), C, float(b1), float(b2), nrows, ncols, *_p(MGd, CuGd, CvGd, DuGd, DvGd))
+
+
+# ---- stages of the FAS full-multigrid flow driver (csrc/pdeip_fas.hpp) ------------------------------------
+
+def _half(n):
+    return (n + 1) // 2
+
+
+def fas_gauss5(I, G):
+    """imfilter(I, G, 'replicate', 'conv'); G: 5x5 numpy kernel."""
+    import numpy as np
+    _chk(I)
+    nrows, ncols, F = _dims(I)
+    g = np.asfortranarray(G, dtype=np.float32)
+    out = torch.empty_like(I)
+    capi.call("pdeip_fas_gauss5_dev", _stream(), I.data_ptr(), nrows, ncols, F, g.ctypes.data, out.data_ptr())
+    return out
+
+
+def fas_down(I):
+    """[C, ncols, nrows] -> [C, ceil(ncols/2), ceil(nrows/2)] (lpf twice, 1:2:end)"""
+    _chk(I)
+    nrows, ncols, F = _dims(I)
+    out = torch.empty(I.shape[:-2] + (_half(ncols), _half(nrows)), dtype=I.dtype, device=I.device)
+    capi.call("pdeip_fas_down_dev", _stream(), I.data_ptr(), nrows, ncols, F, out.data_ptr())
+    return out
+
+
+def fas_prepare(It0, It1, b1, b2):
+    """-> planes [13, C, ncols, nrows]: Idt, Idx, Idy, Idxx, Idyy, Idxy, Idxt, Idyt, M, Cu, Cv, Du, Dv"""
+    _chk(It0, It1)
+    nrows, ncols, F = _dims(It0)
+    planes = torch.empty((13, F, ncols, nrows), dtype=It0.dtype, device=It0.device)
+    capi.call("pdeip_fas_prepare_dev", _stream(), *_p(It0, It1), nrows, ncols, F, float(b1), float(b2), planes.data_ptr())
+    return planes
+
+
+def fas_assemble(planes, Cu, Cv, U, V, b1, b2, k, per_frame, MGd, CuGd, CvGd, DuGd, DvGd, gd=None):
+    _chk(planes, U, V, MGd, DuGd, DvGd)
+    nrows, ncols, _ = _dims(U)
+    F = planes.shape[1]
+    opt = lambda t: None if t is None else (_chk(t), t.data_ptr())[1]
+    capi.call("pdeip_fas_assemble_dev", _stream(), planes.data_ptr(), opt(Cu), opt(Cv), *_p(U, V), nrows, ncols, F, float(b1),
+              float(b2), float(k), int(bool(per_frame)), MGd.data_ptr(), opt(CuGd), opt(CvGd), DuGd.data_ptr(), DvGd.data_ptr(), opt(gd))
+
+
+def fas_restrict(A, scale):
+    _chk(A)
+    nrows, ncols, F = _dims(A)
+    out = torch.empty(A.shape[:-2] + (_half(ncols), _half(nrows)), dtype=A.dtype, device=A.device)
+    capi.call("pdeip_fas_restrict_dev", _stream(), A.data_ptr(), nrows, ncols, F, float(scale), out.data_ptr())
+    return out
+
+
+def fas_rhs(R, A, gd):
+    _chk(R, A, gd)
+    nrows, ncols, F = _dims(R)
+    out = torch.empty_like(R)
+    capi.call("pdeip_fas_rhs_dev", _stream(), *_p(R, A, gd), nrows, ncols, F, out.data_ptr())
+    return out
+
+
+def fas_prolong_add(U, Uc, Ures, inv_scale):
+    """In place on U."""
+    _chk(U, Uc, Ures)
+    nrows, ncols, _ = _dims(U)
+    nrows_c, ncols_c, _ = _dims(Uc)
+    capi.call("pdeip_fas_prolong_add_dev", _stream(), U.data_ptr(), nrows, ncols, *_p(Uc, Ures), nrows_c, ncols_c, float(inv_scale))

@@ -32,26 +32,37 @@ def smooth(I, G=None):
     return out.astype(np.float32).reshape(I.shape)
 
 
-def _resize_matrix(n_in, n_out):
-    """Row-stochastic [n_out, n_in] matrix of a triangle-kernel resize (antialiased when shrinking)."""
+def _cubic(t):
+    """imresize's bicubic kernel (Keys, a = -0.5), support [-2, 2]."""
+    t = abs(t)
+    if t <= 1:
+        return 1.5 * t ** 3 - 2.5 * t ** 2 + 1
+    return -0.5 * t ** 3 + 2.5 * t ** 2 - 4 * t + 2 if t <= 2 else 0.0
+
+
+def _resize_matrix(n_in, n_out, method="bilinear"):
+    """[n_out, n_in] matrix (rows summing to one) of a triangle- or cubic-kernel resize, antialiased when shrinking."""
     scale = n_out / n_in
-    width = 1.0 if scale >= 1 else 1.0 / scale
+    stretch = 1.0 if scale >= 1 else 1.0 / scale
+    support = 1.0 if method == "bilinear" else 2.0
+    kern = (lambda t: max(0.0, 1.0 - abs(t))) if method == "bilinear" else _cubic
+    width = support * stretch
     M = np.zeros((n_out, n_in), dtype=np.float64)
     for o in range(n_out):
         x = (o + 0.5) / scale - 0.5                       # centre of output pixel o in input coordinates
         lo, hi = int(math.floor(x - width)), int(math.ceil(x + width))
         for i in range(lo, hi + 1):
-            w = max(0.0, 1.0 - abs(i - x) / width)
-            if w > 0:
+            w = kern((i - x) / stretch)
+            if w != 0:
                 M[o, min(max(i, 0), n_in - 1)] += w       # replicate at the ends
         M[o] /= M[o].sum()
     return M
 
 
-def resize(I, out_rows, out_cols):
-    """imresize(I, 'bilinear', 'OutputSize', [out_rows out_cols])"""
+def resize(I, out_rows, out_cols, method="bilinear"):
+    """imresize(I, [out_rows out_cols], method); method 'bilinear' or 'bicubic' (imresize's default)"""
     I3 = I if I.ndim == 3 else I[:, :, None]
-    R, C = _resize_matrix(I3.shape[0], out_rows), _resize_matrix(I3.shape[1], out_cols)
+    R, C = _resize_matrix(I3.shape[0], out_rows, method), _resize_matrix(I3.shape[1], out_cols, method)
     out = np.einsum("or,rck->ock", R, I3.astype(np.float64))
     out = np.einsum("pc,ock->opk", C, out)
     return out.astype(np.float32).reshape((out_rows, out_cols) + I.shape[2:])

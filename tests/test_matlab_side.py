@@ -94,3 +94,43 @@ def test_tv_assembly_shapes_and_trace():
     psi = 1.0 / np.sqrt((Iout.astype(np.float64) - Iin) ** 2 + 2.220446049250313e-16)
     assert np.allclose(B, psi * Iin, rtol=1e-5) and np.allclose(TRACE, psi + sum(w), rtol=1e-5)
     assert np.array_equal(w[2][:, :, 0], w[2][:, :, 1])          # repmat over frames
+
+
+def test_fas_transfer_operators():
+    """Full weighting keeps constants (times the scale), halves the size like 1:2:end; the bilinear prolongation of a
+    zero correction is the identity and reproduces a linear ramp away from the edges."""
+    A = np.full((9, 12, 2), 3.0, dtype=np.float32)
+    R = ms.fas_restrict(A, 0.5)
+    assert R.shape == (5, 6, 2) and np.all(R == np.float32(1.5))
+    U = np.asfortranarray(np.random.default_rng(0).random((9, 12)).astype(np.float32))
+    Uc = np.ones((5, 6), dtype=np.float32)
+    assert np.array_equal(ms.fas_prolong_add(U, Uc, Uc, 2.0), U)
+    ramp = np.tile(np.arange(6, dtype=np.float32), (5, 1))
+    out = ms.fas_prolong_add(np.zeros((10, 12), np.float32), ramp, np.zeros_like(ramp), 1.0)
+    np.testing.assert_allclose(out[:, 1:-1], np.tile((np.arange(1, 11) + 0.5) / 2 - 0.5, (10, 1)), rtol=0, atol=1e-6)
+
+
+def test_fas_pyramid_and_constants():
+    rng = np.random.default_rng(1)
+    I0 = np.asfortranarray((rng.random((45, 70)) * 255).astype(np.float32))
+    P0, P1 = ms.fas_pyramid(I0, I0)
+    assert [p.shape[:2] for p in P0] == [(45, 70), (23, 35), (12, 18), (6, 9)]        # stops at the first side <= 10
+    flat = np.full((20, 30), 128.0, dtype=np.float32)
+    assert np.allclose(ms.fas_gauss5(flat, ms.fas_gaussian5(1.0))[:, :, 0], 128.0, atol=1e-4)
+    pl = ms.fas_prepare(P0[1], P1[1], 0.03, 0.97)
+    assert set(pl) == set(ms.FAS_PLANES) and pl["M"].shape == (23, 35, 1)
+    assert np.all(pl["Idt"] == 0) and np.all(pl["Cu"] == 0) and np.all(pl["Idxt"] == 0)   # identical frames: no temporal terms
+    assert np.all(pl["Du"] >= 0) and np.all(pl["Dv"] >= 0)
+
+
+def test_fas_cycle_moves_towards_the_shift(oracle):
+    """Second frame = first shifted by one pixel along x: the cycle at half resolution recovers about half a pixel."""
+    from scipy.ndimage import gaussian_filter
+    I0 = (gaussian_filter(np.random.default_rng(0).random((60, 80)), 2) * 255).astype(np.float32)
+    I1 = np.roll(I0, 1, axis=1)
+    P0, P1 = ms.fas_pyramid(I0, I1)
+    param = dict(alpha=0.035, omega=1.9, firstLoop=4, iter=4, b1=0.03, b2=0.97, scl_factor=0.5, solver=2, cycle_index=1, order=0)
+    planes = [ms.fas_prepare(a, b, 0.03, 0.97) for a, b in zip(P0, P1)]
+    Z = np.zeros(P0[1].shape[:2], dtype=np.float32, order="F")
+    U, V = ms.fas_cycle(oracle, planes, Z, Z.copy(), planes[1]["Cu"], planes[1]["Cv"], 1, param)
+    assert 0.35 < U[5:-5, 5:-5].mean() < 0.6 and abs(V[5:-5, 5:-5].mean()) < 0.05
