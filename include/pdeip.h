@@ -333,6 +333,8 @@ int pdeip_fas_rhs_dev(void *stream, const float *R, const float *A, const float 
 /* U = U + imresize((Uc-Ures)*inv_scale, size(U), 'bilinear') (:256-257); Uc, Ures are [nrows_c x ncols_c] */
 int pdeip_fas_prolong_add_dev(void *stream, float *U, int nrows, int ncols, const float *Uc, const float *Ures, int nrows_c,
                               int ncols_c, float inv_scale);
+/* out = imresize(in.*mul, [nrows_out ncols_out]) with imresize's default bicubic kernel, enlarging (:177-180) */
+int pdeip_fas_upscale_dev(void *stream, const float *in, int nrows, int ncols, float mul, int nrows_out, int ncols_out, float *out);
 /* TVdenoise8's work between two PDEsolver8 calls (matlab/denoising/TVdenoise8.m:80-86 with ADdiffWeights :119-231):
  * the anisotropic weights of Iout (double; Alvarez derivative, strongest frame per pixel, lambda = median of the
  * non-zero squared gradient norms), then TRACE = PsiData + alpha*sum(w), B = PsiData.*Iin with

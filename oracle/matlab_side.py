@@ -465,3 +465,53 @@ def fas_cycle(orc, planes, U, V, Cu, Cv, scl, param):
         Uc, Vc = fas_cycle(orc, planes, Ures, Vres, fu, fv, scl + 1, param)
         U, V = fas_prolong_add(U, Uc, Ures, 1.0 / s), fas_prolong_add(V, Vc, Vres, 1.0 / s)
     return fas_smooth(orc, U, V, pl, Cu, Cv, param)
+
+
+def _cubic(t):
+    t = np.abs(t)
+    t2 = t * t
+    t3 = t2 * t
+    inner = (1.5 * t3 - 2.5 * t2) + 1.0
+    outer = ((-0.5 * t3 + 2.5 * t2) - 4.0 * t) + 2.0
+    return np.where(t <= 1.0, inner, np.where(t <= 2.0, outer, 0.0))
+
+
+def _cubic_axis(n_in, n_out):
+    scale = n_out / n_in
+    x = (np.arange(n_out, dtype=np.float64) + 0.5) / scale - 0.5
+    first = np.floor(x).astype(np.int64) - 1
+    idx = [np.clip(first + t, 0, n_in - 1) for t in range(4)]
+    w = [_cubic(x - (first + t).astype(np.float64)) for t in range(4)]
+    total = ((w[0] + w[1]) + w[2]) + w[3]
+    return idx, [wt / total for wt in w]
+
+
+def fas_upscale(U, mul, nrows_out, ncols_out):
+    """imresize(U.*mul, [nrows_out ncols_out]) of the outer loop (:177-180): bicubic (imresize's default), enlarging;
+    four taps per axis, weights normalised, rows first, then columns, in double, rounded to single once."""
+    D = (U.astype(F32) * F32(mul)).astype(F32).astype(np.float64)
+    ri, rw = _cubic_axis(D.shape[0], nrows_out)
+    ci, cw = _cubic_axis(D.shape[1], ncols_out)
+    T = rw[0][:, None] * D[ri[0], :]
+    for t in range(1, 4):
+        T = T + rw[t][:, None] * D[ri[t], :]
+    R = cw[0][None, :] * T[:, ci[0]]
+    for t in range(1, 4):
+        R = R + cw[t][None, :] * T[:, ci[t]]
+    return np.asfortranarray(R.astype(F32))
+
+
+def fas_fmg(orc, I0, I1, param, max_scales=None):
+    """The whole driver (:104-183): pyramid, constants, one cycle per scale coarse to fine, bicubic up-scaling between."""
+    P0, P1 = fas_pyramid(I0, I1, max_scales)
+    planes = [fas_prepare(a, b, param["b1"], param["b2"]) for a, b in zip(P0, P1)]
+    U = V = None
+    for scl in range(len(planes) - 1, -1, -1):
+        if U is None:
+            U = np.zeros(P0[scl].shape[:2], dtype=F32, order="F")
+            V = U.copy()
+        U, V = fas_cycle(orc, planes, U, V, planes[scl]["Cu"], planes[scl]["Cv"], scl, param)
+        if scl > 0:
+            r, c = P0[scl - 1].shape[:2]
+            U, V = fas_upscale(U, 1.0 / param["scl_factor"], r, c), fas_upscale(V, 1.0 / param["scl_factor"], r, c)
+    return U, V

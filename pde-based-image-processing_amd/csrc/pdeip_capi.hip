@@ -1206,6 +1206,17 @@ extern "C" int pdeip_fas_prolong_add_dev(void *stream, float *U, int nrows, int 
     return PDEIP_OK;
 }
 
+extern "C" int pdeip_fas_upscale_dev(void *stream, const float *in, int nrows, int ncols, float mul, int nrows_out, int ncols_out, float *out)
+{
+    RC(check_dims("pdeip_fas_upscale_dev", nrows, ncols, 1));
+    RC(check_dims("pdeip_fas_upscale_dev", nrows_out, ncols_out, 1));
+    if (nrows_out < nrows || ncols_out < ncols) return set_err(PDEIP_ERR_ARG, "pdeip_fas_upscale_dev: enlarging only");
+    hipLaunchKernelGGL(k_fas_upscale, pixel_grid(nrows_out, ncols_out, 1), dim3(256), 0, static_cast<hipStream_t>(stream), out, in, mul, nrows,
+                       ncols, nrows_out, ncols_out);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, const float *dU, const float *dV, int nrows,
                                             int ncols, float *wW, float *wN, float *wS, float *wE)
 {

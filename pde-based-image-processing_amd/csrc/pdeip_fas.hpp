@@ -192,4 +192,51 @@ __global__ void k_fas_prolong_add(float *U, const float *Uc, const float *Ures, 
     U[pos] = U[pos] + (float)r;
 }
 
+// U = imresize(U.*(1/scl_factor), size_of_the_finer_scale) of the driver's outer loop (:177-180): imresize's default method,
+// bicubic (Keys kernel, a = -0.5), enlarging so not antialiased.  Four taps per axis at MATLAB's pixel-centre alignment,
+// indices clamped, weights divided by their sum as imresize does; rows first, then columns, in double, rounded once.
+__device__ __forceinline__ double fas_cubic(double t)
+{
+    t = fabs(t);
+    const double t2 = t * t, t3 = t2 * t;
+    if (t <= 1.0) return (1.5 * t3 - 2.5 * t2) + 1.0;
+    if (t <= 2.0) return ((-0.5 * t3 + 2.5 * t2) - 4.0 * t) + 2.0;
+    return 0.0;
+}
+
+__device__ __forceinline__ void fas_cubic_axis(int o, int n_in, int n_out, int idx[4], double w[4])
+{
+    const double scale = (double)n_out / (double)n_in;
+    const double x = ((double)o + 0.5) / scale - 0.5;
+    const int first = (int)floor(x) - 1;
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        w[t] = fas_cubic(x - (double)(first + t));
+        sum = t ? sum + w[t] : w[t];
+        idx[t] = min(max(first + t, 0), n_in - 1);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w[t] = w[t] / sum;
+}
+
+__global__ void k_fas_upscale(float *out, const float *in, float mul, int nrows_in, int ncols_in, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    int ri[4], ci[4];
+    double rw[4], cw[4];
+    fas_cubic_axis(i, nrows_in, nrows, ri, rw);
+    fas_cubic_axis(j, ncols_in, ncols, ci, cw);
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float *col = in + (size_t)ci[c] * nrows_in;
+        double t = rw[0] * (double)(col[ri[0]] * mul);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) t = t + rw[r] * (double)(col[ri[r]] * mul);
+        acc = c ? acc + cw[c] * t : cw[c] * t;
+    }
+    out[pos] = (float)acc;
+}
+
 } // namespace pdeip

@@ -312,3 +312,12 @@ def fas_prolong_add(U, Uc, Ures, inv_scale):
     nrows, ncols, _ = _dims(U)
     nrows_c, ncols_c, _ = _dims(Uc)
     capi.call("pdeip_fas_prolong_add_dev", _stream(), U.data_ptr(), nrows, ncols, *_p(Uc, Ures), nrows_c, ncols_c, float(inv_scale))
+
+
+def fas_upscale(U, mul, nrows_out, ncols_out):
+    """imresize(U.*mul, [nrows_out ncols_out]) (bicubic, enlarging) -> new [ncols_out, nrows_out] plane"""
+    _chk(U)
+    nrows, ncols, _ = _dims(U)
+    out = torch.empty((ncols_out, nrows_out), dtype=U.dtype, device=U.device)
+    capi.call("pdeip_fas_upscale_dev", _stream(), U.data_ptr(), nrows, ncols, float(mul), nrows_out, ncols_out, out.data_ptr())
+    return out

@@ -7,16 +7,16 @@ Oflow_sor_elin4_2d]; residuals through the solver's residual operator, coarse ri
 Oflow_lhs_elin4_2d, full-weighting restriction, bilinear prolongation of the correction.
 
 Every stage is a kernel of libpdeip.so (csrc/pdeip_fas.hpp + the solver / residual / LHS kernels); the recursion
-is host control flow only and nothing crosses PCIe inside `run` except the flow between two scales of the
-outer loop, which the MATLAB code up-scales with imresize's default (bicubic) method -- done on the host by
-pyramid.resize(..., method="bicubic"), our own definition of that IPT call like the rest of pyramid.py.
+is host control flow only and nothing crosses PCIe inside `run`, the bicubic up-scaling of the flow between two
+scales of the outer loop (imresize's default method, :177-180) included.  The IPT calls (imfilter, imresize) are
+restated by their documented meaning with our own summation order, see the kernels.
 
 Planes are torch float32 CUDA tensors [C, ncols, nrows] / [ncols, nrows] (device.to_device).
 """
 import numpy as np
 import torch
 
-from . import capi, device as dev, pyramid
+from . import capi, device as dev
 
 IDT, IDX, IDY, IDXX, IDYY, IDXY, IDXT, IDYT, M, CU, CV, DU, DV = range(13)   # plane order of fas_prepare
 
@@ -116,6 +116,5 @@ class FasFmgFlow:
             U, V = self.cycle(scl, U, V)
             if scl > 0:
                 nc, nr = self.planes[scl - 1].shape[-2:]
-                U, V = [dev.to_device(pyramid.resize(dev.to_matlab(t) * np.float32(1.0 / self.p["scl_factor"]), nr, nc, method="bicubic"),
-                                      I0.device) for t in (U, V)]
+                U, V = [dev.fas_upscale(t, 1.0 / self.p["scl_factor"], nr, nc) for t in (U, V)]
         return U, V

@@ -65,22 +65,13 @@ def test_stages(pdeip, shape, C):
     got = dU.clone()
     dev.fas_prolong_add(got, dev.to_device(Uc), dev.to_device(Ur), 2.0)
     same(dev.to_matlab(got), ms.fas_prolong_add(U, Uc, Ur, 2.0), "prolongation %s" % (shape,))
+    for out_shape in ((2 * cs[0], 2 * cs[1]), (2 * cs[0] - 1, 2 * cs[1] - 1), (cs[0] + 3, 3 * cs[1])):
+        up = dev.fas_upscale(dev.to_device(Uc), 2.0, *out_shape)
+        same(dev.to_matlab(up), ms.fas_upscale(Uc, 2.0, *out_shape), "bicubic upscale %s -> %s" % (cs, out_shape))
 
 
 def statement_fmg(ms, py, oracle, I0, I1, param, max_scales=None):
-    P0, P1 = ms.fas_pyramid(I0, I1, max_scales)
-    planes = [ms.fas_prepare(a, b, param["b1"], param["b2"]) for a, b in zip(P0, P1)]
-    U = V = None
-    for scl in range(len(planes) - 1, -1, -1):
-        if U is None:
-            U = np.zeros(P0[scl].shape[:2], dtype=np.float32, order="F")
-            V = U.copy()
-        U, V = ms.fas_cycle(oracle, planes, U, V, planes[scl]["Cu"], planes[scl]["Cv"], scl, param)
-        if scl > 0:
-            r, c = P0[scl - 1].shape[:2]
-            inv = np.float32(1.0 / param["scl_factor"])
-            U, V = py.resize(U * inv, r, c, method="bicubic"), py.resize(V * inv, r, c, method="bicubic")
-    return U, V
+    return ms.fas_fmg(oracle, I0, I1, param, max_scales)
 
 
 @pytest.mark.parametrize("solver,mode,order,omega,cycle_index,C",
