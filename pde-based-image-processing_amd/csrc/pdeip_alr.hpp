@@ -968,6 +968,299 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra2(typename Mdl::Ctx q, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_alr_zebra3: the APPLY pass of k_alr_zebra2 with the solver wave's instruction count cut to the bone.
+//
+// With the movers disabled-in-reverse (solver switched off) a 4K colour pass takes 70-100 us; with the
+// solver on, 150-270 us: the one wave that runs the recurrences is bound by instruction ISSUE (a wave gets
+// one issue slot every ~4 cycles), and k_alr_zebra2 spends ~9 instructions per element there: element-wise
+// (a,div,cp,d) rows read one dword pair at a time, per-sub-block scalar bookkeeping, the SOR blend.  Here
+//   * a tile keeps each line as three rows of 32 floats (a | divisor | d->dp going down, old x | cp | dp->x
+//     coming back), so the solver moves four elements per ds_read_b128 / ds_write_b128;
+//   * the SOR blend moves to the movers (they hold old x and get the raw x from LDS);
+//   * rounds that contain neither end of the line run a branch-free body, one tile (32 elements) per
+//     loop trip;
+// which leaves 4 instructions per element going down (3 of them the dependent mul-sub-mul) and 2.75 coming
+// back.  Arithmetic, operand order and results are those of k_alr_zebra2 (bit-identical).
+// ------------------------------------------------------------------------------------------------
+constexpr int Z3_LSF = 3 * ZB_TE + 4;              // floats per line of a tile; +4 keeps the 16 lines' b128 reads on distinct banks
+constexpr int Z3_TILE = ZB_LW * Z3_LSF;            // floats per tile
+constexpr size_t Z3_LDS_BYTES = (size_t)2 * ZB_NM * Z3_TILE * sizeof(float);
+
+template <class Mdl, bool VERT>
+__global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, float *x, const float *__restrict__ cp,
+                                                           const float *__restrict__ dv, float *__restrict__ dp, int nrows, int ncols,
+                                                           size_t frame_stride, int first, int lastc, int lstep, float omega)
+{
+    extern __shared__ float z3_lds[]; // [2][ZB_NM][Z3_TILE]
+    const size_t fo = (size_t)blockIdx.y * frame_stride;
+    q.shift(fo);
+    x += fo;
+    cp += fo;
+    dv += fo;
+    dp += fo;
+    const int n = VERT ? nrows : ncols, nlines = VERT ? ncols : nrows;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int line0 = first + lstep * ZB_LW * (int)blockIdx.x;
+    const float om1 = 1.0f - omega;
+    constexpr int RE = ZB_NM * ZB_TE, TE = ZB_TE;
+    const int nrounds = (n + RE - 1) / RE;
+    const int mslot = wave - 1;
+    const int mg = lane % ZB_GP, ml = lane / ZB_GP;
+    auto tile_of = [&](int buf, int slot) __attribute__((always_inline)) { return z3_lds + ((size_t)buf * ZB_NM + slot) * Z3_TILE; };
+    auto lds_st4 = [](float *p, float a, float b, float c, float d) __attribute__((always_inline)) { *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d); };
+    auto lds_ld4 = [](const float *p, float (&v)[4]) __attribute__((always_inline)) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    };
+
+    // ---- movers ---------------------------------------------------------------------------------
+    auto produce = [&](int r, int buf) __attribute__((always_inline)) { // operands of round r, slot mslot -> rows a | divisor | d
+        const int k0 = (r * ZB_NM + mslot) * TE;
+        if (k0 >= n) return;
+        float *T = tile_of(buf, mslot);
+        if (k0 + TE - 1 <= n - 1) {
+            Tri t[ZB_NP][4];
+            float fd[ZB_NP][4];
+#pragma unroll
+            for (int rr = 0; rr < ZB_NP; ++rr) {
+                const int l = min(line0 + lstep * (ml + ZB_LP * rr), lastc);
+                Mdl::template coef4<VERT>(q, l, k0 + 4 * mg, n, nlines, t[rr]);
+                alr_ld4(dv + (size_t)l * n + k0 + 4 * mg, fd[rr]);
+            }
+#pragma unroll
+            for (int rr = 0; rr < ZB_NP; ++rr) {
+                float *row = T + (ml + ZB_LP * rr) * Z3_LSF + 4 * mg;
+                lds_st4(row, t[rr][0].a, t[rr][1].a, t[rr][2].a, t[rr][3].a);
+                lds_st4(row + TE, fd[rr][0], fd[rr][1], fd[rr][2], fd[rr][3]);
+                lds_st4(row + 2 * TE, t[rr][0].d, t[rr][1].d, t[rr][2].d, t[rr][3].d);
+            }
+            return;
+        }
+#pragma unroll
+        for (int rr = 0; rr < ZB_NP; ++rr) {
+            const int L = ml + ZB_LP * rr, k = k0 + 4 * mg;
+            const int l = min(line0 + lstep * L, lastc);
+            float *row = T + L * Z3_LSF + 4 * mg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e <= n - 1) {
+                    const Tri t = Mdl::template coef<VERT>(q, AlrAt(l, k + e, n, nlines));
+                    row[e] = t.a;
+                    row[TE + e] = dv[(size_t)l * n + k + e];
+                    row[2 * TE + e] = t.d;
+                }
+        }
+    };
+    auto load_bwd = [&](int r, int buf) __attribute__((always_inline)) { // rows old x | cp | dp of round r
+        const int k0 = (r * ZB_NM + mslot) * TE;
+        if (k0 >= n) return;
+        float *T = tile_of(buf, mslot);
+        if (k0 + TE - 1 <= n - 1) {
+            float c[ZB_NP][4], d[ZB_NP][4], o[ZB_NP][4];
+#pragma unroll
+            for (int rr = 0; rr < ZB_NP; ++rr) {
+                const size_t pos = (size_t)min(line0 + lstep * (ml + ZB_LP * rr), lastc) * n + k0 + 4 * mg;
+                alr_ld4(cp + pos, c[rr]); alr_ld4(dp + pos, d[rr]); alr_ld4(x + pos, o[rr]);
+            }
+#pragma unroll
+            for (int rr = 0; rr < ZB_NP; ++rr) {
+                float *row = T + (ml + ZB_LP * rr) * Z3_LSF + 4 * mg;
+                lds_st4(row, o[rr][0], o[rr][1], o[rr][2], o[rr][3]);
+                lds_st4(row + TE, c[rr][0], c[rr][1], c[rr][2], c[rr][3]);
+                lds_st4(row + 2 * TE, d[rr][0], d[rr][1], d[rr][2], d[rr][3]);
+            }
+            return;
+        }
+#pragma unroll
+        for (int rr = 0; rr < ZB_NP; ++rr) {
+            const int L = ml + ZB_LP * rr, k = k0 + 4 * mg;
+            const size_t pos = (size_t)min(line0 + lstep * L, lastc) * n + min(k, n - 1);
+            float *row = T + L * Z3_LSF + 4 * mg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e <= n - 1) {
+                    row[e] = x[pos + e];
+                    row[TE + e] = cp[pos + e];
+                    row[2 * TE + e] = dp[pos + e];
+                }
+        }
+    };
+    // results of a finished tile: into registers first (the tile is about to be refilled), to global after the
+    // next tile's loads have been consumed.  Going down: dp.  Coming back: the blended x (:1951-1958).
+    float res[ZB_NP][4];
+    auto grab = [&](int buf, bool fwd) __attribute__((always_inline)) {
+        const float *T = tile_of(buf, mslot);
+#pragma unroll
+        for (int rr = 0; rr < ZB_NP; ++rr) {
+            const float *row = T + (ml + ZB_LP * rr) * Z3_LSF + 4 * mg;
+            lds_ld4(row + 2 * TE, res[rr]);
+            if (!fwd) {
+                float old[4];
+                lds_ld4(row, old);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) res[rr][e] = omega * res[rr][e] + om1 * old[e];
+            }
+        }
+    };
+    auto put = [&](int r, bool fwd) __attribute__((always_inline)) {
+        const int k0 = (r * ZB_NM + mslot) * TE;
+        float *out = fwd ? dp : x;
+#pragma unroll
+        for (int rr = 0; rr < ZB_NP; ++rr) {
+            const int k = k0 + 4 * mg;
+            const int l = line0 + lstep * (ml + ZB_LP * rr);
+            const size_t pos = (size_t)min(l, lastc) * n + min(k, n - 1);
+            if (l <= lastc && k + 3 <= n - 1) {
+                alr_st4(out + pos, res[rr][0], res[rr][1], res[rr][2], res[rr][3]);
+            } else if (l <= lastc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e <= n - 1) out[pos + e] = res[rr][e];
+            }
+        }
+    };
+    auto lds_barrier = [&]() __attribute__((always_inline)) { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- solver ---------------------------------------------------------------------------------
+    const bool solver = wave == 0 && lane < ZB_LW;
+    auto ld8 = [&](const float *p, float (&v)[8]) __attribute__((always_inline)) {
+        const float4 lo = *reinterpret_cast<const float4 *>(p), hi = *reinterpret_cast<const float4 *>(p + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+    auto st8 = [&](float *p, const float (&v)[8]) __attribute__((always_inline)) {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    };
+
+    // going down (opticalflowSolvers.c:1890-1950): dp_k = (d_k - dp_{k-1} a_k) * divisor_k
+    float dpv = 0.0f;
+    if (wave > 0) produce(0, 0);
+    lds_barrier();
+    for (int r = 0; r < nrounds; ++r) {
+        if (solver) {
+            float *P = tile_of(r & 1, 0) + lane * Z3_LSF;
+            const int kr = __builtin_amdgcn_readfirstlane(r * RE);
+            if (kr >= 1 && kr + RE - 1 <= n - 2) { // neither end of the line in this round
+                float a0[8], v0[8], d0[8], a1[8], v1[8], d1[8];
+                ld8(P, a0); ld8(P + TE, v0); ld8(P + 2 * TE, d0);
+#pragma unroll 1
+                for (int s = 0; s < ZB_NM; ++s) {
+                    float *Q = P + s * Z3_TILE;
+                    const float *N = P + min(s + 1, ZB_NM - 1) * Z3_TILE;
+#pragma unroll
+                    for (int h = 0; h < ZB_TE / 16; ++h) {
+                        const bool last = h == ZB_TE / 16 - 1;
+                        ld8(Q + 16 * h + 8, a1); ld8(Q + 16 * h + 8 + TE, v1); ld8(Q + 16 * h + 8 + 2 * TE, d1);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            dpv = (d0[e] - dpv * a0[e]) * v0[e];
+                            d0[e] = dpv;
+                        }
+                        st8(Q + 16 * h + 2 * TE, d0);
+                        const float *F = last ? N : Q + 16 * (h + 1);
+                        ld8(F, a0); ld8(F + TE, v0); ld8(F + 2 * TE, d0);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            dpv = (d1[e] - dpv * a1[e]) * v1[e];
+                            d1[e] = dpv;
+                        }
+                        st8(Q + 16 * h + 8 + 2 * TE, d1);
+                    }
+                }
+            } else { // first and last round: the first element is divided by b, the last by its bare denominator
+#pragma unroll 1
+                for (int j = 0; j < RE / 8; ++j) {
+                    const int k0 = kr + 8 * j;
+                    if (k0 > n - 1) break;
+                    float *Q = P + (j / (TE / 8)) * Z3_TILE + (j % (TE / 8)) * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = k0 + e; // wave-uniform
+                        if (k <= n - 1) {
+                            const float a = Q[e], v = Q[TE + e], d = Q[2 * TE + e];
+                            if (k == 0) dpv = d / v;
+                            else if (k == n - 1) dpv = (d - dpv * a) / v;
+                            else dpv = (d - dpv * a) * v;
+                            Q[2 * TE + e] = dpv;
+                        }
+                    }
+                }
+            }
+        } else if (wave > 0) {
+            if (r >= 1) grab((r - 1) & 1, true);
+            if (r + 1 < nrounds) produce(r + 1, (r + 1) & 1);
+            if (r >= 1) put(r - 1, true);
+        }
+        lds_barrier();
+    }
+    if (wave > 0) {
+        grab((nrounds - 1) & 1, true);
+        put(nrounds - 1, true);
+        __threadfence_block(); // every dp this thread reloads below was stored by this thread: drain them once
+        load_bwd(nrounds - 1, (nrounds - 1) & 1);
+    }
+    lds_barrier();
+
+    // coming back: x_k = dp_k - cp_k x_{k+1} (cp of the last element is 0); the blend is the movers' (grab)
+    float xs = 0.0f;
+    for (int r = nrounds - 1; r >= 0; --r) {
+        if (solver) {
+            float *P = tile_of(r & 1, 0) + lane * Z3_LSF;
+            const int kr = __builtin_amdgcn_readfirstlane(r * RE);
+            if (kr + RE - 1 <= n - 1) {
+                float c0[8], d0[8], c1[8], d1[8];
+                ld8(P + (ZB_NM - 1) * Z3_TILE + TE - 8 + TE, c0); ld8(P + (ZB_NM - 1) * Z3_TILE + TE - 8 + 2 * TE, d0);
+#pragma unroll 1
+                for (int s = ZB_NM - 1; s >= 0; --s) {
+                    float *Q = P + s * Z3_TILE;
+                    const float *N = P + max(s - 1, 0) * Z3_TILE + TE - 8;
+#pragma unroll
+                    for (int h = ZB_TE / 16 - 1; h >= 0; --h) {
+                        ld8(Q + 16 * h + TE, c1); ld8(Q + 16 * h + 2 * TE, d1);
+#pragma unroll
+                        for (int e = 7; e >= 0; --e) {
+                            xs = d0[e] - c0[e] * xs;
+                            d0[e] = xs;
+                        }
+                        st8(Q + 16 * h + 8 + 2 * TE, d0);
+                        const float *F = h == 0 ? N : Q + 16 * (h - 1) + 8;
+                        ld8(F + TE, c0); ld8(F + 2 * TE, d0);
+#pragma unroll
+                        for (int e = 7; e >= 0; --e) {
+                            xs = d1[e] - c1[e] * xs;
+                            d1[e] = xs;
+                        }
+                        st8(Q + 16 * h + 2 * TE, d1);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int j = RE / 8 - 1; j >= 0; --j) {
+                    const int k0 = kr + 8 * j;
+                    if (k0 > n - 1) continue;
+                    float *Q = P + (j / (TE / 8)) * Z3_TILE + (j % (TE / 8)) * 8;
+#pragma unroll
+                    for (int e = 7; e >= 0; --e)
+                        if (k0 + e <= n - 1) { // wave-uniform
+                            xs = Q[2 * TE + e] - Q[TE + e] * xs;
+                            Q[2 * TE + e] = xs;
+                        }
+                }
+            }
+        } else if (wave > 0) {
+            if (r + 1 <= nrounds - 1) grab((r + 1) & 1, false);
+            if (r - 1 >= 0) load_bwd(r - 1, (r - 1) & 1);
+            if (r + 1 <= nrounds - 1) put(r + 1, false);
+        }
+        lds_barrier();
+    }
+    if (wave > 0) {
+        grab(0, false);
+        put(0, false);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Reference line order.
 //
 // cp[k] = c/(b - cp[k-1] a) depends on the coefficient planes only, not on the iterate, so it is the same

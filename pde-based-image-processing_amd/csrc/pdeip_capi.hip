@@ -716,6 +716,28 @@ static int zebra2_launch(hipStream_t s, const typename Mdl::Ctx &q, float *x, fl
     return PDEIP_OK;
 }
 
+// the APPLY pass: k_alr_zebra3 unless PDEIP_ALR_ZEBRA2 asks for the older kernel (same results)
+template <class Mdl, bool VERT>
+static int zebra_apply_launch(hipStream_t s, const typename Mdl::Ctx &q, float *x, const float *cp, const float *dv, float *dp, int nrows,
+                              int ncols, int nframes, int first, int lastc, int lstep, float omega)
+{
+    static const bool old = getenv("PDEIP_ALR_ZEBRA2") != nullptr;
+    if (old)
+        return zebra2_launch<Mdl, VERT, ZB_APPLY>(s, q, x, const_cast<float *>(cp), const_cast<float *>(dv), dp, nrows, ncols, nframes, first,
+                                                  lastc, lstep, omega);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_alr_zebra3<Mdl, VERT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z3_LDS_BYTES));
+        attr_set = true;
+    }
+    const int count = (lastc - first) / lstep + 1;
+    hipLaunchKernelGGL((k_alr_zebra3<Mdl, VERT>), dim3((unsigned)((count + ZB_LW - 1) / ZB_LW), (unsigned)nframes), dim3(ZB_THREADS), Z3_LDS_BYTES, s,
+                       q, x, cp, dv, dp, nrows, ncols, (size_t)nrows * ncols, first, lastc, lstep, omega);
+    g.last_launches++;
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 // cp and divisor planes of every (field, direction): the part of the Thomas recurrence that depends on the
 // coefficient planes only, once per call (pdeip_alr.hpp).  Column planes from q, row planes from the transposed qt.
 template <class Mdl>
@@ -798,8 +820,8 @@ static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, c
         const int lastc = hi - (((hi & 1) != colour) ? 1 : 0);
         {
             if (cpf) {
-                if (vertical) RC((zebra2_launch<Mdl, true, ZB_APPLY>(s, q, x, const_cast<float *>(cpf), const_cast<float *>(dvf), dp, nrows, ncols, nframes, first, lastc, 2, omega)));
-                else RC((zebra2_launch<Mdl, false, ZB_APPLY>(s, q, x, const_cast<float *>(cpf), const_cast<float *>(dvf), dp, nrows, ncols, nframes, first, lastc, 2, omega)));
+                if (vertical) RC((zebra_apply_launch<Mdl, true>(s, q, x, cpf, dvf, dp, nrows, ncols, nframes, first, lastc, 2, omega)));
+                else RC((zebra_apply_launch<Mdl, false>(s, q, x, cpf, dvf, dp, nrows, ncols, nframes, first, lastc, 2, omega)));
                 continue;
             }
         }
