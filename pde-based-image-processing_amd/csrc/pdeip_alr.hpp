@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(64) k_alr_zebra(typename Mdl::Ctx q, float *x,
 // instead of 30.  Arithmetic and operand order are those of k_alr_zebra (bit-identical).
 // ------------------------------------------------------------------------------------------------
 constexpr int ZB_NM = 7;                        // mover waves = tiles per round
-constexpr int ZB_LW = 16;                       // lines per workgroup
+constexpr int ZB_LW = 8;                        // lines per workgroup
 constexpr int ZB_TE = 32;                       // elements per tile
 constexpr int ZB_SB = 8;                        // elements the solver holds in registers at a time
 constexpr int ZB_GP = ZB_TE / 4;                // 4-element groups per line of a tile
@@ -1132,60 +1132,67 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
         *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
     };
 
-    // going down (opticalflowSolvers.c:1890-1950): dp_k = (d_k - dp_{k-1} a_k) * divisor_k
+    // going down (opticalflowSolvers.c:1890-1950): dp_k = (d_k - dp_{k-1} a_k) * divisor_k; the first element is divided
+    // by b, the last by its bare denominator.  Tiles that hold neither end of the line take the branch-free body.
     float dpv = 0.0f;
+    auto fwd_edge = [&](float *P, int kr, int s0, int s1) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (int j = s0 * (TE / 8); j < s1 * (TE / 8); ++j) {
+            const int k0 = kr + 8 * j;
+            if (k0 > n - 1) break;
+            float *Q = P + (j / (TE / 8)) * Z3_TILE + (j % (TE / 8)) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e; // wave-uniform
+                if (k <= n - 1) {
+                    const float a = Q[e], v = Q[TE + e], d = Q[2 * TE + e];
+                    if (k == 0) dpv = d / v;
+                    else if (k == n - 1) dpv = (d - dpv * a) / v;
+                    else dpv = (d - dpv * a) * v;
+                    Q[2 * TE + e] = dpv;
+                }
+            }
+        }
+    };
+    auto fwd_fast = [&](float *P, int s0, int s1) __attribute__((always_inline)) {
+        if (s0 >= s1) return;
+        float a0[8], v0[8], d0[8], a1[8], v1[8], d1[8];
+        ld8(P + s0 * Z3_TILE, a0); ld8(P + s0 * Z3_TILE + TE, v0); ld8(P + s0 * Z3_TILE + 2 * TE, d0);
+#pragma unroll 1
+        for (int s = s0; s < s1; ++s) {
+            float *Q = P + s * Z3_TILE;
+            const float *N = P + min(s + 1, s1 - 1) * Z3_TILE;
+#pragma unroll
+            for (int h = 0; h < TE / 16; ++h) {
+                ld8(Q + 16 * h + 8, a1); ld8(Q + 16 * h + 8 + TE, v1); ld8(Q + 16 * h + 8 + 2 * TE, d1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    dpv = (d0[e] - dpv * a0[e]) * v0[e];
+                    d0[e] = dpv;
+                }
+                st8(Q + 16 * h + 2 * TE, d0);
+                const float *F = h == TE / 16 - 1 ? N : Q + 16 * (h + 1);
+                ld8(F, a0); ld8(F + TE, v0); ld8(F + 2 * TE, d0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    dpv = (d1[e] - dpv * a1[e]) * v1[e];
+                    d1[e] = dpv;
+                }
+                st8(Q + 16 * h + 8 + 2 * TE, d1);
+            }
+        }
+    };
     if (wave > 0) produce(0, 0);
     lds_barrier();
     for (int r = 0; r < nrounds; ++r) {
         if (solver) {
             float *P = tile_of(r & 1, 0) + lane * Z3_LSF;
             const int kr = __builtin_amdgcn_readfirstlane(r * RE);
-            if (kr >= 1 && kr + RE - 1 <= n - 2) { // neither end of the line in this round
-                float a0[8], v0[8], d0[8], a1[8], v1[8], d1[8];
-                ld8(P, a0); ld8(P + TE, v0); ld8(P + 2 * TE, d0);
-#pragma unroll 1
-                for (int s = 0; s < ZB_NM; ++s) {
-                    float *Q = P + s * Z3_TILE;
-                    const float *N = P + min(s + 1, ZB_NM - 1) * Z3_TILE;
-#pragma unroll
-                    for (int h = 0; h < ZB_TE / 16; ++h) {
-                        const bool last = h == ZB_TE / 16 - 1;
-                        ld8(Q + 16 * h + 8, a1); ld8(Q + 16 * h + 8 + TE, v1); ld8(Q + 16 * h + 8 + 2 * TE, d1);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            dpv = (d0[e] - dpv * a0[e]) * v0[e];
-                            d0[e] = dpv;
-                        }
-                        st8(Q + 16 * h + 2 * TE, d0);
-                        const float *F = last ? N : Q + 16 * (h + 1);
-                        ld8(F, a0); ld8(F + TE, v0); ld8(F + 2 * TE, d0);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            dpv = (d1[e] - dpv * a1[e]) * v1[e];
-                            d1[e] = dpv;
-                        }
-                        st8(Q + 16 * h + 8 + 2 * TE, d1);
-                    }
-                }
-            } else { // first and last round: the first element is divided by b, the last by its bare denominator
-#pragma unroll 1
-                for (int j = 0; j < RE / 8; ++j) {
-                    const int k0 = kr + 8 * j;
-                    if (k0 > n - 1) break;
-                    float *Q = P + (j / (TE / 8)) * Z3_TILE + (j % (TE / 8)) * 8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int k = k0 + e; // wave-uniform
-                        if (k <= n - 1) {
-                            const float a = Q[e], v = Q[TE + e], d = Q[2 * TE + e];
-                            if (k == 0) dpv = d / v;
-                            else if (k == n - 1) dpv = (d - dpv * a) / v;
-                            else dpv = (d - dpv * a) * v;
-                            Q[2 * TE + e] = dpv;
-                        }
-                    }
-                }
-            }
+            const int s0 = kr == 0 ? 1 : 0;                                   // tile 0 of round 0 holds the first element
+            const int s1 = max(s0, min(ZB_NM, (n - 1 - kr) / TE));            // tiles [s0, s1) end at or before element n-2
+            fwd_edge(P, kr, 0, s0);
+            fwd_fast(P, s0, s1);
+            fwd_edge(P, kr, s1, ZB_NM);
         } else if (wave > 0) {
             if (r >= 1) grab((r - 1) & 1, true);
             if (r + 1 < nrounds) produce(r + 1, (r + 1) & 1);
@@ -1203,50 +1210,55 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
 
     // coming back: x_k = dp_k - cp_k x_{k+1} (cp of the last element is 0); the blend is the movers' (grab)
     float xs = 0.0f;
+    auto bwd_edge = [&](float *P, int kr, int s0, int s1) __attribute__((always_inline)) { // tiles s1-1 down to s0
+#pragma unroll 1
+        for (int j = s1 * (TE / 8) - 1; j >= s0 * (TE / 8); --j) {
+            const int k0 = kr + 8 * j;
+            if (k0 > n - 1) continue;
+            float *Q = P + (j / (TE / 8)) * Z3_TILE + (j % (TE / 8)) * 8;
+#pragma unroll
+            for (int e = 7; e >= 0; --e)
+                if (k0 + e <= n - 1) { // wave-uniform
+                    xs = Q[2 * TE + e] - Q[TE + e] * xs;
+                    Q[2 * TE + e] = xs;
+                }
+        }
+    };
+    auto bwd_fast = [&](float *P, int s1) __attribute__((always_inline)) { // tiles s1-1 down to 0, all inside the line
+        if (s1 <= 0) return;
+        float c0[8], d0[8], c1[8], d1[8];
+        ld8(P + (s1 - 1) * Z3_TILE + TE - 8 + TE, c0); ld8(P + (s1 - 1) * Z3_TILE + TE - 8 + 2 * TE, d0);
+#pragma unroll 1
+        for (int s = s1 - 1; s >= 0; --s) {
+            float *Q = P + s * Z3_TILE;
+            const float *N = P + max(s - 1, 0) * Z3_TILE + TE - 8;
+#pragma unroll
+            for (int h = TE / 16 - 1; h >= 0; --h) {
+                ld8(Q + 16 * h + TE, c1); ld8(Q + 16 * h + 2 * TE, d1);
+#pragma unroll
+                for (int e = 7; e >= 0; --e) {
+                    xs = d0[e] - c0[e] * xs;
+                    d0[e] = xs;
+                }
+                st8(Q + 16 * h + 8 + 2 * TE, d0);
+                const float *F = h == 0 ? N : Q + 16 * (h - 1) + 8;
+                ld8(F + TE, c0); ld8(F + 2 * TE, d0);
+#pragma unroll
+                for (int e = 7; e >= 0; --e) {
+                    xs = d1[e] - c1[e] * xs;
+                    d1[e] = xs;
+                }
+                st8(Q + 16 * h + 2 * TE, d1);
+            }
+        }
+    };
     for (int r = nrounds - 1; r >= 0; --r) {
         if (solver) {
             float *P = tile_of(r & 1, 0) + lane * Z3_LSF;
             const int kr = __builtin_amdgcn_readfirstlane(r * RE);
-            if (kr + RE - 1 <= n - 1) {
-                float c0[8], d0[8], c1[8], d1[8];
-                ld8(P + (ZB_NM - 1) * Z3_TILE + TE - 8 + TE, c0); ld8(P + (ZB_NM - 1) * Z3_TILE + TE - 8 + 2 * TE, d0);
-#pragma unroll 1
-                for (int s = ZB_NM - 1; s >= 0; --s) {
-                    float *Q = P + s * Z3_TILE;
-                    const float *N = P + max(s - 1, 0) * Z3_TILE + TE - 8;
-#pragma unroll
-                    for (int h = ZB_TE / 16 - 1; h >= 0; --h) {
-                        ld8(Q + 16 * h + TE, c1); ld8(Q + 16 * h + 2 * TE, d1);
-#pragma unroll
-                        for (int e = 7; e >= 0; --e) {
-                            xs = d0[e] - c0[e] * xs;
-                            d0[e] = xs;
-                        }
-                        st8(Q + 16 * h + 8 + 2 * TE, d0);
-                        const float *F = h == 0 ? N : Q + 16 * (h - 1) + 8;
-                        ld8(F + TE, c0); ld8(F + 2 * TE, d0);
-#pragma unroll
-                        for (int e = 7; e >= 0; --e) {
-                            xs = d1[e] - c1[e] * xs;
-                            d1[e] = xs;
-                        }
-                        st8(Q + 16 * h + 2 * TE, d1);
-                    }
-                }
-            } else {
-#pragma unroll 1
-                for (int j = RE / 8 - 1; j >= 0; --j) {
-                    const int k0 = kr + 8 * j;
-                    if (k0 > n - 1) continue;
-                    float *Q = P + (j / (TE / 8)) * Z3_TILE + (j % (TE / 8)) * 8;
-#pragma unroll
-                    for (int e = 7; e >= 0; --e)
-                        if (k0 + e <= n - 1) { // wave-uniform
-                            xs = Q[2 * TE + e] - Q[TE + e] * xs;
-                            Q[2 * TE + e] = xs;
-                        }
-                }
-            }
+            const int s1 = min(ZB_NM, (n - kr) / TE);                         // tiles [0, s1) lie wholly inside the line
+            bwd_edge(P, kr, s1, ZB_NM);
+            bwd_fast(P, s1);
         } else if (wave > 0) {
             if (r + 1 <= nrounds - 1) grab((r + 1) & 1, false);
             if (r - 1 >= 0) load_bwd(r - 1, (r - 1) & 1);
