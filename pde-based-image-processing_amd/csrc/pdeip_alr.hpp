@@ -968,7 +968,7 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra2(typename Mdl::Ctx q, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_alr_zebra3: the APPLY pass of k_alr_zebra2 with the solver wave's instruction count cut to the bone.
+// k_alr_zebra3: k_alr_zebra2 (both modes) with the solver wave's instruction count cut to the bone.
 //
 // With the movers disabled-in-reverse (solver switched off) a 4K colour pass takes 70-100 us; with the
 // solver on, 150-270 us: the one wave that runs the recurrences is bound by instruction ISSUE (a wave gets
@@ -986,9 +986,9 @@ constexpr int Z3_LSF = 3 * ZB_TE + 4;              // floats per line of a tile;
 constexpr int Z3_TILE = ZB_LW * Z3_LSF;            // floats per tile
 constexpr size_t Z3_LDS_BYTES = (size_t)2 * ZB_NM * Z3_TILE * sizeof(float);
 
-template <class Mdl, bool VERT>
-__global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, float *x, const float *__restrict__ cp,
-                                                           const float *__restrict__ dv, float *__restrict__ dp, int nrows, int ncols,
+template <class Mdl, bool VERT, int MODE>
+__global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, float *x, float *__restrict__ cp,
+                                                           float *__restrict__ dv, float *__restrict__ dp, int nrows, int ncols,
                                                            size_t frame_stride, int first, int lastc, int lstep, float omega)
 {
     extern __shared__ float z3_lds[]; // [2][ZB_NM][Z3_TILE]
@@ -1014,7 +1014,7 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
     };
 
     // ---- movers ---------------------------------------------------------------------------------
-    auto produce = [&](int r, int buf) __attribute__((always_inline)) { // operands of round r, slot mslot -> rows a | divisor | d
+    auto produce = [&](int r, int buf) __attribute__((always_inline)) { // operands of round r, slot mslot -> rows a | divisor | d  (FACTOR: a | b | c)
         const int k0 = (r * ZB_NM + mslot) * TE;
         if (k0 >= n) return;
         float *T = tile_of(buf, mslot);
@@ -1025,14 +1025,19 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
             for (int rr = 0; rr < ZB_NP; ++rr) {
                 const int l = min(line0 + lstep * (ml + ZB_LP * rr), lastc);
                 Mdl::template coef4<VERT>(q, l, k0 + 4 * mg, n, nlines, t[rr]);
-                alr_ld4(dv + (size_t)l * n + k0 + 4 * mg, fd[rr]);
+                if (MODE == ZB_APPLY) alr_ld4(dv + (size_t)l * n + k0 + 4 * mg, fd[rr]);
             }
 #pragma unroll
             for (int rr = 0; rr < ZB_NP; ++rr) {
                 float *row = T + (ml + ZB_LP * rr) * Z3_LSF + 4 * mg;
                 lds_st4(row, t[rr][0].a, t[rr][1].a, t[rr][2].a, t[rr][3].a);
-                lds_st4(row + TE, fd[rr][0], fd[rr][1], fd[rr][2], fd[rr][3]);
-                lds_st4(row + 2 * TE, t[rr][0].d, t[rr][1].d, t[rr][2].d, t[rr][3].d);
+                if (MODE == ZB_APPLY) {
+                    lds_st4(row + TE, fd[rr][0], fd[rr][1], fd[rr][2], fd[rr][3]);
+                    lds_st4(row + 2 * TE, t[rr][0].d, t[rr][1].d, t[rr][2].d, t[rr][3].d);
+                } else {
+                    lds_st4(row + TE, t[rr][0].b, t[rr][1].b, t[rr][2].b, t[rr][3].b);
+                    lds_st4(row + 2 * TE, t[rr][0].c, t[rr][1].c, t[rr][2].c, t[rr][3].c);
+                }
             }
             return;
         }
@@ -1046,8 +1051,8 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
                 if (k + e <= n - 1) {
                     const Tri t = Mdl::template coef<VERT>(q, AlrAt(l, k + e, n, nlines));
                     row[e] = t.a;
-                    row[TE + e] = dv[(size_t)l * n + k + e];
-                    row[2 * TE + e] = t.d;
+                    row[TE + e] = MODE == ZB_APPLY ? dv[(size_t)l * n + k + e] : t.b;
+                    row[2 * TE + e] = MODE == ZB_APPLY ? t.d : t.c;
                 }
         }
     };
@@ -1087,13 +1092,14 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
     };
     // results of a finished tile: into registers first (the tile is about to be refilled), to global after the
     // next tile's loads have been consumed.  Going down: dp.  Coming back: the blended x (:1951-1958).
-    float res[ZB_NP][4];
+    float res[ZB_NP][4], res2[ZB_NP][4]; // FACTOR: cp and the divisor
     auto grab = [&](int buf, bool fwd) __attribute__((always_inline)) {
         const float *T = tile_of(buf, mslot);
 #pragma unroll
         for (int rr = 0; rr < ZB_NP; ++rr) {
             const float *row = T + (ml + ZB_LP * rr) * Z3_LSF + 4 * mg;
             lds_ld4(row + 2 * TE, res[rr]);
+            if (MODE == ZB_FACTOR) lds_ld4(row + TE, res2[rr]);
             if (!fwd) {
                 float old[4];
                 lds_ld4(row, old);
@@ -1104,7 +1110,7 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
     };
     auto put = [&](int r, bool fwd) __attribute__((always_inline)) {
         const int k0 = (r * ZB_NM + mslot) * TE;
-        float *out = fwd ? dp : x;
+        float *out = MODE == ZB_FACTOR ? cp : (fwd ? dp : x);
 #pragma unroll
         for (int rr = 0; rr < ZB_NP; ++rr) {
             const int k = k0 + 4 * mg;
@@ -1112,10 +1118,14 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
             const size_t pos = (size_t)min(l, lastc) * n + min(k, n - 1);
             if (l <= lastc && k + 3 <= n - 1) {
                 alr_st4(out + pos, res[rr][0], res[rr][1], res[rr][2], res[rr][3]);
+                if (MODE == ZB_FACTOR) alr_st4(dv + pos, res2[rr][0], res2[rr][1], res2[rr][2], res2[rr][3]);
             } else if (l <= lastc) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (k + e <= n - 1) out[pos + e] = res[rr][e];
+                    if (k + e <= n - 1) {
+                        out[pos + e] = res[rr][e];
+                        if (MODE == ZB_FACTOR) dv[pos + e] = res2[rr][e];
+                    }
             }
         }
     };
@@ -1146,9 +1156,24 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
                 const int k = k0 + e; // wave-uniform
                 if (k <= n - 1) {
                     const float a = Q[e], v = Q[TE + e], d = Q[2 * TE + e];
-                    if (k == 0) dpv = d / v;
-                    else if (k == n - 1) dpv = (d - dpv * a) / v;
-                    else dpv = (d - dpv * a) * v;
+                    if (MODE == ZB_APPLY) {
+                        if (k == 0) dpv = d / v;
+                        else if (k == n - 1) dpv = (d - dpv * a) / v;
+                        else dpv = (d - dpv * a) * v;
+                    } else { // rows a | b | c; dpv carries cp.  The first element is divided by b, the last by its bare denominator
+                        float dvv;
+                        if (k == 0) {
+                            dvv = v;
+                            dpv = d / v;
+                        } else if (k == n - 1) {
+                            dvv = v - dpv * a;
+                            dpv = 0.0f; // cp = 0 closes the back-substitution
+                        } else {
+                            dvv = 1.0f / (v - dpv * a);
+                            dpv = d * dvv;
+                        }
+                        Q[TE + e] = dvv;
+                    }
                     Q[2 * TE + e] = dpv;
                 }
             }
@@ -1167,18 +1192,30 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
                 ld8(Q + 16 * h + 8, a1); ld8(Q + 16 * h + 8 + TE, v1); ld8(Q + 16 * h + 8 + 2 * TE, d1);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    dpv = (d0[e] - dpv * a0[e]) * v0[e];
+                    if (MODE == ZB_APPLY) {
+                        dpv = (d0[e] - dpv * a0[e]) * v0[e];
+                    } else {
+                        v0[e] = 1.0f / (v0[e] - dpv * a0[e]);
+                        dpv = d0[e] * v0[e];
+                    }
                     d0[e] = dpv;
                 }
                 st8(Q + 16 * h + 2 * TE, d0);
+                if (MODE == ZB_FACTOR) st8(Q + 16 * h + TE, v0);
                 const float *F = h == TE / 16 - 1 ? N : Q + 16 * (h + 1);
                 ld8(F, a0); ld8(F + TE, v0); ld8(F + 2 * TE, d0);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    dpv = (d1[e] - dpv * a1[e]) * v1[e];
+                    if (MODE == ZB_APPLY) {
+                        dpv = (d1[e] - dpv * a1[e]) * v1[e];
+                    } else {
+                        v1[e] = 1.0f / (v1[e] - dpv * a1[e]);
+                        dpv = d1[e] * v1[e];
+                    }
                     d1[e] = dpv;
                 }
                 st8(Q + 16 * h + 8 + 2 * TE, d1);
+                if (MODE == ZB_FACTOR) st8(Q + 16 * h + 8 + TE, v1);
             }
         }
     };
@@ -1203,6 +1240,9 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
     if (wave > 0) {
         grab((nrounds - 1) & 1, true);
         put(nrounds - 1, true);
+    }
+    if (MODE == ZB_FACTOR) return;
+    if (wave > 0) {
         __threadfence_block(); // every dp this thread reloads below was stored by this thread: drain them once
         load_bwd(nrounds - 1, (nrounds - 1) & 1);
     }

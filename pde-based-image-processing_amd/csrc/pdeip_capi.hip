@@ -716,23 +716,21 @@ static int zebra2_launch(hipStream_t s, const typename Mdl::Ctx &q, float *x, fl
     return PDEIP_OK;
 }
 
-// the APPLY pass: k_alr_zebra3 unless PDEIP_ALR_ZEBRA2 asks for the older kernel (same results)
-template <class Mdl, bool VERT>
-static int zebra_apply_launch(hipStream_t s, const typename Mdl::Ctx &q, float *x, const float *cp, const float *dv, float *dp, int nrows,
-                              int ncols, int nframes, int first, int lastc, int lstep, float omega)
+// k_alr_zebra3 unless PDEIP_ALR_ZEBRA2 asks for the older kernel (same results)
+template <class Mdl, bool VERT, int MODE>
+static int zebra3_launch(hipStream_t s, const typename Mdl::Ctx &q, float *x, float *cp, float *dv, float *dp, int nrows, int ncols, int nframes,
+                         int first, int lastc, int lstep, float omega)
 {
     static const bool old = getenv("PDEIP_ALR_ZEBRA2") != nullptr;
-    if (old)
-        return zebra2_launch<Mdl, VERT, ZB_APPLY>(s, q, x, const_cast<float *>(cp), const_cast<float *>(dv), dp, nrows, ncols, nframes, first,
-                                                  lastc, lstep, omega);
+    if (old) return zebra2_launch<Mdl, VERT, MODE>(s, q, x, cp, dv, dp, nrows, ncols, nframes, first, lastc, lstep, omega);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_alr_zebra3<Mdl, VERT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z3_LDS_BYTES));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_alr_zebra3<Mdl, VERT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z3_LDS_BYTES));
         attr_set = true;
     }
     const int count = (lastc - first) / lstep + 1;
-    hipLaunchKernelGGL((k_alr_zebra3<Mdl, VERT>), dim3((unsigned)((count + ZB_LW - 1) / ZB_LW), (unsigned)nframes), dim3(ZB_THREADS), Z3_LDS_BYTES, s,
-                       q, x, cp, dv, dp, nrows, ncols, (size_t)nrows * ncols, first, lastc, lstep, omega);
+    hipLaunchKernelGGL((k_alr_zebra3<Mdl, VERT, MODE>), dim3((unsigned)((count + ZB_LW - 1) / ZB_LW), (unsigned)nframes), dim3(ZB_THREADS),
+                       Z3_LDS_BYTES, s, q, x, cp, dv, dp, nrows, ncols, (size_t)nrows * ncols, first, lastc, lstep, omega);
     g.last_launches++;
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
@@ -753,8 +751,8 @@ static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, const typename 
             f->cp[c][d] = base + plane * (size_t)((c * 2 + d) * 2);
             f->dv[c][d] = f->cp[c][d] + plane;
             const int hi = (d == 0 ? ncols : nrows) - 1 - lo;
-            if (d == 0) RC((zebra2_launch<Mdl, true, ZB_FACTOR>(s, q[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
-            else RC((zebra2_launch<Mdl, false, ZB_FACTOR>(s, qt[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
+            if (d == 0) RC((zebra3_launch<Mdl, true, ZB_FACTOR>(s, q[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
+            else RC((zebra3_launch<Mdl, false, ZB_FACTOR>(s, qt[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
         }
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
@@ -820,8 +818,8 @@ static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, c
         const int lastc = hi - (((hi & 1) != colour) ? 1 : 0);
         {
             if (cpf) {
-                if (vertical) RC((zebra_apply_launch<Mdl, true>(s, q, x, cpf, dvf, dp, nrows, ncols, nframes, first, lastc, 2, omega)));
-                else RC((zebra_apply_launch<Mdl, false>(s, q, x, cpf, dvf, dp, nrows, ncols, nframes, first, lastc, 2, omega)));
+                if (vertical) RC((zebra3_launch<Mdl, true, ZB_APPLY>(s, q, x, const_cast<float *>(cpf), const_cast<float *>(dvf), dp, nrows, ncols, nframes, first, lastc, 2, omega)));
+                else RC((zebra3_launch<Mdl, false, ZB_APPLY>(s, q, x, const_cast<float *>(cpf), const_cast<float *>(dvf), dp, nrows, ncols, nframes, first, lastc, 2, omega)));
                 continue;
             }
         }
