@@ -309,6 +309,12 @@ int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, c
                                  int ncols, float *wW, float *wN, float *wS, float *wE);
 /* dU, dV may both be NULL: OPdiffWeights(U, V) of the early-linearisation drivers (FlowEminNDFASFMG_elin_2D_v10.m:392). */
 
+/* [W NW N NE E SE S SW] = ADdiffWeights(D, quantile) of the anisotropic flow driver (matlab/optical_flow/
+ * FlowEminAD_llin_2D_v10.m:416-487): Alvarez derivative in double, strongest frame per pixel, lambda = the quantile of the
+ * non-zero squared gradient norms, tensor weights with circshift wrap-around; returned as single (the solver's arguments). */
+int pdeip_ad_weights_dev(void *stream, const float *D, int nrows, int ncols, int nframes, double quantile, float *wW, float *wNW,
+                         float *wN, float *wNE, float *wE, float *wSE, float *wS, float *wSW);
+
 /* ---- FAS full-multigrid flow (matlab/optical_flow/FlowEminNDFASFMG_elin_2D_v10.m): the stages between its MEX calls ----
  * Planes are [nrows x ncols x frames], column-major, as everywhere.  Output dimensions of the two halving stages are
  * ceil(nrows/2) x ceil(ncols/2) (MATLAB's 1:2:end). */

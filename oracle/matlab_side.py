@@ -162,8 +162,10 @@ def _pad_edge(A):
     return np.pad(A, 1, mode="edge")
 
 
-def ad_diff_weights(D):
-    """[W NW N NE E SE S SW] = ADdiffWeights(D) (TVdenoise8.m:119-231), double; D is [nrows, ncols(, F)] single."""
+def ad_diff_weights(D, quantile=None):
+    """[W NW N NE E SE S SW] = ADdiffWeights(D), double; D is [nrows, ncols(, F)] single.
+    quantile None: TVdenoise8.m:119-231 (lambda = median, outer rows/columns of the weights zeroed);
+    a number: FlowEminAD_llin_2D_v10.m:416-487 (lambda = sorted(round(numel*quantile)), circshift wrap-around kept)."""
     D = D.astype(np.float64)
     if D.ndim == 2:
         D = D[:, :, None]
@@ -195,10 +197,16 @@ def ad_diff_weights(D):
     norm = mx * mx + my * my
     srt = np.sort(norm.ravel())
     srt = srt[srt != 0]
-    lam = srt[(srt.size + 1) // 2 - 1] if srt.size else 1.0   # sorted(round(numel*0.5 + eps))
+    if quantile is None:
+        lam = srt[(srt.size + 1) // 2 - 1] if srt.size else 1.0   # sorted(round(numel*0.5 + eps))
+    else:
+        lam = srt[max(int(np.floor(srt.size * quantile + 0.5)), 1) - 1] if srt.size else 1.0   # sorted(round(numel*quantile))
     multip = 1.0 / (norm + 2.0 * lam)
     dyy, dxx, dxy = multip * (my * my + lam), multip * (mx * mx + lam), -multip * (mx * my)
     sh = lambda A, di, dj: np.roll(np.roll(A, di, axis=0), dj, axis=1)
+    if quantile is not None:
+        return [0.5 * (dyy + sh(dyy, 0, 1)), 0.25 * (dxy + sh(dxy, 1, 1)), 0.5 * (dxx + sh(dxx, 1, 0)), -0.25 * (dxy + sh(dxy, 1, -1)),
+                0.5 * (dyy + sh(dyy, 0, -1)), 0.25 * (dxy + sh(dxy, -1, -1)), 0.5 * (dxx + sh(dxx, -1, 0)), -0.25 * (dxy + sh(dxy, -1, 1))], lam
     W = 0.5 * (dyy + sh(dyy, 0, 1)); W[:, 0] = 0
     NW = 0.25 * (dxy + sh(dxy, 1, 1)); NW[:, 0] = 0; NW[0, :] = 0
     N = 0.5 * (dxx + sh(dxx, 1, 0)); N[0, :] = 0
@@ -514,4 +522,33 @@ def fas_fmg(orc, I0, I1, param, max_scales=None):
         if scl > 0:
             r, c = P0[scl - 1].shape[:2]
             U, V = fas_upscale(U, 1.0 / param["scl_factor"], r, c), fas_upscale(V, 1.0 / param["scl_factor"], r, c)
+    return U, V
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Anisotropic-diffusion flow with late linearisation (matlab/optical_flow/FlowEminAD_llin_2D_v10.m)
+# ---------------------------------------------------------------------------------------------------------
+def flow_ad_level(orc, I1t0, I1t1, U, V, param, It0, I2t0=None, I2t1=None):
+    """One pyramid level (:198-366, without imresize, the GRADMAG second term and the spatial a-priori terms):
+    anisotropic weights from the image It0 ('image', once per level) or from U+dU+V+dV ('flow', every inner iteration),
+    robust assembly as in the isotropic driver, Oflow_sor_llin8_2d, median.
+    param: firstLoop, secondLoop, iter, omega, solver, alpha, b1, b2, quantile, diffusion, order."""
+    U, V = U.astype(F32), V.astype(F32)
+    single = lambda ws: [np.asfortranarray(w.astype(F32)) for w in ws]
+    if param["diffusion"] == "image":
+        w8 = single(ad_diff_weights(It0, param["quantile"])[0])
+    for _ in range(param["firstLoop"]):
+        X, Y = flow_coords(U, V)
+        t1 = orc.FstDerivatives5(I1t0, orc.BilinInterp_2d(I1t1, X, Y)) + (param["b1"],)
+        t2 = None
+        if I2t1 is not None:
+            t2 = orc.FstDerivatives5(I2t0, orc.BilinInterp_2d(I2t1, X, Y)) + (param["b2"],)
+        dU, dV = np.zeros_like(U), np.zeros_like(V)
+        for _ in range(param["secondLoop"]):
+            MGd, CuGd, CvGd, DuGd, DvGd = flow_assemble(t1, t2, dU, dV, param["alpha"])
+            if param["diffusion"] == "flow":
+                w8 = single(ad_diff_weights((((U + dU).astype(F32) + V).astype(F32) + dV).astype(F32), param["quantile"])[0])
+            dU, dV = orc.Oflow_sor_llin8_2d(U, V, dU, dV, MGd, CuGd, CvGd, DuGd, DvGd, *w8, param["iter"], param["omega"],
+                                            solver=param["solver"], order=param["order"])
+        U, V = median3_sum(U, dU), median3_sum(V, dV)
     return U, V

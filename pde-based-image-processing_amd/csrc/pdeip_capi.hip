@@ -1276,9 +1276,34 @@ extern "C" int pdeip_tv_assemble_dev(void *stream, const float *Iout, const floa
     void *temp = lambda + 2;
     hipLaunchKernelGGL(k_tv_gradient, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, gx, gy, nrm, Iout, nrows, ncols, nframes);
     HIPCHK(rocprim::radix_sort_keys(temp, temp_bytes, nrm, sorted, n, 0, 64, s));
-    hipLaunchKernelGGL(k_tv_lambda, dim3(1), dim3(64), 0, s, lambda, sorted, n);
+    hipLaunchKernelGGL(k_tv_lambda, dim3(1), dim3(64), 0, s, lambda, sorted, n, -1.0);
     hipLaunchKernelGGL(k_tv_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, TRACE, B, aW, aNW, aN, aNE, aE, aSE, aS, aSW, gx, gy,
                        nrm, lambda, Iout, Iin, alpha, nrows, ncols, nframes);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_ad_weights_dev(void *stream, const float *D, int nrows, int ncols, int nframes, double quantile, float *wW, float *wNW,
+                                    float *wN, float *wNE, float *wE, float *wSE, float *wS, float *wSW)
+{
+    const char *who = "pdeip_ad_weights_dev";
+    RC(check_dims(who, nrows, ncols, nframes));
+    if (!(quantile > 0.0 && quantile <= 1.0)) return set_err(PDEIP_ERR_ARG, "%s: quantile must be in (0, 1]", who);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = (size_t)nrows * ncols;
+    size_t temp_bytes = 0;
+    double *nul = nullptr;
+    HIPCHK(rocprim::radix_sort_keys(nullptr, temp_bytes, nul, nul, n, 0, 64, s));
+    const size_t doubles = 4 * n + 2 + (temp_bytes + 7) / 8;
+    float *basef;
+    RC(ws_get(WS_TV, doubles * sizeof(double), &basef));
+    double *gx = reinterpret_cast<double *>(basef), *gy = gx + n, *nrm = gy + n, *sorted = nrm + n, *lambda = sorted + n;
+    void *temp = lambda + 2;
+    hipLaunchKernelGGL(k_tv_gradient, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, gx, gy, nrm, D, nrows, ncols, nframes);
+    HIPCHK(rocprim::radix_sort_keys(temp, temp_bytes, nrm, sorted, n, 0, 64, s));
+    hipLaunchKernelGGL(k_tv_lambda, dim3(1), dim3(64), 0, s, lambda, sorted, n, quantile);
+    hipLaunchKernelGGL(k_ad_weights, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, wW, wNW, wN, wNE, wE, wSE, wS, wSW, gx, gy, nrm, lambda, nrows,
+                       ncols);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

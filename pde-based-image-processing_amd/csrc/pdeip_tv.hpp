@@ -57,8 +57,9 @@ __global__ void k_tv_gradient(double *gx, double *gy, double *nrm, const float *
     nrm[pos] = bx * bx + by * by;
 }
 
-// lambda = sorted_nonzero(round(numel * 0.5 + eps)) from the ascending array `sorted` (zeros first); 1 if all are zero
-__global__ void k_tv_lambda(double *lambda, const double *sorted, size_t n)
+// lambda = sorted_nonzero(round(numel * 0.5 + eps)) from the ascending array `sorted` (zeros first); 1 if all are zero.
+// quantile >= 0: the flow driver's form sorted_nonzero(round(numel * quantile)) (FlowEminAD_llin_2D_v10.m:461-467).
+__global__ void k_tv_lambda(double *lambda, const double *sorted, size_t n, double quantile)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     size_t lo = 0, hi = n; // first index with sorted[idx] > 0 (norms are >= 0; NaN sorts last and counts as non-zero)
@@ -72,7 +73,11 @@ __global__ void k_tv_lambda(double *lambda, const double *sorted, size_t n)
         *lambda = 1.0;
         return;
     }
-    const size_t idx = (cnt + 1) / 2; // round(cnt*0.5 + eps), 1-based
+    size_t idx = (cnt + 1) / 2; // round(cnt*0.5 + eps), 1-based
+    if (quantile >= 0.0) {
+        idx = (size_t)floor((double)cnt * quantile + 0.5);
+        idx = idx < 1 ? 1 : (idx > cnt ? cnt : idx);
+    }
     *lambda = sorted[lo + idx - 1];
 }
 
@@ -135,6 +140,43 @@ __global__ void k_tv_assemble(float *TRACE, float *B, float *aW, float *aNW, flo
 #pragma unroll
         for (int k = 0; k < 8; ++k) outs[k][p] = w8[k];
     }
+}
+
+// The eight weights of the flow driver's ADdiffWeights (FlowEminAD_llin_2D_v10.m:469-487): the same tensor, circshift
+// wrap-around kept at the frame edges (nothing zeroed), handed to Oflow_sor_llin8_2d as single.
+__global__ void k_ad_weights(float *wW, float *wNW, float *wN, float *wNE, float *wE, float *wSE, float *wS, float *wSW, const double *gx,
+                             const double *gy, const double *nrm, const double *lambda_p, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    const double lambda = *lambda_p;
+    auto tens = [&](int ii, int jj, double &dyy, double &dxx, double &dxy) {
+        ii = ii < 0 ? nrows - 1 : (ii > nrows - 1 ? 0 : ii);
+        jj = jj < 0 ? ncols - 1 : (jj > ncols - 1 ? 0 : jj);
+        const size_t p = (size_t)jj * nrows + ii;
+        const double x = gx[p], y = gy[p];
+        const double multip = 1.0 / (nrm[p] + 2.0 * lambda);
+        dyy = multip * (y * y + lambda);
+        dxx = multip * (x * x + lambda);
+        dxy = -multip * (x * y);
+    };
+    double dyy, dxx, dxy, a, b, c;
+    tens(i, j, dyy, dxx, dxy);
+    tens(i, j - 1, a, b, c);
+    wW[pos] = (float)(0.5 * (dyy + a));
+    tens(i - 1, j - 1, a, b, c);
+    wNW[pos] = (float)(0.25 * (dxy + c));
+    tens(i - 1, j, a, b, c);
+    wN[pos] = (float)(0.5 * (dxx + b));
+    tens(i - 1, j + 1, a, b, c);
+    wNE[pos] = (float)(-0.25 * (dxy + c));
+    tens(i, j + 1, a, b, c);
+    wE[pos] = (float)(0.5 * (dyy + a));
+    tens(i + 1, j + 1, a, b, c);
+    wSE[pos] = (float)(0.25 * (dxy + c));
+    tens(i + 1, j, a, b, c);
+    wS[pos] = (float)(0.5 * (dxx + b));
+    tens(i + 1, j - 1, a, b, c);
+    wSW[pos] = (float)(-0.25 * (dxy + c));
 }
 
 } // namespace pdeip

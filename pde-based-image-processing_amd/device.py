@@ -321,3 +321,10 @@ def fas_upscale(U, mul, nrows_out, ncols_out):
     out = torch.empty((ncols_out, nrows_out), dtype=U.dtype, device=U.device)
     capi.call("pdeip_fas_upscale_dev", _stream(), U.data_ptr(), nrows, ncols, float(mul), nrows_out, ncols_out, out.data_ptr())
     return out
+
+
+def ad_weights(D, quantile, w8):
+    """ADdiffWeights(D, quantile) of FlowEminAD_llin_2D_v10.m; w8 = [wW, wNW, wN, wNE, wE, wSE, wS, wSW] planes [ncols, nrows]."""
+    _chk(D, *w8)
+    nrows, ncols, F = _dims(D)
+    capi.call("pdeip_ad_weights_dev", _stream(), D.data_ptr(), nrows, ncols, F, float(quantile), *_p(*w8))

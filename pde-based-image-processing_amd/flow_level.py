@@ -55,6 +55,55 @@ class FlowLlinLevel:
         return U, V
 
 
+class FlowAdLevel:
+    """The anisotropic-diffusion twin (matlab/optical_flow/FlowEminAD_llin_2D_v10.m:198-366): eight ADdiffWeights from
+    the image (`diffusion` 'image', once per level) or from U+dU+V+dV ('flow', every inner iteration), and
+    Oflow_sor_llin8_2d.  Not built: the GRADMAG second term and the spatial a-priori terms.
+    param: firstLoop, secondLoop, iter, omega, solver, alpha, b1, b2, quantile, diffusion."""
+
+    def __init__(self, param, mode=capi.MODE_EXACT_ORDER):
+        self.p, self.mode = dict(param), mode
+
+    def run(self, I1t0, I1t1, U, V, It0, I2t0=None, I2t1=None):
+        p = self.p
+        new = lambda like: torch.empty_like(like)
+        X, Y, S = new(U), new(U), new(U)
+        w1, d1 = new(I1t1), [new(I1t1) for _ in range(3)]
+        w2, d2 = (new(I2t1), [new(I2t1) for _ in range(3)]) if I2t1 is not None else (None, None)
+        coef = [new(U) for _ in range(5)]   # MGd, CuGd, CvGd, DuGd, DvGd
+        w8 = [new(U) for _ in range(8)]     # wW, wNW, wN, wNE, wE, wSE, wS, wSW
+        if int(p["solver"]) == 1:   # the 8-neighbour point solver runs the 4-neighbour arithmetic (opticalflowSolvers.c:1487): W, N, E, S only
+            solve = lambda U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wNW, wN, wNE, wE, wSE, wS, wSW, it, om, mode: dev.oflow_sor_llin4(
+                U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, om, mode)
+        else:
+            solve = dev.oflow_alr_llin8
+        if p["diffusion"] == "image":
+            dev.ad_weights(It0, p["quantile"], w8)
+        U, V = U.clone(), V.clone()
+        Un, Vn = new(U), new(U)
+        for _ in range(int(p["firstLoop"])):
+            dev.flow_coords(U, V, X, Y)
+            dev.warp_bilinear(I1t1, X, Y, w1)
+            dev.fst_derivatives5(I1t0, w1, *d1)
+            t1, t2 = (d1[0], d1[1], d1[2], p["b1"]), None
+            if I2t1 is not None:
+                dev.warp_bilinear(I2t1, X, Y, w2)
+                dev.fst_derivatives5(I2t0, w2, *d2)
+                t2 = (d2[0], d2[1], d2[2], p["b2"])
+            dU, dV = torch.zeros_like(U), torch.zeros_like(V)
+            for _ in range(int(p["secondLoop"])):
+                dev.flow_assemble(t1, t2, dU, dV, p["alpha"], *coef)
+                if p["diffusion"] == "flow":
+                    dev.add(U, dU, S); dev.add(S, V, S); dev.add(S, dV, S)      # U+dU+V+dV, left to right
+                    dev.ad_weights(S, p["quantile"], w8)
+                solve(U, V, dU, dV, *coef, *w8, int(p["iter"]), float(p["omega"]), self.mode)
+            dev.median3(U, dU, Un)
+            dev.median3(V, dV, Vn)
+            U, Un = Un, U
+            V, Vn = Vn, V
+        return U, V
+
+
 class DispLlinLevel:
     """The same for stereo disparity: body of the coarse-to-fine loop of matlab/disparity/DispEminND_llin_2D.m:202-316
     (warp along x only, one unknown, DdiffWeights, Disp_sor_llin4_2d).

@@ -182,3 +182,42 @@ def test_resident_horn_schunck_scale(pdeip, oracle, solver, mode, order):
     gU, gV = sub("flow_level").FlowHsLevel(param, mode=mode).run(dev.to_device(I0), dev.to_device(I1), dev.to_device(U0), dev.to_device(U0))
     same(dev.to_matlab(gU), wU, "H&S scale U (solver %d mode %d)" % (solver, mode))
     same(dev.to_matlab(gV), wV, "H&S scale V (solver %d mode %d)" % (solver, mode))
+
+
+@pytest.mark.parametrize("shape,C,quantile", [((37, 53), 1, 0.9), ((64, 80), 3, 0.9), ((6, 120), 2, 0.5), ((131, 5), 1, 0.25), ((3, 5), 1, 0.9), ((5, 7), 1, 0.7)])
+def test_anisotropic_flow_weights(pdeip, shape, C, quantile):
+    import torch
+    ms, dev = matlab_side(), sub("device")
+    I0, _ = frames(51 + C, shape[0], shape[1], C)
+    if C == 1:
+        I0 = np.asfortranarray(I0[:, :, 0])
+    w8 = [torch.empty((shape[1], shape[0]), device="cuda") for _ in range(8)]
+    dev.ad_weights(dev.to_device(I0), quantile, w8)
+    want, _ = ms.ad_diff_weights(I0, quantile)
+    for k, (g, w) in enumerate(zip(w8, want)):
+        same(dev.to_matlab(g), w.astype(np.float32), "AD weight %d %s C=%d q=%g" % (k, shape, C, quantile))
+    flat = dev.to_device(np.zeros(shape, dtype=np.float32))       # no gradient anywhere: lambda = 1
+    dev.ad_weights(flat, quantile, w8)
+    for g, w in zip(w8, ms.ad_diff_weights(np.zeros(shape, dtype=np.float32), quantile)[0]):
+        same(dev.to_matlab(g), w.astype(np.float32), "AD weights of a flat image")
+
+
+@pytest.mark.parametrize("solver,mode,order,diffusion,two_terms", [(2, 0, 0, "image", True), (2, 1, 1, "flow", False), (1, 0, 0, "flow", True),
+                                                                   (1, 1, 1, "image", False)])
+def test_resident_anisotropic_level(pdeip, oracle, solver, mode, order, diffusion, two_terms):
+    ms, dev = matlab_side(), sub("device")
+    I0, I1 = frames(61, 48, 60, 2)
+    J0, J1 = frames(62, 48, 60, 1)
+    rng = np.random.default_rng(4)
+    U0 = np.asfortranarray(rng.uniform(-0.4, 0.4, (48, 60)).astype(np.float32))
+    V0 = np.asfortranarray(rng.uniform(-0.4, 0.4, (48, 60)).astype(np.float32))
+    param = dict(firstLoop=2, secondLoop=2, iter=3, omega=1.0 if solver == 1 else 1.9, solver=solver, alpha=0.4, b1=0.7, b2=0.3, quantile=0.9,
+                 diffusion=diffusion, order=order)
+    extra = (J0, J1) if two_terms else (None, None)
+    wU, wV = ms.flow_ad_level(oracle, I0, I1, U0, V0, param, I0, *extra)
+    dextra = [dev.to_device(a) for a in extra] if two_terms else [None, None]
+    gU, gV = sub("flow_level").FlowAdLevel(param, mode=mode).run(dev.to_device(I0), dev.to_device(I1), dev.to_device(U0), dev.to_device(V0),
+                                                                 dev.to_device(I0), *dextra)
+    same(dev.to_matlab(gU), wU, "AD level U (solver %d mode %d %s)" % (solver, mode, diffusion))
+    same(dev.to_matlab(gV), wV, "AD level V (solver %d mode %d %s)" % (solver, mode, diffusion))
+    assert np.isfinite(wU).all() and np.abs(wU).max() < 20

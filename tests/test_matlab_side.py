@@ -144,3 +144,19 @@ def test_fas_upscale_agrees_with_the_host_bicubic_resize():
     for shape in ((26, 34), (25, 33)):
         np.testing.assert_allclose(ms.fas_upscale(A, 2.0, *shape), py.resize(A * np.float32(2), *shape, method="bicubic"), rtol=0, atol=2e-6)
     assert np.allclose(ms.fas_upscale(np.ones((5, 7), np.float32), 1.0, 10, 14), 1.0, atol=1e-7)
+
+
+def test_flow_driver_anisotropic_weights():
+    """The flow driver's ADdiffWeights: same tensor as the denoiser's, wrap-around kept, lambda at the given quantile."""
+    rng = np.random.default_rng(8)
+    D = rng.random((12, 15)).astype(np.float32)
+    w_tv, lam_tv = ms.ad_diff_weights(D)
+    w_fl, lam_fl = ms.ad_diff_weights(D, 0.5)
+    assert lam_fl == lam_tv                                     # even count: round(n/2) == round(n/2 + eps)
+    for a, b in zip(w_tv, w_fl):
+        assert np.array_equal(a[1:-1, 1:-1], b[1:-1, 1:-1])     # interior identical, the borders are not zeroed
+    assert all(np.all(np.abs(w[0]) > 0) or k in (1, 3, 5, 7) for k, w in enumerate(w_fl))
+    _, lam9 = ms.ad_diff_weights(D, 0.9)
+    assert lam9 > lam_fl
+    flat, lam = ms.ad_diff_weights(np.zeros((5, 6), np.float32), 0.9)
+    assert lam == 1.0 and np.allclose(flat[0], 0.5) and np.allclose(flat[1], 0.0)   # isotropic: W = (1/2 + 1/2)/2
