@@ -309,6 +309,10 @@ int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, c
                                  int ncols, float *wW, float *wN, float *wS, float *wE);
 /* dU, dV may both be NULL: OPdiffWeights(U, V) of the early-linearisation drivers (FlowEminNDFASFMG_elin_2D_v10.m:392). */
 
+/* TVdenoise4's work between two PDEsolver4 calls (matlab/denoising/TVdenoise4.m:84-98 with DiffWeights :116-156), all single:
+ * the four weights (maximum over the frames, outer column/row zeroed) scaled by alpha, PsiData, TRACE, B; [.. x nframes] each. */
+int pdeip_tv4_assemble_dev(void *stream, const float *Iout, const float *Iin, int nrows, int ncols, int nframes, float alpha,
+                           float *TRACE, float *B, float *aW, float *aN, float *aE, float *aS);
 /* [W NW N NE E SE S SW] = ADdiffWeights(D, quantile) of the anisotropic flow driver (matlab/optical_flow/
  * FlowEminAD_llin_2D_v10.m:416-487): Alvarez derivative in double, strongest frame per pixel, lambda = the quantile of the
  * non-zero squared gradient norms, tensor weights with circshift wrap-around; returned as single (the solver's arguments). */

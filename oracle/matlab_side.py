@@ -552,3 +552,49 @@ def flow_ad_level(orc, I1t0, I1t1, U, V, param, It0, I2t0=None, I2t1=None):
                                             solver=param["solver"], order=param["order"])
         U, V = median3_sum(U, dU), median3_sum(V, dV)
     return U, V
+
+
+# ---------------------------------------------------------------------------------------------------------
+# TV denoising with 4 neighbours (matlab/denoising/TVdenoise4.m)
+# ---------------------------------------------------------------------------------------------------------
+def tv4_diff_weights(D):
+    """[wW wN wE wS] = DiffWeights(D) (TVdenoise4.m:116-156), single throughout; D [nrows, ncols(, F)].  One plane each
+    (the caller's repmat over the frames is left to the caller)."""
+    D3 = _c3(D)
+    P = np.pad(D3, ((1, 1), (0, 0), (0, 0)), mode="edge")
+    ver = (F32(0.25) * P[:-2] - F32(0.25) * P[2:]).astype(F32)          # imfilter(D, [0.25 0 -0.25]', 'replicate')
+    P = np.pad(D3, ((0, 0), (1, 1), (0, 0)), mode="edge")
+    hor = (F32(0.25) * P[:, :-2] - F32(0.25) * P[:, 2:]).astype(F32)
+    sh = lambda A, di, dj: np.roll(np.roll(A, di, axis=0), dj, axis=1)
+
+    def w(di, dj, cross):
+        a = (sh(D3, di, dj) - D3).astype(F32)
+        b = (cross + sh(cross, di, dj)).astype(F32)
+        m = ((a * a).astype(F32) + (b * b).astype(F32)).astype(F32).max(axis=2)
+        return (F32(1) / np.sqrt((m + F32(0.00001)).astype(F32))).astype(F32)
+
+    wW, wE, wN, wS = w(0, 1, ver), w(0, -1, ver), w(1, 0, hor), w(-1, 0, hor)
+    wW[:, 0] = 0; wE[:, -1] = 0; wN[0, :] = 0; wS[-1, :] = 0
+    return wW, wN, wE, wS
+
+
+def tv4_assemble(Iout, Iin, alpha):
+    """TRACE, B and single(alpha*w) of one outer iteration (TVdenoise4.m:84-98); returns TRACE, B, [aW, aN, aE, aS]."""
+    shape3 = _c3(Iout).shape
+    wW, wN, wE, wS = tv4_diff_weights(Iout)
+    tot = (((wW + wN).astype(F32) + wE).astype(F32) + wS).astype(F32)
+    diff = (_c3(Iout) - _c3(Iin)).astype(F32)
+    psi = (F32(1.0) / np.sqrt(diff * diff + F32(2.220446049250313e-16))).astype(F32)
+    TRACE = (psi + (F32(alpha) * tot).astype(F32)[:, :, None]).astype(F32)
+    B = (psi * _c3(Iin)).astype(F32)
+    ws = [np.asfortranarray(np.repeat((F32(alpha) * a).astype(F32)[:, :, None], shape3[2], axis=2).reshape(Iout.shape)) for a in (wW, wN, wE, wS)]
+    return np.asfortranarray(TRACE.reshape(Iout.shape)), np.asfortranarray(B.reshape(Iout.shape)), ws
+
+
+def tv4_level(orc, Iin, Iout, param):
+    """The lagged-diffusivity loop of one scale (TVdenoise4.m:82-103)."""
+    X = np.asfortranarray(Iout.astype(F32))
+    for _ in range(param["outer_iter"] + 1):
+        TRACE, B, (aW, aN, aE, aS) = tv4_assemble(X, Iin, param["alpha"])
+        X = orc.PDEsolver4(X, TRACE, B, aW, aN, aE, aS, param["inner_iter"], param["omega"], solver=param["solver"], order=param["order"])
+    return X

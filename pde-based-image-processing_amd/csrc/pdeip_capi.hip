@@ -1283,6 +1283,16 @@ extern "C" int pdeip_tv_assemble_dev(void *stream, const float *Iout, const floa
     return PDEIP_OK;
 }
 
+extern "C" int pdeip_tv4_assemble_dev(void *stream, const float *Iout, const float *Iin, int nrows, int ncols, int nframes, float alpha,
+                                      float *TRACE, float *B, float *aW, float *aN, float *aE, float *aS)
+{
+    RC(check_dims("pdeip_tv4_assemble_dev", nrows, ncols, nframes));
+    hipLaunchKernelGGL(k_tv4_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), TRACE, B, aW, aN, aE, aS, Iout,
+                       Iin, alpha, nrows, ncols, nframes);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_ad_weights_dev(void *stream, const float *D, int nrows, int ncols, int nframes, double quantile, float *wW, float *wNW,
                                     float *wN, float *wNE, float *wE, float *wSE, float *wS, float *wSW)
 {

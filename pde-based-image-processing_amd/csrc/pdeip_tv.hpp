@@ -142,6 +142,54 @@ __global__ void k_tv_assemble(float *TRACE, float *B, float *aW, float *aNW, flo
     }
 }
 
+// TVdenoise4.m:84-98 with its DiffWeights (:116-156), all single: per direction the squared difference to the neighbour plus
+// the squared sum of the cross derivatives (imfilter [0.25 0 -0.25], replicate; circshift wraps), maximum over the frames,
+// 1/sqrt(. + 0.00001), outer column / row zeroed; then PsiData, TRACE, B and the alpha-scaled weights per frame.
+__global__ void k_tv4_assemble(float *TRACE, float *B, float *aW, float *aN, float *aE, float *aS, const float *Iout, const float *Iin,
+                               float alpha, int nrows, int ncols, int nframes)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t n = (size_t)nrows * ncols;
+    auto wrap_i = [&](int v) { return v < 0 ? nrows - 1 : (v > nrows - 1 ? 0 : v); };
+    auto wrap_j = [&](int v) { return v < 0 ? ncols - 1 : (v > ncols - 1 ? 0 : v); };
+    float m[4] = {0.0f, 0.0f, 0.0f, 0.0f}; // W, E, N, S
+    for (int f = 0; f < nframes; ++f) {
+        const float *P = Iout + (size_t)f * n;
+        auto at = [&](int ii, int jj) { return P[(size_t)jj * nrows + ii]; };
+        auto ver = [&](int ii, int jj) { return 0.25f * at(max(ii - 1, 0), jj) - 0.25f * at(min(ii + 1, nrows - 1), jj); };
+        auto hor = [&](int ii, int jj) { return 0.25f * at(ii, max(jj - 1, 0)) - 0.25f * at(ii, min(jj + 1, ncols - 1)); };
+        const float c = at(i, j);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int ii = d == 2 ? wrap_i(i - 1) : (d == 3 ? wrap_i(i + 1) : i), jj = d == 0 ? wrap_j(j - 1) : (d == 1 ? wrap_j(j + 1) : j);
+            const float a = at(ii, jj) - c;
+            const float b = d < 2 ? ver(i, j) + ver(ii, jj) : hor(i, j) + hor(ii, jj);
+            const float v = a * a + b * b;
+            m[d] = f == 0 ? v : fmaxf(m[d], v);
+        }
+    }
+    float w[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) w[d] = 1.0f / sqrtf(m[d] + 0.00001f);
+    if (j == 0) w[0] = 0.0f;
+    if (j == ncols - 1) w[1] = 0.0f;
+    if (i == 0) w[2] = 0.0f;
+    if (i == nrows - 1) w[3] = 0.0f;
+    const float tot = ((w[0] + w[2]) + w[1]) + w[3]; // wW+wN+wE+wS
+    const float atot = alpha * tot;
+    for (int f = 0; f < nframes; ++f) {
+        const size_t p = (size_t)f * n + pos;
+        const float diff = Iout[p] - Iin[p];
+        const float psi = 1.0f / sqrtf(diff * diff + 2.220446049250313e-16f);
+        TRACE[p] = psi + atot;
+        B[p] = psi * Iin[p];
+        aW[p] = alpha * w[0];
+        aE[p] = alpha * w[1];
+        aN[p] = alpha * w[2];
+        aS[p] = alpha * w[3];
+    }
+}
+
 // The eight weights of the flow driver's ADdiffWeights (FlowEminAD_llin_2D_v10.m:469-487): the same tensor, circshift
 // wrap-around kept at the frame edges (nothing zeroed), handed to Oflow_sor_llin8_2d as single.
 __global__ void k_ad_weights(float *wW, float *wNW, float *wN, float *wNE, float *wE, float *wSE, float *wS, float *wSW, const double *gx,

@@ -328,3 +328,10 @@ def ad_weights(D, quantile, w8):
     _chk(D, *w8)
     nrows, ncols, F = _dims(D)
     capi.call("pdeip_ad_weights_dev", _stream(), D.data_ptr(), nrows, ncols, F, float(quantile), *_p(*w8))
+
+
+def tv4_assemble(Iout, Iin, alpha, TRACE, B, w4):
+    """TVdenoise4.m:84-98: DiffWeights(Iout), PsiData, TRACE, B; w4 = [aW, aN, aE, aS] (alpha-scaled)."""
+    _chk(Iout, Iin, TRACE, B, *w4)
+    nrows, ncols, F = _dims(Iout)
+    capi.call("pdeip_tv4_assemble_dev", _stream(), *_p(Iout, Iin), nrows, ncols, F, float(alpha), *_p(TRACE, B, *w4))

@@ -162,6 +162,25 @@ class TvLevel:
         return X
 
 
+class Tv4Level:
+    """The 4-neighbour denoiser's loop (matlab/denoising/TVdenoise4.m:82-103): outer_iter + 1 times DiffWeights, PsiData/TRACE/B,
+    PDEsolver4.  param: alpha, omega, outer_iter, inner_iter, solver."""
+
+    def __init__(self, param, mode=capi.MODE_EXACT_ORDER):
+        self.p, self.mode = dict(param), mode
+
+    def run(self, Iin, Iout):
+        p = self.p
+        X = Iout.clone()
+        TRACE, B = torch.empty_like(X), torch.empty_like(X)
+        w4 = [torch.empty_like(X) for _ in range(4)]  # aW, aN, aE, aS
+        solve = dev.pde_sor4 if int(p["solver"]) == 1 else dev.pde_alr4
+        for _ in range(int(p["outer_iter"]) + 1):
+            dev.tv4_assemble(X, Iin, p["alpha"], TRACE, B, w4)
+            solve(X, TRACE, B, w4[0], w4[1], w4[2], w4[3], int(p["inner_iter"]), float(p["omega"]), self.mode)
+        return X
+
+
 class FlowHsLevel:
     """One scale of Horn-Schunck with early linearisation (matlab/optical_flow/FlowEminHS_elin_2D_v10.m:119-196):
     data terms from the unwarped frames, constant diffusion weight alpha*channels, one Oflow_sor_elin4_2d call.

@@ -221,3 +221,38 @@ def test_resident_anisotropic_level(pdeip, oracle, solver, mode, order, diffusio
     same(dev.to_matlab(gU), wU, "AD level U (solver %d mode %d %s)" % (solver, mode, diffusion))
     same(dev.to_matlab(gV), wV, "AD level V (solver %d mode %d %s)" % (solver, mode, diffusion))
     assert np.isfinite(wU).all() and np.abs(wU).max() < 20
+
+
+@pytest.mark.parametrize("shape,F", [((37, 53), 1), ((40, 48), 3), ((5, 90), 2), ((131, 6), 1)])
+def test_tv4_assembly(pdeip, shape, F):
+    import torch
+    ms, dev = matlab_side(), sub("device")
+    rng = np.random.default_rng(shape[0] + 3 * F)
+    shp = shape if F == 1 else shape + (F,)
+    Iin = np.asfortranarray(rng.uniform(0, 1, shp).astype(np.float32))
+    Iout = np.asfortranarray((Iin + rng.normal(0, 0.05, shp)).astype(np.float32))
+    d_in, d_out = dev.to_device(Iin), dev.to_device(Iout)
+    TRACE, B = torch.empty_like(d_out), torch.empty_like(d_out)
+    w4 = [torch.empty_like(d_out) for _ in range(4)]
+    dev.tv4_assemble(d_out, d_in, 5.0, TRACE, B, w4)
+    wT, wB, ww = ms.tv4_assemble(Iout, Iin, 5.0)
+    same(dev.to_matlab(TRACE), wT, "TRACE"); same(dev.to_matlab(B), wB, "B")
+    for k, (g, w) in enumerate(zip(w4, ww)):
+        same(dev.to_matlab(g), w, "alpha*w %d" % k)
+
+
+@pytest.mark.parametrize("solver,mode,order,F", [(1, 0, 0, 1), (1, 1, 1, 2), (2, 0, 0, 2), (2, 1, 1, 1)])
+def test_resident_tv4_level(pdeip, oracle, solver, mode, order, F):
+    ms, dev = matlab_side(), sub("device")
+    rng = np.random.default_rng(22)
+    jj, ii = np.meshgrid(np.arange(72), np.arange(56))
+    clean = (0.5 + 0.4 * np.sin(0.2 * ii) * np.cos(0.15 * jj) + 0.3 * (ii > 28)).astype(np.float32)
+    noisy = np.clip(clean + rng.normal(0, 0.1, clean.shape), 0, 1).astype(np.float32)
+    if F > 1:
+        noisy = np.stack([noisy, np.clip(clean[::-1] + rng.normal(0, 0.1, clean.shape), 0, 1).astype(np.float32)], axis=2)
+    noisy = np.asfortranarray(noisy)
+    param = dict(alpha=5.0, omega=1.75, outer_iter=3, inner_iter=5, solver=solver, order=order)
+    want = ms.tv4_level(oracle, noisy, noisy, param)
+    got = sub("flow_level").Tv4Level(param, mode=mode).run(dev.to_device(noisy), dev.to_device(noisy))
+    same(dev.to_matlab(got), want, "TV-4 level (solver %d mode %d)" % (solver, mode))
+    assert np.isfinite(want).all()

@@ -160,3 +160,17 @@ def test_flow_driver_anisotropic_weights():
     assert lam9 > lam_fl
     flat, lam = ms.ad_diff_weights(np.zeros((5, 6), np.float32), 0.9)
     assert lam == 1.0 and np.allclose(flat[0], 0.5) and np.allclose(flat[1], 0.0)   # isotropic: W = (1/2 + 1/2)/2
+
+
+def test_tv4_weights_known_cases():
+    """A flat image: every difference is zero, so w = 1/sqrt(1e-5) except on the zeroed outer column / row; a vertical
+    step only lowers the weights across it."""
+    flat = np.full((6, 7), 0.3, dtype=np.float32)
+    wW, wN, wE, wS = ms.tv4_diff_weights(flat)
+    big = np.float32(1) / np.sqrt(np.float32(0.00001))
+    assert np.all(wW[:, 1:] == big) and np.all(wW[:, 0] == 0) and np.all(wE[:, -1] == 0) and np.all(wN[0] == 0) and np.all(wS[-1] == 0)
+    step = np.zeros((6, 8), dtype=np.float32); step[:, 4:] = 1
+    wW, wN, wE, wS = ms.tv4_diff_weights(step)
+    assert wW[2, 4] < 1.01 and wE[2, 3] < 1.01 and wW[2, 2] == big and wN[2, 1] == big
+    T, B, ws = ms.tv4_assemble(step, step, 5.0)
+    assert T.shape == step.shape and np.all(ws[0] == np.float32(5.0) * wW)
