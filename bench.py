@@ -259,25 +259,30 @@ def main():
             I0 = np.asfortranarray(np.stack([tex(0, 0, c) for c in range(3)], axis=2))
             I1 = np.asfortranarray(np.stack([tex(0.7, -0.4, c) for c in range(3)], axis=2))
             Z = np.zeros((1080, 1920), dtype=np.float32, order="F")
-            lp = dict(firstLoop=1, secondLoop=4, iter=4, omega=1.9, solver=1, alpha=0.4, b1=0.7, b2=0.0, order=0)
+            # runme.m:44 runs the driver with ('grad', 'gradmag'): first term = rgb2grad (6 planes), second = gradient magnitude (3 planes)
+            lp = dict(firstLoop=1, secondLoop=4, iter=4, omega=1.9, solver=1, alpha=0.042, b1=1.4843, b2=0.2915, sndTerm="gradmag", order=0)
             dI0, dI1, dZ = dev.to_device(I0), dev.to_device(I1), dev.to_device(Z)
+            dG0, dG1 = dev.rgb2grad(dI0), dev.rgb2grad(dI1)
             level = {}
-            for name, mode in (("exact_order", capi.MODE_EXACT_ORDER), ("red_black", capi.MODE_RED_BLACK)):
-                lv = fl.FlowLlinLevel(lp, mode=mode)
-                gU, gV = lv.run(dI0, dI1, dZ, dZ)
+            for name, prm, mode in (("exact_order", lp, capi.MODE_EXACT_ORDER), ("red_black", lp, capi.MODE_RED_BLACK),
+                                    ("zebra_alr", dict(lp, solver=2, omega=1.5), capi.MODE_RED_BLACK)):
+                lv = fl.FlowLlinLevel(prm, mode=mode)
+                gU, gV = lv.run(dG0, dG1, dZ, dZ, dI0, dI1)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(3):
-                    gU, gV = lv.run(dI0, dI1, dZ, dZ)
+                    gU, gV = lv.run(dG0, dG1, dZ, dZ, dI0, dI1)
                 torch.cuda.synchronize()
                 level[name + "_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
-                if mode == capi.MODE_EXACT_ORDER:
+                if name == "exact_order":
                     t0 = time.perf_counter()
-                    wU, wV = ms.flow_level(sys.modules["oracle_lib"], I0, I1, Z, Z, lp)
+                    wU, wV = ms.flow_level(sys.modules["oracle_lib"], ms.rgb2grad(I0), ms.rgb2grad(I1), Z, Z, lp, I2t0=I0, I2t1=I1)
                     level["cpu_statement_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
                     level["exact_order_max_abs_vs_cpu"] = float(max(np.abs(dev.to_matlab(gU).astype(np.float64) - wU).max(),
                                                                     np.abs(dev.to_matlab(gV).astype(np.float64) - wV).max()))
-            level["workload"] = "FlowEminND_llin_2D_v10 firstLoop body, 1080x1920x3, secondLoop=4, iter=4, solver=1"
+            level["workload"] = ("FlowEminND_llin_2D_v10 firstLoop body as runme.m configures it ('grad', 'gradmag'): 1080x1920, 6 + 3 planes, "
+                                 "secondLoop=4, iter=4; solver 1 (exact / red-black) and solver 2 zebra")
+            del dG0, dG1
             out["flow_level"] = level
             # ---- the lagged-diffusivity loop of the TV denoiser resident in HBM (BASELINE config C3: 2160x3840 gray) ----
             tvp = dict(alpha=500.0, omega=1.75, outer_iter=20, inner_iter=4, solver=1)

@@ -298,6 +298,19 @@ int pdeip_flow_assemble_dev(void *stream, const float *It1, const float *Ix1, co
 int pdeip_disp_assemble_dev(void *stream, const float *It1, const float *Ix1, int C1, float b1, const float *It2,
                             const float *Ix2, int C2, float b2, const float *dU, float alpha, int nrows, int ncols,
                             float *CuGd, float *DuGd);
+/* The same with a gradient-magnitude second term (sndTerm 'gradmag', :253-258, :291-293 -- what runme.m configures): the five
+ * planes of SndDerivatives5(I2t0, I2t1w) [.. x C2] take the place of the first-order derivatives. */
+int pdeip_flow_assemble_gradmag_dev(void *stream, const float *It1, const float *Ix1, const float *Iy1, int C1, float b1,
+                                    const float *Ixt, const float *Iyt, const float *Ixx, const float *Iyy, const float *Ixy, int C2,
+                                    float b2, const float *dU, const float *dV, float alpha, int nrows, int ncols, float *MGd,
+                                    float *CuGd, float *CvGd, float *DuGd, float *DvGd);
+/* disparity twin (matlab/disparity/DispEminND_llin_2D.m:236-238, :271) */
+int pdeip_disp_assemble_gradmag_dev(void *stream, const float *It1, const float *Ix1, int C1, float b1, const float *Ixt,
+                                    const float *Iyt, const float *Ixx, const float *Ixy, int C2, float b2, const float *dU, float alpha,
+                                    int nrows, int ncols, float *CuGd, float *DuGd);
+/* rgb2grad (FlowEminND_llin_2D_v10.m:368-381; fstTerm 'grad'): out [.. x 2*nframes], frames 2f-1 / 2f (1-based) = the [1 0 -1]
+ * differences of input frame f along x / y, replicate borders */
+int pdeip_rgb2grad_dev(void *stream, const float *in, int nrows, int ncols, int nframes, float *out);
 /* out = A + B (single); e.g. the argument of DdiffWeights(single(U+dU), eps) (:283) */
 int pdeip_add_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out);
 /* Horn-Schunck, early linearisation: the data terms of one scale (matlab/optical_flow/FlowEminHS_elin_2D_v10.m:133-164) from the

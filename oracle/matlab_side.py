@@ -32,11 +32,34 @@ def _term(It, Ix, Iy, b, alpha, dU, dV):
     return [(Iy * Ix) * gD, (It * Ix) * gD, (It * Iy) * gD, (Ix * Ix) * gD, (Iy * Iy) * gD]  # :236-240 times gD (:321-325)
 
 
+def _term_gradmag(Ixt, Iyt, Ixx, Iyy, Ixy, b, alpha, dU, dV):
+    """The gradient-magnitude second term (:253-258, :291-293)."""
+    Ixt, Iyt, Ixx, Iyy, Ixy = [a if a.ndim == 3 else a[:, :, None] for a in (Ixt, Iyt, Ixx, Iyy, Ixy)]
+    du, dv = dU.astype(F32)[:, :, None], dV.astype(F32)[:, :, None]
+    r1 = (Ixt - Ixx * du) - Ixy * dv
+    r2 = (Iyt - Ixy * du) - Iyy * dv
+    gD = F32(b) / (F32(alpha) * np.sqrt((r1 * r1 + r2 * r2) + F32(0.00001)))
+    return [(Ixy * (Ixx + Iyy)) * gD, (Ixt * Ixx + Iyt * Ixy) * gD, (Ixt * Ixy + Iyt * Iyy) * gD, (Ixx * Ixx + Ixy * Ixy) * gD,
+            (Ixy * Ixy + Iyy * Iyy) * gD]
+
+
+def rgb2grad(I):
+    """rgb2grad (:368-381): frames 2f-1 / 2f = imfilter(I(:,:,f), [1 0 -1] / [1 0 -1]', 'replicate')"""
+    I3 = I.astype(F32) if I.ndim == 3 else I.astype(F32)[:, :, None]
+    out = np.zeros(I3.shape[:2] + (2 * I3.shape[2],), dtype=F32, order="F")
+    Px = np.pad(I3, ((0, 0), (1, 1), (0, 0)), mode="edge")
+    Py = np.pad(I3, ((1, 1), (0, 0), (0, 0)), mode="edge")
+    out[:, :, 0::2] = Px[:, :-2] - Px[:, 2:]
+    out[:, :, 1::2] = Py[:-2] - Py[2:]
+    return out
+
+
 def flow_assemble(term1, term2, dU, dV, alpha):
-    """term = (It, Ix, Iy, b) or None.  Returns MGd, CuGd, CvGd, DuGd, DvGd = nansum over all channels (:321-325)."""
+    """term = (It, Ix, Iy, b), or for the second one None or the gradient-magnitude term (Ixt, Iyt, Ixx, Iyy, Ixy, b).
+    Returns MGd, CuGd, CvGd, DuGd, DvGd = nansum over all channels (:321-325)."""
     stacks = _term(*term1[:3], term1[3], alpha, dU, dV)
     if term2 is not None:
-        second = _term(*term2[:3], term2[3], alpha, dU, dV)
+        second = _term_gradmag(*term2, alpha, dU, dV) if len(term2) == 6 else _term(*term2[:3], term2[3], alpha, dU, dV)
         stacks = [np.concatenate([a, b], axis=2) for a, b in zip(stacks, second)]
     outs = []
     for s in stacks:
@@ -102,7 +125,8 @@ def flow_level(orc, I1t0, I1t1, U, V, param, I2t0=None, I2t1=None):
         t2 = None
         if I2t1 is not None:
             w2 = orc.BilinInterp_2d(I2t1, X, Y)
-            t2 = orc.FstDerivatives5(I2t0, w2) + (param["b2"],)
+            snd = param.get("sndTerm", "rgb") == "gradmag"
+            t2 = (orc.SndDerivatives5(I2t0, w2) if snd else orc.FstDerivatives5(I2t0, w2)) + (param["b2"],)
         dU, dV = np.zeros_like(U), np.zeros_like(V)
         for _ in range(param["secondLoop"]):
             MGd, CuGd, CvGd, DuGd, DvGd = flow_assemble(t1, t2, dU, dV, param["alpha"])
@@ -120,9 +144,15 @@ def disp_assemble(term1, term2, dU, alpha):
         r = It - Ix * dU.astype(F32)[:, :, None]
         gD = F32(b) / (F32(alpha) * np.sqrt(r * r + F32(0.00001)))
         return (It * Ix) * gD, (Ix * Ix) * gD
+    def gradmag(Ixt, Iyt, Ixx, Ixy, b):   # :236-238, :271
+        Ixt, Iyt, Ixx, Ixy = [a if a.ndim == 3 else a[:, :, None] for a in (Ixt, Iyt, Ixx, Ixy)]
+        du_ = dU.astype(F32)[:, :, None]
+        r1, r2 = Ixt - Ixx * du_, Iyt - Ixy * du_
+        gD = F32(b) / (F32(alpha) * np.sqrt((r1 * r1 + r2 * r2) + F32(0.00001)))
+        return (Ixt * Ixx + Iyt * Ixy) * gD, (Ixx * Ixx + Ixy * Ixy) * gD
     cu, du = one(*term1)
     if term2 is not None:
-        c2, d2 = one(*term2)
+        c2, d2 = gradmag(*term2) if len(term2) == 5 else one(*term2)
         cu, du = np.concatenate([cu, c2], axis=2), np.concatenate([du, d2], axis=2)
     outs = []
     for s in (cu, du):
@@ -144,8 +174,12 @@ def disp_level(orc, I1t0, I1t1, U, param, I2t0=None, I2t1=None):
         t1, t2 = (d[0], d[1], param["b1"]), None
         if I2t1 is not None:
             w2 = orc.BilinInterp_2d(I2t1, X, Y)
-            d2 = orc.FstDerivatives5(I2t0, w2)
-            t2 = (d2[0], d2[1], param["b2"])
+            if param.get("sndTerm", "rgb") == "gradmag":
+                s2 = orc.SndDerivatives5(I2t0, w2)                     # Ixt, Iyt, Ixx, Iyy, Ixy
+                t2 = (s2[0], s2[1], s2[2], s2[4], param["b2"])
+            else:
+                d2 = orc.FstDerivatives5(I2t0, w2)
+                t2 = (d2[0], d2[1], param["b2"])
         dU = np.zeros_like(U)
         for _ in range(param["secondLoop"]):
             CuGd, DuGd = disp_assemble(t1, t2, dU, param["alpha"])
@@ -542,7 +576,9 @@ def flow_ad_level(orc, I1t0, I1t1, U, V, param, It0, I2t0=None, I2t1=None):
         t1 = orc.FstDerivatives5(I1t0, orc.BilinInterp_2d(I1t1, X, Y)) + (param["b1"],)
         t2 = None
         if I2t1 is not None:
-            t2 = orc.FstDerivatives5(I2t0, orc.BilinInterp_2d(I2t1, X, Y)) + (param["b2"],)
+            snd = param.get("sndTerm", "rgb") == "gradmag"
+            w2 = orc.BilinInterp_2d(I2t1, X, Y)
+            t2 = (orc.SndDerivatives5(I2t0, w2) if snd else orc.FstDerivatives5(I2t0, w2)) + (param["b2"],)
         dU, dV = np.zeros_like(U), np.zeros_like(V)
         for _ in range(param["secondLoop"]):
             MGd, CuGd, CvGd, DuGd, DvGd = flow_assemble(t1, t2, dU, dV, param["alpha"])

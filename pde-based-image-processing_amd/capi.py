@@ -79,6 +79,9 @@ SIGNATURES = {
     "pdeip_fas_upscale_dev": [_P, _P, _I, _I, _F, _I, _I, _P],
     "pdeip_ad_weights_dev": [_P, _P, _I, _I, _I, ctypes.c_double] + [_P] * 8,
     "pdeip_tv4_assemble_dev": [_P, _P, _P, _I, _I, _I, _F] + [_P] * 6,
+    "pdeip_flow_assemble_gradmag_dev": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _I, _F, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
+    "pdeip_disp_assemble_gradmag_dev": [_P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F, _P, _F, _I, _I, _P, _P],
+    "pdeip_rgb2grad_dev": [_P, _P, _I, _I, _I, _P],
     "pdeip_flow_opdiffweights_dev": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "pdeip_tv_assemble_dev": [_P, _P, _P, _I, _I, _I, _F] + [_P] * 10,
     "pdeip_median3_dev": [_P, _P, _P, _I, _I, _P],

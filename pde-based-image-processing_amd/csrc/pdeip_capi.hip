@@ -1129,6 +1129,44 @@ extern "C" int pdeip_disp_assemble_dev(void *stream, const float *It1, const flo
     return PDEIP_OK;
 }
 
+extern "C" int pdeip_flow_assemble_gradmag_dev(void *stream, const float *It1, const float *Ix1, const float *Iy1, int C1, float b1,
+                                               const float *Ixt, const float *Iyt, const float *Ixx, const float *Iyy, const float *Ixy, int C2,
+                                               float b2, const float *dU, const float *dV, float alpha, int nrows, int ncols, float *MGd,
+                                               float *CuGd, float *CvGd, float *DuGd, float *DvGd)
+{
+    const char *who = "pdeip_flow_assemble_gradmag_dev";
+    RC(check_dims(who, nrows, ncols, C1));
+    if (C2 < 1 || !Ixt || !Iyt || !Ixx || !Iyy || !Ixy) return set_err(PDEIP_ERR_ARG, "%s: the gradient-magnitude term needs its five derivative arrays", who);
+    const FlowTerm t1{It1, Ix1, Iy1, C1, b1}, t2{Ixt, Iyt, Ixx, C2, b2, Iyy, Ixy};
+    hipLaunchKernelGGL(k_flow_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), MGd, CuGd, CvGd, DuGd,
+                       DvGd, t1, t2, dU, dV, alpha, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_disp_assemble_gradmag_dev(void *stream, const float *It1, const float *Ix1, int C1, float b1, const float *Ixt,
+                                               const float *Iyt, const float *Ixx, const float *Ixy, int C2, float b2, const float *dU, float alpha,
+                                               int nrows, int ncols, float *CuGd, float *DuGd)
+{
+    const char *who = "pdeip_disp_assemble_gradmag_dev";
+    RC(check_dims(who, nrows, ncols, C1));
+    if (C2 < 1 || !Ixt || !Iyt || !Ixx || !Ixy) return set_err(PDEIP_ERR_ARG, "%s: the gradient-magnitude term needs its four derivative arrays", who);
+    const FlowTerm t1{It1, Ix1, nullptr, C1, b1}, t2{Ixt, Iyt, Ixx, C2, b2, nullptr, Ixy};
+    hipLaunchKernelGGL(k_disp_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), CuGd, DuGd, t1, t2, dU,
+                       alpha, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_rgb2grad_dev(void *stream, const float *in, int nrows, int ncols, int nframes, float *out)
+{
+    RC(check_dims("pdeip_rgb2grad_dev", nrows, ncols, nframes));
+    if (in == out) return set_err(PDEIP_ERR_ARG, "pdeip_rgb2grad_dev: output must not alias the input");
+    hipLaunchKernelGGL(k_rgb2grad, pixel_grid(nrows, ncols, nframes), dim3(256), 0, static_cast<hipStream_t>(stream), out, in, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_add_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out)
 {
     RC(check_dims("pdeip_add_dev", nrows, ncols, 1));

@@ -28,10 +28,14 @@ __global__ void k_flow_coords(float *X, float *Y, const float *U, const float *V
 //   M = Iy.*Ix; Cu = It.*Ix; Cv = It.*Iy; Du = Ix.*Ix; Dv = Iy.*Iy                     (:236-240)
 // and the five planes accumulate nansum(cat(3, M.*gD, ...), 3): NaN products are skipped, in channel
 // order, first term then second term; a pixel whose products are all NaN gets 0 (nansum's empty sum).
+// A GRADMAG second term (:253-258, :291-293; sndTerm 'gradmag', what runme.m asks for) carries the five second-order planes
+// of SndDerivatives5 instead: OPnorm = (Ixt - Ixx.*dU - Ixy.*dV).^2 + (Iyt - Ixy.*dU - Iyy.*dV).^2,
+//   M = Ixy.*(Ixx+Iyy); Cu = Ixt.*Ixx + Iyt.*Ixy; Cv = Ixt.*Ixy + Iyt.*Iyy; Du = Ixx.*Ixx + Ixy.*Ixy; Dv = Ixy.*Ixy + Iyy.*Iyy.
 struct FlowTerm {
-    const float *It, *Ix, *Iy; // [nrows x ncols x C]
+    const float *It, *Ix, *Iy; // [nrows x ncols x C]; GRADMAG: Ixt, Iyt, Ixx
     int C;
     float b;
+    const float *Iyy = nullptr, *Ixy = nullptr; // GRADMAG only (Ixy != nullptr marks the kind)
 };
 
 __device__ __forceinline__ void nan_add(float &acc, float v)
@@ -51,6 +55,20 @@ __global__ void k_flow_assemble(float *MGd, float *CuGd, float *CvGd, float *DuG
         const FlowTerm &t = term == 0 ? t1 : t2;
         for (int c = 0; c < t.C; ++c) {
             const size_t p = (size_t)c * n + pos;
+            if (t.Ixy) {
+                const float Ixt = t.It[p], Iyt = t.Ix[p], Ixx = t.Iy[p], Iyy = t.Iyy[p], Ixy = t.Ixy[p];
+                float r1 = Ixt - Ixx * du;
+                r1 = r1 - Ixy * dv;
+                float r2 = Iyt - Ixy * du;
+                r2 = r2 - Iyy * dv;
+                const float gD = t.b / (alpha * sqrtf((r1 * r1 + r2 * r2) + 0.00001f));
+                nan_add(m, (Ixy * (Ixx + Iyy)) * gD);
+                nan_add(cu, (Ixt * Ixx + Iyt * Ixy) * gD);
+                nan_add(cv, (Ixt * Ixy + Iyt * Iyy) * gD);
+                nan_add(Du, (Ixx * Ixx + Ixy * Ixy) * gD);
+                nan_add(Dv, (Ixy * Ixy + Iyy * Iyy) * gD);
+                continue;
+            }
             const float It = t.It[p], Ix = t.Ix[p], Iy = t.Iy[p];
             float r = It - Ix * du; // (It - Ix.*dU) - Iy.*dV
             r = r - Iy * dv;
@@ -85,10 +103,20 @@ __global__ void k_disp_assemble(float *CuGd, float *DuGd, FlowTerm t1, FlowTerm 
         const FlowTerm &t = term == 0 ? t1 : t2;
         for (int c = 0; c < t.C; ++c) {
             const size_t p = (size_t)c * n + pos;
-            const float It = t.It[p], Ix = t.Ix[p];
-            const float r = It - Ix * du;
-            const float gD = t.b / (alpha * sqrtf(r * r + 0.00001f));
-            const float a = (It * Ix) * gD, b = (Ix * Ix) * gD;
+            float a, b;
+            if (t.Ixy) { // GRADMAG (DispEminND_llin_2D.m:236-238, :271): Iy holds Ixx
+                const float Ixt = t.It[p], Iyt = t.Ix[p], Ixx = t.Iy[p], Ixy = t.Ixy[p];
+                const float r1 = Ixt - Ixx * du, r2 = Iyt - Ixy * du;
+                const float gD = t.b / (alpha * sqrtf((r1 * r1 + r2 * r2) + 0.00001f));
+                a = (Ixt * Ixx + Iyt * Ixy) * gD;
+                b = (Ixx * Ixx + Ixy * Ixy) * gD;
+            } else {
+                const float It = t.It[p], Ix = t.Ix[p];
+                const float r = It - Ix * du;
+                const float gD = t.b / (alpha * sqrtf(r * r + 0.00001f));
+                a = (It * Ix) * gD;
+                b = (Ix * Ix) * gD;
+            }
             cu = first ? a : cu + a; // sum(cat(3, ...), 3): slices added in order
             Du = first ? b : Du + b;
             first = false;
@@ -96,6 +124,18 @@ __global__ void k_disp_assemble(float *CuGd, float *DuGd, FlowTerm t1, FlowTerm 
     }
     CuGd[pos] = cu;
     DuGd[pos] = Du;
+}
+
+// rgb2grad (FlowEminND_llin_2D_v10.m:368-381): per input frame f, out(:,:,2f-1) = imfilter(IN, [1 0 -1], 'replicate') (west minus
+// east), out(:,:,2f) = imfilter(IN, [1 0 -1]', 'replicate') (north minus south).  blockIdx.z = input frame.
+__global__ void k_rgb2grad(float *out, const float *in, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    const size_t n = (size_t)nrows * ncols;
+    const float *P = in + blockIdx.z * n;
+    const int jw = max(j - 1, 0), je = min(j + 1, ncols - 1), in_ = max(i - 1, 0), is = min(i + 1, nrows - 1);
+    out[(2 * blockIdx.z) * n + pos] = P[(size_t)jw * nrows + i] - P[(size_t)je * nrows + i];
+    out[(2 * blockIdx.z + 1) * n + pos] = P[(size_t)j * nrows + in_] - P[(size_t)j * nrows + is];
 }
 
 // out = A + B (single): DdiffWeights(single(U+dU), ...) takes the sum as its input (:283)

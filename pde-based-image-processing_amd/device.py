@@ -182,10 +182,16 @@ def flow_coords(U, V, X, Y):
 
 
 def flow_assemble(term1, term2, dU, dV, alpha, MGd, CuGd, CvGd, DuGd, DvGd):
-    """term = (It, Ix, Iy, b) with [C, ncols, nrows] derivative arrays; term2 may be None."""
+    """term = (It, Ix, Iy, b) with [C, ncols, nrows] derivative arrays; term2 may be None, or the gradient-magnitude
+    term (Ixt, Iyt, Ixx, Iyy, Ixy, b) built from snd_derivatives5."""
     It1, Ix1, Iy1, b1 = term1
     _chk(It1, Ix1, Iy1, dU, dV, MGd, CuGd, CvGd, DuGd, DvGd)
     nrows, ncols, C1 = _dims(It1)
+    if term2 is not None and len(term2) == 6:
+        _chk(*term2[:5])
+        capi.call("pdeip_flow_assemble_gradmag_dev", _stream(), *_p(It1, Ix1, Iy1), C1, float(b1), *_p(*term2[:5]), _dims(term2[0])[2],
+                  float(term2[5]), *_p(dU, dV), float(alpha), nrows, ncols, *_p(MGd, CuGd, CvGd, DuGd, DvGd))
+        return
     if term2 is None:
         p2, C2, b2 = [None, None, None], 0, 0.0
     else:
@@ -212,10 +218,15 @@ def median3(A, B, out):
 
 
 def disp_assemble(term1, term2, dU, alpha, CuGd, DuGd):
-    """term = (It, Ix, b); term2 may be None (DispEminND_llin_2D.m:258-293)."""
+    """term = (It, Ix, b); term2 may be None (DispEminND_llin_2D.m:258-293) or the gradient-magnitude term (Ixt, Iyt, Ixx, Ixy, b)."""
     It1, Ix1, b1 = term1
     _chk(It1, Ix1, dU, CuGd, DuGd)
     nrows, ncols, C1 = _dims(It1)
+    if term2 is not None and len(term2) == 5:
+        _chk(*term2[:4])
+        capi.call("pdeip_disp_assemble_gradmag_dev", _stream(), *_p(It1, Ix1), C1, float(b1), *_p(*term2[:4]), _dims(term2[0])[2],
+                  float(term2[4]), dU.data_ptr(), float(alpha), nrows, ncols, *_p(CuGd, DuGd))
+        return
     if term2 is None:
         p2, C2, b2 = [None, None], 0, 0.0
     else:
@@ -335,3 +346,12 @@ def tv4_assemble(Iout, Iin, alpha, TRACE, B, w4):
     _chk(Iout, Iin, TRACE, B, *w4)
     nrows, ncols, F = _dims(Iout)
     capi.call("pdeip_tv4_assemble_dev", _stream(), *_p(Iout, Iin), nrows, ncols, F, float(alpha), *_p(TRACE, B, *w4))
+
+
+def rgb2grad(I):
+    """[C, ncols, nrows] (or [ncols, nrows]) -> [2C, ncols, nrows]: the x / y differences of every frame (fstTerm 'grad')."""
+    _chk(I)
+    nrows, ncols, F = _dims(I)
+    out = torch.empty((2 * F, ncols, nrows), dtype=I.dtype, device=I.device)
+    capi.call("pdeip_rgb2grad_dev", _stream(), I.data_ptr(), nrows, ncols, F, out.data_ptr())
+    return out

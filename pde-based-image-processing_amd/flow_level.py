@@ -30,7 +30,8 @@ class FlowLlinLevel:
         new = lambda like: torch.empty_like(like)
         X, Y = new(U), new(U)
         w1, d1 = new(I1t1), [new(I1t1) for _ in range(3)]
-        w2, d2 = (new(I2t1), [new(I2t1) for _ in range(3)]) if I2t1 is not None else (None, None)
+        gradmag = str(p.get("sndTerm", "rgb")).lower() == "gradmag"   # second term through SndDerivatives5 (:253-258)
+        w2, d2 = (new(I2t1), [new(I2t1) for _ in range(5 if gradmag else 3)]) if I2t1 is not None else (None, None)
         coef = [new(U) for _ in range(9)]  # MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wE, wS
         U, V = U.clone(), V.clone()
         Un, Vn = new(U), new(U)
@@ -41,8 +42,12 @@ class FlowLlinLevel:
             t1, t2 = (d1[0], d1[1], d1[2], p["b1"]), None
             if I2t1 is not None:
                 dev.warp_bilinear(I2t1, X, Y, w2)
-                dev.fst_derivatives5(I2t0, w2, *d2)
-                t2 = (d2[0], d2[1], d2[2], p["b2"])
+                if gradmag:
+                    dev.snd_derivatives5(I2t0, w2, *d2)               # Ixt, Iyt, Ixx, Iyy, Ixy
+                    t2 = (*d2, p["b2"])
+                else:
+                    dev.fst_derivatives5(I2t0, w2, *d2)
+                    t2 = (d2[0], d2[1], d2[2], p["b2"])
             dU, dV = torch.zeros_like(U), torch.zeros_like(V)
             for _ in range(int(p["secondLoop"])):
                 dev.flow_assemble(t1, t2, dU, dV, p["alpha"], *coef[:5])
@@ -69,7 +74,8 @@ class FlowAdLevel:
         new = lambda like: torch.empty_like(like)
         X, Y, S = new(U), new(U), new(U)
         w1, d1 = new(I1t1), [new(I1t1) for _ in range(3)]
-        w2, d2 = (new(I2t1), [new(I2t1) for _ in range(3)]) if I2t1 is not None else (None, None)
+        gradmag = str(p.get("sndTerm", "rgb")).lower() == "gradmag"
+        w2, d2 = (new(I2t1), [new(I2t1) for _ in range(5 if gradmag else 3)]) if I2t1 is not None else (None, None)
         coef = [new(U) for _ in range(5)]   # MGd, CuGd, CvGd, DuGd, DvGd
         w8 = [new(U) for _ in range(8)]     # wW, wNW, wN, wNE, wE, wSE, wS, wSW
         if int(p["solver"]) == 1:   # the 8-neighbour point solver runs the 4-neighbour arithmetic (opticalflowSolvers.c:1487): W, N, E, S only
@@ -88,8 +94,12 @@ class FlowAdLevel:
             t1, t2 = (d1[0], d1[1], d1[2], p["b1"]), None
             if I2t1 is not None:
                 dev.warp_bilinear(I2t1, X, Y, w2)
-                dev.fst_derivatives5(I2t0, w2, *d2)
-                t2 = (d2[0], d2[1], d2[2], p["b2"])
+                if gradmag:
+                    dev.snd_derivatives5(I2t0, w2, *d2)               # Ixt, Iyt, Ixx, Iyy, Ixy
+                    t2 = (*d2, p["b2"])
+                else:
+                    dev.fst_derivatives5(I2t0, w2, *d2)
+                    t2 = (d2[0], d2[1], d2[2], p["b2"])
             dU, dV = torch.zeros_like(U), torch.zeros_like(V)
             for _ in range(int(p["secondLoop"])):
                 dev.flow_assemble(t1, t2, dU, dV, p["alpha"], *coef)
@@ -117,7 +127,8 @@ class DispLlinLevel:
         new = lambda like: torch.empty_like(like)
         X, Y, zero = new(U), new(U), torch.zeros_like(U)
         w1, d1 = new(I1t1), [new(I1t1) for _ in range(3)]
-        w2, d2 = (new(I2t1), [new(I2t1) for _ in range(3)]) if I2t1 is not None else (None, None)
+        gradmag = str(p.get("sndTerm", "rgb")).lower() == "gradmag"   # DispEminND_llin_2D.m:236-238
+        w2, d2 = (new(I2t1), [new(I2t1) for _ in range(5 if gradmag else 3)]) if I2t1 is not None else (None, None)
         CuGd, DuGd, S = new(U), new(U), new(U)
         wts = [new(U) for _ in range(4)]  # wW, wN, wE, wS
         U, Un = U.clone(), new(U)
@@ -129,8 +140,12 @@ class DispLlinLevel:
             t1, t2 = (d1[0], d1[1], p["b1"]), None
             if I2t1 is not None:
                 dev.warp_bilinear(I2t1, X, Y, w2)
-                dev.fst_derivatives5(I2t0, w2, *d2)
-                t2 = (d2[0], d2[1], p["b2"])
+                if gradmag:
+                    dev.snd_derivatives5(I2t0, w2, *d2)
+                    t2 = (d2[0], d2[1], d2[2], d2[4], p["b2"])        # Ixt, Iyt, Ixx, Ixy
+                else:
+                    dev.fst_derivatives5(I2t0, w2, *d2)
+                    t2 = (d2[0], d2[1], p["b2"])
             dU = torch.zeros_like(U)
             for _ in range(int(p["secondLoop"])):
                 dev.disp_assemble(t1, t2, dU, p["alpha"], CuGd, DuGd)

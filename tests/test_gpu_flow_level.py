@@ -256,3 +256,61 @@ def test_resident_tv4_level(pdeip, oracle, solver, mode, order, F):
     got = sub("flow_level").Tv4Level(param, mode=mode).run(dev.to_device(noisy), dev.to_device(noisy))
     same(dev.to_matlab(got), want, "TV-4 level (solver %d mode %d)" % (solver, mode))
     assert np.isfinite(want).all()
+
+
+@pytest.mark.parametrize("shape,C", [((37, 53), 1), ((40, 56), 3), ((5, 90), 2), ((70, 4), 1)])
+def test_gradient_terms(pdeip, shape, C):
+    """fstTerm 'grad' (rgb2grad) and sndTerm 'gradmag' (second-order assembly), the combination runme.m configures."""
+    import torch
+    ms, dev = matlab_side(), sub("device")
+    nrows, ncols = shape
+    rng = np.random.default_rng(nrows * 3 + C)
+    f = lambda lo, hi, *s: np.asfortranarray(rng.uniform(lo, hi, size=s or shape).astype(np.float32))
+    I = f(0, 1, nrows, ncols, C)
+    same(dev.to_matlab(dev.rgb2grad(dev.to_device(I))), ms.rgb2grad(I), "rgb2grad %s C=%d" % (shape, C))
+    if C == 1:
+        same(dev.to_matlab(dev.rgb2grad(dev.to_device(I[:, :, 0]))), ms.rgb2grad(I[:, :, 0]), "rgb2grad of a plane")
+    dU, dV = f(-.5, .5), f(-.5, .5)
+    t1 = [f(-1, 1, nrows, ncols, 2 * C) for _ in range(3)]
+    t2 = [f(-1, 1, nrows, ncols, C) for _ in range(5)]
+    t2[0][rng.uniform(size=t2[0].shape) < 0.05] = np.nan            # out-of-range warps
+    t1[1][rng.uniform(size=t1[1].shape) < 0.03] = np.nan
+    outs = [torch.empty((ncols, nrows), device="cuda") for _ in range(5)]
+    dev.flow_assemble(tuple(dev.to_device(a) for a in t1) + (1.4843,), tuple(dev.to_device(a) for a in t2) + (0.2915,), dev.to_device(dU),
+                      dev.to_device(dV), 0.042, *outs)
+    want = ms.flow_assemble(tuple(t1) + (1.4843,), tuple(t2) + (0.2915,), dU, dV, 0.042)
+    for k, (g, w) in enumerate(zip(outs, want)):
+        same(dev.to_matlab(g), w, "gradmag assembly %d" % k)
+    d1 = [t1[0], t1[1]]
+    d2 = [t2[0], t2[1], t2[2], t2[4]]
+    dev.disp_assemble(tuple(dev.to_device(a) for a in d1) + (0.7,), tuple(dev.to_device(a) for a in d2) + (0.3,), dev.to_device(dU), 0.15,
+                      outs[0], outs[1])
+    for g, w, name in zip(outs[:2], ms.disp_assemble(tuple(d1) + (0.7,), tuple(d2) + (0.3,), dU, 0.15), ("CuGd", "DuGd")):
+        got = dev.to_matlab(g)
+        assert np.array_equal(np.isnan(got), np.isnan(w))           # plain sum: NaN goes through to the solver's isnan test
+        same(got, w, "disparity gradmag " + name)
+
+
+@pytest.mark.parametrize("solver,mode,order", [(2, 0, 0), (1, 1, 1)])
+def test_resident_levels_with_grad_and_gradmag(pdeip, oracle, solver, mode, order):
+    """The runme.m configuration ('grad', 'gradmag') of the isotropic, anisotropic and disparity levels."""
+    ms, dev, fl = matlab_side(), sub("device"), sub("flow_level")
+    I0, I1 = frames(71, 44, 56, 3)
+    G0, G1 = ms.rgb2grad(I0), ms.rgb2grad(I1)
+    g0, g1 = dev.rgb2grad(dev.to_device(I0)), dev.rgb2grad(dev.to_device(I1))
+    same(dev.to_matlab(g0), G0, "rgb2grad of the first frame")
+    param = dict(firstLoop=2, secondLoop=2, iter=3, omega=1.9 if solver == 2 else 1.0, solver=solver, alpha=0.3, b1=0.6, b2=0.4, sndTerm="gradmag",
+                 quantile=0.9, diffusion="flow", order=order)
+    Z = np.zeros((44, 56), dtype=np.float32, order="F")
+    dZ, d0, d1 = dev.to_device(Z), dev.to_device(I0), dev.to_device(I1)
+    wU, wV = ms.flow_level(oracle, G0, G1, Z, Z, param, I2t0=I0, I2t1=I1)
+    gU, gV = fl.FlowLlinLevel(param, mode=mode).run(g0, g1, dZ, dZ, d0, d1)
+    same(dev.to_matlab(gU), wU, "grad+gradmag level U"); same(dev.to_matlab(gV), wV, "grad+gradmag level V")
+    assert np.isfinite(wU).all() and np.abs(wU).max() > 1e-3
+    wU, wV = ms.flow_ad_level(oracle, G0, G1, Z, Z, param, I0, I0, I1)
+    gU, gV = fl.FlowAdLevel(param, mode=mode).run(g0, g1, dZ, dZ, d0, d0, d1)
+    same(dev.to_matlab(gU), wU, "anisotropic grad+gradmag level U"); same(dev.to_matlab(gV), wV, "anisotropic grad+gradmag level V")
+    U0 = np.full((44, 56), 1.5, dtype=np.float32, order="F")
+    want = ms.disp_level(oracle, G0, G1, U0, param, I2t0=I0, I2t1=I1)
+    got = fl.DispLlinLevel(param, mode=mode).run(g0, g1, dev.to_device(U0), d0, d1)
+    same(dev.to_matlab(got), want, "disparity grad+gradmag level")

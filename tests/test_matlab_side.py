@@ -174,3 +174,22 @@ def test_tv4_weights_known_cases():
     assert wW[2, 4] < 1.01 and wE[2, 3] < 1.01 and wW[2, 2] == big and wN[2, 1] == big
     T, B, ws = ms.tv4_assemble(step, step, 5.0)
     assert T.shape == step.shape and np.all(ws[0] == np.float32(5.0) * wW)
+
+
+def test_gradient_terms_statement():
+    """rgb2grad is the [1 0 -1] correlation per frame; the gradient-magnitude term reduces to closed forms at dU = dV = 0."""
+    I = np.arange(20, dtype=np.float32).reshape(4, 5) ** 2
+    G = ms.rgb2grad(I)
+    assert G.shape == (4, 5, 2)
+    assert np.array_equal(G[:, 1:-1, 0], I[:, :-2] - I[:, 2:]) and np.array_equal(G[1:-1, :, 1], I[:-2] - I[2:])
+    assert np.array_equal(G[:, 0, 0], I[:, 0] - I[:, 1]) and np.array_equal(G[-1, :, 1], I[-2] - I[-1])
+    rng = np.random.default_rng(2)
+    p = [rng.uniform(-1, 1, (6, 7, 2)).astype(np.float32) for _ in range(5)]
+    Z = np.zeros((6, 7), np.float32)
+    Ixt, Iyt, Ixx, Iyy, Ixy = p
+    gD = np.float32(0.3) / (np.float32(0.05) * np.sqrt((Ixt * Ixt + Iyt * Iyt) + np.float32(0.00001)))
+    t1 = [np.zeros((6, 7, 1), np.float32)] * 3
+    M, Cu, Cv, Du, Dv = ms.flow_assemble(tuple(t1) + (1.0,), tuple(p) + (0.3,), Z, Z, 0.05)
+    acc = lambda S: (S[:, :, 0] + S[:, :, 1]).astype(np.float32)
+    assert np.array_equal(Du, acc((Ixx * Ixx + Ixy * Ixy) * gD)) and np.array_equal(M, acc((Ixy * (Ixx + Iyy)) * gD))
+    assert np.array_equal(Cv, acc((Ixt * Ixy + Iyt * Iyy) * gD))
