@@ -322,6 +322,21 @@ int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, c
                                  int ncols, float *wW, float *wN, float *wS, float *wE);
 /* dU, dV may both be NULL: OPdiffWeights(U, V) of the early-linearisation drivers (FlowEminNDFASFMG_elin_2D_v10.m:392). */
 
+/* ---- symmetric stereo (matlab/disparity/DispEminND_llin_sym_2D.m): the stages the other drivers do not have.  Planes marked
+ * double are MATLAB doubles there (U, the warped disparities and what is derived from them). ---- */
+/* out = interp2(X, Y, U, X+Uq, Y) (:140-141): linear along x, NaN outside the grid */
+int pdeip_sym_warp_flow_dev(void *stream, const float *U, const float *Uq, int nrows, int ncols, double *out);
+/* Udt = (U+Uw)*0.5, Udx = prefiltered x-derivative of Uw, CuS = Udt.*(1+Udx), DuS = 1+Udx+Udx+Udx.*Udx (:156-175) */
+int pdeip_sym_flow_terms_dev(void *stream, const float *U, const double *Uw, int nrows, int ncols, double *Udt, double *Udx,
+                             double *CuS, double *DuS);
+/* CuG, DuG of one view (:189-222): robust data term over the C channels plus the symmetry term with
+ * gSYM = kS./(1 + Snorm/sr2), kS = channels*beta/alpha, sr2 = srDiff^2; first != 0 in the first inner iteration (dU still
+ * MATLAB's double zeros: symmetry weights in double), 0 afterwards (single) */
+int pdeip_sym_assemble_dev(void *stream, const float *Idt, const float *Idx, const float *Idxt, const float *Idyt, const float *Idxx,
+                           const float *Idxy, int C, const double *Udt, const double *Udx, const double *CuS, const double *DuS,
+                           const float *dU, float b1, float b2, float alpha, double kS, double sr2, int first, int nrows, int ncols,
+                           float *CuG, float *DuG);
+
 /* TVdenoise4's work between two PDEsolver4 calls (matlab/denoising/TVdenoise4.m:84-98 with DiffWeights :116-156), all single:
  * the four weights (maximum over the frames, outer column/row zeroed) scaled by alpha, PsiData, TRACE, B; [.. x nframes] each. */
 int pdeip_tv4_assemble_dev(void *stream, const float *Iout, const float *Iin, int nrows, int ncols, int nframes, float alpha,

@@ -634,3 +634,108 @@ def tv4_level(orc, Iin, Iout, param):
         TRACE, B, (aW, aN, aE, aS) = tv4_assemble(X, Iin, param["alpha"])
         X = orc.PDEsolver4(X, TRACE, B, aW, aN, aE, aS, param["inner_iter"], param["omega"], solver=param["solver"], order=param["order"])
     return X
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Symmetric stereo disparity (matlab/disparity/DispEminND_llin_sym_2D.m)
+# ---------------------------------------------------------------------------------------------------------
+SYM_PRE = np.array([0.037659, 0.249724, 0.439911, 0.249724, 0.037659], dtype=np.float64)       # prefilter_spa (:71)
+SYM_D1F = np.array([-0.104550, -0.292315, 0.0, 0.292315, 0.104550], dtype=np.float64)          # O_dx (:73) flipped by 'conv'
+
+
+def sym_warp_flow(U, Uq):
+    """interp2(X, Y, U, X+Uq, Y) (:140-141), our statement of interp2's default: linear, NaN outside the grid.  The query
+    rows are the grid rows, so only x is interpolated: v0*(1-s) + v1*s in double, at xq == cols the last column itself."""
+    nrows, ncols = U.shape
+    Ud = U.astype(np.float64)
+    xq = np.arange(1, ncols + 1, dtype=np.float64)[None, :] + Uq.astype(np.float64)
+    ok = (xq >= 1) & (xq <= ncols)                                   # NaN queries fail both
+    j0 = np.where(ok, np.floor(np.where(ok, xq, 1.0)), 1.0)
+    j0 = np.minimum(j0, ncols - 1)
+    s = np.where(ok, xq, 1.0) - j0
+    j0 = j0.astype(np.int64) - 1
+    ii = np.arange(nrows)[:, None]
+    out = Ud[ii, j0] * (1.0 - s) + Ud[ii, np.minimum(j0 + 1, ncols - 1)] * s
+    return np.where(ok, out, np.nan)
+
+
+def _conv5_f64(A, k, axis):
+    pad = [(0, 0)] * A.ndim
+    pad[axis] = (2, 2)
+    P = np.pad(A, pad, mode="edge")
+    n = A.shape[axis]
+    sl = lambda t: tuple(slice(t, t + n) if ax == axis else slice(None) for ax in range(A.ndim))
+    s = k[0] * P[sl(0)]
+    for t in range(1, 5):
+        s = s + k[t] * P[sl(t)]
+    return s
+
+
+def sym_flow_terms(U, Uw):
+    """Udt, Udx, CuS, DuS of one direction (:156-175), double: Udt = (U+Uw)*0.5, Udx = the prefiltered x-derivative of the
+    warped other-view disparity, CuS = Udt.*(1+Udx), DuS = 1 + Udx + Udx + Udx.*Udx."""
+    Udt = (U.astype(np.float64) + Uw) * 0.5
+    Udx = _conv5_f64(_conv5_f64(Uw, SYM_PRE, 0), SYM_D1F, 1)
+    CuS = Udt * (1.0 + Udx)
+    DuS = ((1.0 + Udx) + Udx) + Udx * Udx
+    return Udt, Udx, CuS, DuS
+
+
+def sym_assemble(d, sym, dU, param, channels, sr_diff, first):
+    """CuG, DuG of one view (:189-222).  d = (Idt, Idx, Idxt, Idyt, Idxx, Idxy) single [.., C]; sym = (Udt, Udx, CuS, DuS) double.
+    first: dU is still the double zeros of :177-178, so the symmetry weights are evaluated in double; afterwards dU is the
+    solver's single output and MATLAB's `single op double -> single` makes them single."""
+    Idt, Idx, Idxt, Idyt, Idxx, Idxy = [a if a.ndim == 3 else a[:, :, None] for a in d]
+    Udt, Udx, CuS, DuS = sym
+    b1, b2, alpha = F32(param["b1"]), F32(param["b2"]), F32(param["alpha"])
+    du = dU.astype(F32)[:, :, None]
+    r1, r2, r3 = Idt - Idx * du, Idxt - Idxx * du, Idyt - Idxy * du
+    opnorm = b1 * (r1 * r1) + b2 * ((r2 * r2) + (r3 * r3))
+    gD = (F32(1) / (alpha * np.sqrt(opnorm + F32(0.00001)))).astype(F32)
+    CuD = (b1 * Idt) * Idx + b2 * (Idxt * Idxx + Idyt * Idxy)              # :165-168 (constant in the inner loop)
+    DuD = (b1 * Idx) * Idx + b2 * (Idxx * Idxx + Idxy * Idxy)
+    kS, sr2 = channels * param["beta"] / param["alpha"], sr_diff ** 2
+    if first:
+        du64 = dU.astype(np.float64)
+        sn = (du64 + Udt) + Udx * du64
+        gS = kS / (1.0 + (sn * sn) / sr2)
+        cS, dS = ((-gS) * CuS).astype(F32), (gS * DuS).astype(F32)
+    else:
+        du32 = dU.astype(F32)
+        sn = ((du32 + Udt.astype(F32)).astype(F32) + (Udx.astype(F32) * du32).astype(F32)).astype(F32)
+        gS = (F32(kS) / (F32(1) + ((sn * sn).astype(F32) / F32(sr2)).astype(F32)).astype(F32)).astype(F32)
+        cS, dS = ((-gS) * CuS.astype(F32)).astype(F32), (gS * DuS.astype(F32)).astype(F32)
+    outs = []
+    for data, s_ in (((gD * CuD).astype(F32), cS), ((gD * DuD).astype(F32), dS)):   # sum(cat(3, ...), 3): slices in order, single
+        acc = data[:, :, 0]
+        for c in range(1, data.shape[2]):
+            acc = (acc + data[:, :, c]).astype(F32)
+        outs.append(np.asfortranarray((acc + s_).astype(F32)))
+    return outs
+
+
+def disp_sym_level(orc, It0, It1, U0, U1, param, sr_diff):
+    """One pyramid level (:116-262, without imresize).  U0 = U(:,:,1), U1 = U(:,:,2); sr_diff = 2*(1/scl_factor)^-(scl-1)."""
+    U0, U1 = np.asfortranarray(U0, dtype=F32), np.asfortranarray(U1, dtype=F32)
+    channels = It0.shape[2] if It0.ndim == 3 else 1
+    Z = np.zeros_like(U0)
+    for _ in range(param["firstLoop"]):
+        X1, Y = flow_coords(U1, Z)
+        X0, _ = flow_coords(U0, Z)
+        It0w, It1w = orc.BilinInterp_2d(It0, X1, Y), orc.BilinInterp_2d(It1, X0, Y)      # :134-135
+        U0w, U1w = sym_warp_flow(U0, U1), sym_warp_flow(U1, U0)                          # :140-141
+        f0, s0 = orc.FstDerivatives5(It0, It1w), orc.SndDerivatives5(It0, It1w)          # Idt0 Idx1 Idy1 / Idxt0 Idyt0 Idxx1 Idyy1 Idxy1
+        f1, s1 = orc.FstDerivatives5(It1, It0w), orc.SndDerivatives5(It1, It0w)
+        d0 = (f0[0], f0[1], s0[0], s0[1], s0[2], s0[4])
+        d1 = (f1[0], f1[1], s1[0], s1[1], s1[2], s1[4])
+        sym0, sym1 = sym_flow_terms(U0, U1w), sym_flow_terms(U1, U0w)                    # :156-175
+        dU0, dU1 = np.zeros_like(U0), np.zeros_like(U1)
+        for k in range(param["secondLoop"]):
+            CuG0, DuG0 = sym_assemble(d0, sym0, dU0, param, channels, sr_diff, k == 0)
+            CuG1, DuG1 = sym_assemble(d1, sym1, dU1, param, channels, sr_diff, k == 0)
+            w0 = orc.DdiffWeights((U0 + dU0).astype(F32), 0.00001)
+            w1 = orc.DdiffWeights((U1 + dU1).astype(F32), 0.00001)
+            dU0, dU1 = orc.Disp_sor_llin_sym4_2d(U0, dU0, CuG0, DuG0, *w0, U1, dU1, CuG1, DuG1, *w1, param["iter"], param["omega"],
+                                                 solver=param["solver"], order=param["order"])
+        U0, U1 = median3_sum(U0, dU0), median3_sum(U1, dU1)
+    return U0, U1

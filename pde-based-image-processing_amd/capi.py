@@ -82,6 +82,9 @@ SIGNATURES = {
     "pdeip_flow_assemble_gradmag_dev": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _I, _F, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
     "pdeip_disp_assemble_gradmag_dev": [_P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F, _P, _F, _I, _I, _P, _P],
     "pdeip_rgb2grad_dev": [_P, _P, _I, _I, _I, _P],
+    "pdeip_sym_warp_flow_dev": [_P, _P, _P, _I, _I, _P],
+    "pdeip_sym_flow_terms_dev": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "pdeip_sym_assemble_dev": [_P] * 7 + [_I] + [_P] * 5 + [_F, _F, _F, ctypes.c_double, ctypes.c_double, _I, _I, _I, _P, _P],
     "pdeip_flow_opdiffweights_dev": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "pdeip_tv_assemble_dev": [_P, _P, _P, _I, _I, _I, _F] + [_P] * 10,
     "pdeip_median3_dev": [_P, _P, _P, _I, _I, _P],

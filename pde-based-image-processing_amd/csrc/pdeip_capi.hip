@@ -17,6 +17,7 @@
 #include "pdeip_alr.hpp"
 #include "pdeip_flow.hpp"
 #include "pdeip_fas.hpp"
+#include "pdeip_sym.hpp"
 #include "pdeip_tv.hpp"
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
@@ -1317,6 +1318,39 @@ extern "C" int pdeip_tv_assemble_dev(void *stream, const float *Iout, const floa
     hipLaunchKernelGGL(k_tv_lambda, dim3(1), dim3(64), 0, s, lambda, sorted, n, -1.0);
     hipLaunchKernelGGL(k_tv_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, TRACE, B, aW, aNW, aN, aNE, aE, aSE, aS, aSW, gx, gy,
                        nrm, lambda, Iout, Iin, alpha, nrows, ncols, nframes);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+// ---- symmetric stereo driver stages (pdeip_sym.hpp) ----------------------------------------------------
+extern "C" int pdeip_sym_warp_flow_dev(void *stream, const float *U, const float *Uq, int nrows, int ncols, double *out)
+{
+    RC(check_dims("pdeip_sym_warp_flow_dev", nrows, ncols, 1));
+    if (ncols < 2) return set_err(PDEIP_ERR_ARG, "pdeip_sym_warp_flow_dev: needs at least two columns");
+    hipLaunchKernelGGL(k_sym_warp_flow, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), out, U, Uq, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_sym_flow_terms_dev(void *stream, const float *U, const double *Uw, int nrows, int ncols, double *Udt, double *Udx,
+                                        double *CuS, double *DuS)
+{
+    RC(check_dims("pdeip_sym_flow_terms_dev", nrows, ncols, 1));
+    hipLaunchKernelGGL(k_sym_flow_terms, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), Udt, Udx, CuS, DuS, U, Uw,
+                       nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_sym_assemble_dev(void *stream, const float *Idt, const float *Idx, const float *Idxt, const float *Idyt, const float *Idxx,
+                                      const float *Idxy, int C, const double *Udt, const double *Udx, const double *CuS, const double *DuS,
+                                      const float *dU, float b1, float b2, float alpha, double kS, double sr2, int first, int nrows, int ncols,
+                                      float *CuG, float *DuG)
+{
+    RC(check_dims("pdeip_sym_assemble_dev", nrows, ncols, C));
+    const SymData d{Idt, Idx, Idxt, Idyt, Idxx, Idxy, C};
+    hipLaunchKernelGGL(k_sym_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), CuG, DuG, d, Udt, Udx, CuS, DuS,
+                       dU, b1, b2, alpha, kS, sr2, first, nrows, ncols);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

@@ -355,3 +355,47 @@ def rgb2grad(I):
     out = torch.empty((2 * F, ncols, nrows), dtype=I.dtype, device=I.device)
     capi.call("pdeip_rgb2grad_dev", _stream(), I.data_ptr(), nrows, ncols, F, out.data_ptr())
     return out
+
+
+# ---- symmetric stereo driver (csrc/pdeip_sym.hpp); float64 planes are MATLAB doubles ----------------------
+
+def _chk64(*tensors):
+    for t in tensors:
+        if t.dtype != torch.float64 or not t.is_contiguous() or not t.is_cuda:
+            raise capi.PdeipError(capi.PDEIP_ERR_ARG, "expected contiguous float64 CUDA tensors")
+
+
+def disp_sor_llin_sym4(U0, dU0, Cu0, Du0, w0, U1, dU1, Cu1, Du1, w1, iter, omega, solver, mode=capi.MODE_EXACT_ORDER):
+    """In place on dU0, dU1 (Disp_sor_llin_sym4_2d: GS_SOR_llinsym4_2d / GS_ALR_SOR_llinsym4_2d); w = [wW, wN, wE, wS]."""
+    _chk(U0, dU0, Cu0, Du0, *w0, U1, dU1, Cu1, Du1, *w1)
+    nrows, ncols, _ = _dims(U0)
+    capi.call("pdeip_disp_sor_llin_sym4_dev", _stream(), *_p(U0, dU0, Cu0, Du0, *w0, U1, dU1, Cu1, Du1, *w1), nrows, ncols, int(iter),
+              float(omega), int(solver), int(mode), 0)
+
+
+def sym_warp_flow(U, Uq):
+    """interp2(X, Y, U, X+Uq, Y) -> float64 plane"""
+    _chk(U, Uq)
+    nrows, ncols, _ = _dims(U)
+    out = torch.empty(U.shape, dtype=torch.float64, device=U.device)
+    capi.call("pdeip_sym_warp_flow_dev", _stream(), *_p(U, Uq), nrows, ncols, out.data_ptr())
+    return out
+
+
+def sym_flow_terms(U, Uw):
+    """-> (Udt, Udx, CuS, DuS) float64 planes"""
+    _chk(U)
+    _chk64(Uw)
+    nrows, ncols, _ = _dims(U)
+    outs = [torch.empty_like(Uw) for _ in range(4)]
+    capi.call("pdeip_sym_flow_terms_dev", _stream(), U.data_ptr(), Uw.data_ptr(), nrows, ncols, *_p(*outs))
+    return outs
+
+
+def sym_assemble(d, sym, dU, b1, b2, alpha, kS, sr2, first, CuG, DuG):
+    """d = (Idt, Idx, Idxt, Idyt, Idxx, Idxy) [C, ncols, nrows]; sym = (Udt, Udx, CuS, DuS) float64."""
+    _chk(*d, dU, CuG, DuG)
+    _chk64(*sym)
+    nrows, ncols, C = _dims(d[0])
+    capi.call("pdeip_sym_assemble_dev", _stream(), *_p(*d), C, *_p(*sym), dU.data_ptr(), float(b1), float(b2), float(alpha), float(kS),
+              float(sr2), int(bool(first)), nrows, ncols, *_p(CuG, DuG))

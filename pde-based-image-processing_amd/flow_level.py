@@ -157,6 +157,52 @@ class DispLlinLevel:
         return U
 
 
+class DispSymLevel:
+    """Symmetric stereo (matlab/disparity/DispEminND_llin_sym_2D.m:116-262): both views' disparities at once, each warped into
+    the other (interp2) for the symmetry term, brightness + gradient constancy data terms, Disp_sor_llin_sym4_2d.
+    param: firstLoop, secondLoop, iter, omega, solver, alpha, beta, b1, b2."""
+
+    def __init__(self, param, mode=capi.MODE_EXACT_ORDER):
+        self.p, self.mode = dict(param), mode
+
+    def run(self, It0, It1, U0, U1, sr_diff):
+        """It*: [C, ncols, nrows]; U0 = U(:,:,1), U1 = U(:,:,2); sr_diff = 2*(1/scl_factor)^-(scl-1) of the scale."""
+        p = self.p
+        new = lambda like: torch.empty_like(like)
+        C = It0.shape[0] if It0.dim() == 3 else 1
+        kS, sr2 = C * float(p["beta"]) / float(p["alpha"]), float(sr_diff) ** 2
+        zero, X, Y = torch.zeros_like(U0), new(U0), new(U0)
+        warped = [new(It0), new(It0)]
+        der = [[new(It0) for _ in range(8)] for _ in range(2)]    # Idt Idx Idy | Idxt Idyt Idxx Idyy Idxy
+        CuG, DuG, S = [new(U0), new(U0)], [new(U0), new(U0)], new(U0)
+        w = [[new(U0) for _ in range(4)] for _ in range(2)]
+        U, Un = [U0.clone(), U1.clone()], [new(U0), new(U0)]
+        I = [It0, It1]
+        for _ in range(int(p["firstLoop"])):
+            d, sym = [], []
+            for v in range(2):                                     # view v: own image It{v}, the other view warped by U{v}
+                dev.flow_coords(U[v], zero, X, Y)
+                dev.warp_bilinear(I[1 - v], X, Y, warped[v])       # It1w = It1 at X+U(:,:,1); It0w = It0 at X+U(:,:,2)
+            Uw = [dev.sym_warp_flow(U[0], U[1]), dev.sym_warp_flow(U[1], U[0])]   # U0w, U1w (:140-141)
+            for v in range(2):
+                dev.fst_derivatives5(I[v], warped[v], *der[v][:3])
+                dev.snd_derivatives5(I[v], warped[v], *der[v][3:])
+                d.append((der[v][0], der[v][1], der[v][3], der[v][4], der[v][5], der[v][7]))
+                sym.append(dev.sym_flow_terms(U[v], Uw[1 - v]))     # Udt0 from U1w, Udt1 from U0w
+            dU = [torch.zeros_like(U0), torch.zeros_like(U0)]
+            for k in range(int(p["secondLoop"])):
+                for v in range(2):
+                    dev.sym_assemble(d[v], sym[v], dU[v], p["b1"], p["b2"], p["alpha"], kS, sr2, k == 0, CuG[v], DuG[v])
+                    dev.add(U[v], dU[v], S)
+                    dev.diffweights6(S, 0.00001, *w[v])
+                dev.disp_sor_llin_sym4(U[0], dU[0], CuG[0], DuG[0], w[0], U[1], dU[1], CuG[1], DuG[1], w[1], int(p["iter"]), float(p["omega"]),
+                                       int(p["solver"]), self.mode)
+            for v in range(2):
+                dev.median3(U[v], dU[v], Un[v])
+            U, Un = Un, U
+        return U[0], U[1]
+
+
 class TvLevel:
     """One scale of the TV denoiser: the lagged-diffusivity loop of matlab/denoising/TVdenoise8.m:78-100
     (outer_iter + 1 times: ADdiffWeights, PsiData/TRACE/B, PDEsolver8) on device planes [F, ncols, nrows] or [ncols, nrows].

@@ -314,3 +314,49 @@ def test_resident_levels_with_grad_and_gradmag(pdeip, oracle, solver, mode, orde
     want = ms.disp_level(oracle, G0, G1, U0, param, I2t0=I0, I2t1=I1)
     got = fl.DispLlinLevel(param, mode=mode).run(g0, g1, dev.to_device(U0), d0, d1)
     same(dev.to_matlab(got), want, "disparity grad+gradmag level")
+
+
+@pytest.mark.parametrize("shape,C", [((37, 53), 1), ((40, 56), 3), ((5, 90), 2), ((70, 6), 1)])
+def test_symmetric_stereo_stages(pdeip, shape, C):
+    import torch
+    ms, dev = matlab_side(), sub("device")
+    nrows, ncols = shape
+    rng = np.random.default_rng(nrows + 11 * C)
+    f = lambda lo, hi, *s: np.asfortranarray(rng.uniform(lo, hi, size=s or shape).astype(np.float32))
+    U, Uq = f(-2, 2), f(-3, 3)
+    Uq[1, 2] = np.float32(ncols - 3)              # lands exactly on the last column
+    Uq[2, 0] = np.float32(0.0)                    # and exactly on the first
+    Uw = dev.sym_warp_flow(dev.to_device(U), dev.to_device(Uq))
+    want = ms.sym_warp_flow(U, Uq)
+    got = Uw.cpu().numpy().T
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want).any()
+    same(got, want, "interp2 flow warp %s" % (shape,))
+    terms = dev.sym_flow_terms(dev.to_device(U), Uw)
+    wterms = ms.sym_flow_terms(U, want)
+    for g, w, name in zip(terms, wterms, ("Udt", "Udx", "CuS", "DuS")):
+        same(g.cpu().numpy().T, w, name)
+    d = [f(-1, 1, nrows, ncols, C) for _ in range(6)]
+    dd = [dev.to_device(a) for a in d]
+    param = dict(b1=0.25, b2=0.72, alpha=0.035, beta=0.4)
+    outs = [torch.empty((ncols, nrows), device="cuda") for _ in range(2)]
+    for first, dU in ((True, np.zeros(shape, np.float32)), (False, f(-.5, .5))):
+        dev.sym_assemble(dd, terms, dev.to_device(dU), 0.25, 0.72, 0.035, C * 0.4 / 0.035, 1.5 ** 2, first, *outs)
+        for g, w, name in zip(outs, ms.sym_assemble(d, wterms, dU, param, C, 1.5, first), ("CuG", "DuG")):
+            got = dev.to_matlab(g)
+            assert np.array_equal(np.isnan(got), np.isnan(w))
+            same(got, w, "%s first=%s" % (name, first))
+
+
+@pytest.mark.parametrize("solver,mode,order", [(1, 0, 0), (1, 1, 1), (2, 0, 0), (2, 1, 1)])
+def test_resident_symmetric_stereo_level(pdeip, oracle, solver, mode, order):
+    ms, dev = matlab_side(), sub("device")
+    I0, I1 = frames(81, 44, 72, 2)
+    param = dict(alpha=0.035, beta=0.4, omega=1.9 if solver == 2 else 1.0, firstLoop=2, secondLoop=3, iter=3, b1=0.25, b2=0.72, solver=solver,
+                 order=order)
+    U0 = np.full((44, 72), 0.8, dtype=np.float32, order="F")
+    U1 = np.full((44, 72), -0.8, dtype=np.float32, order="F")
+    w0, w1 = ms.disp_sym_level(oracle, I0, I1, U0, U1, param, 2.0)
+    g0, g1 = sub("flow_level").DispSymLevel(param, mode=mode).run(dev.to_device(I0), dev.to_device(I1), dev.to_device(U0), dev.to_device(U1), 2.0)
+    same(dev.to_matlab(g0), w0, "symmetric level, left view (solver %d mode %d)" % (solver, mode))
+    same(dev.to_matlab(g1), w1, "symmetric level, right view (solver %d mode %d)" % (solver, mode))
+    assert np.isfinite(w0).all() and np.isfinite(w1).all()

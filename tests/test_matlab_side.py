@@ -193,3 +193,20 @@ def test_gradient_terms_statement():
     acc = lambda S: (S[:, :, 0] + S[:, :, 1]).astype(np.float32)
     assert np.array_equal(Du, acc((Ixx * Ixx + Ixy * Ixy) * gD)) and np.array_equal(M, acc((Ixy * (Ixx + Iyy)) * gD))
     assert np.array_equal(Cv, acc((Ixt * Ixy + Iyt * Iyy) * gD))
+
+
+def test_symmetric_stereo_statement():
+    """interp2 along x: integer shifts reproduce the shifted plane, NaN where the query leaves the grid; a consistent pair of
+    constant disparities (+d, -d) has zero symmetry residual."""
+    U = np.tile(np.arange(8, dtype=np.float32), (3, 1))
+    W = ms.sym_warp_flow(U, np.full((3, 8), 2.0, np.float32))
+    assert np.array_equal(W[:, :6], U[:, 2:].astype(np.float64)) and np.isnan(W[:, 6:]).all()
+    half = ms.sym_warp_flow(U, np.full((3, 8), 0.5, np.float32))
+    assert np.allclose(half[:, :7], U[:, :7] + 0.5) and np.isnan(half[:, 7]).all()
+    d = np.float32(1.0)
+    U0, U1 = np.full((5, 12), d, np.float32), np.full((5, 12), -d, np.float32)
+    Udt, Udx, CuS, DuS = ms.sym_flow_terms(U0, ms.sym_warp_flow(U1, U0))
+    inner = ~np.isnan(Udt)
+    assert inner.any() and np.all(Udt[inner] == 0)
+    flat = np.isfinite(Udx)
+    assert np.allclose(Udx[flat], 0, atol=1e-12) and np.allclose(DuS[flat], 1.0)
