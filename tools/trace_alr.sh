@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_alr
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/time_alr.py 2160 3840 1 > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/time_alr.py 2160 3840 1 > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]
