@@ -288,8 +288,9 @@ def main():
             tvp = dict(alpha=500.0, omega=1.75, outer_iter=20, inner_iter=4, solver=1)
             gI = torch.empty((NCOLS, NROWS), device=device, dtype=torch.float32).uniform_(0, 1)
             tv = {"workload": "TVdenoise8 loop, 2160x3840, outer_iter=20 (21 x [ADdiffWeights+quantile, PsiData/TRACE/B, PDEsolver8 inner_iter=4])"}
-            for name, mode in (("exact_order", capi.MODE_EXACT_ORDER), ("red_black", capi.MODE_RED_BLACK)):
-                lv = fl.TvLevel(tvp, mode=mode)
+            for name, prm, mode in (("exact_order", tvp, capi.MODE_EXACT_ORDER), ("red_black", tvp, capi.MODE_RED_BLACK),
+                                    ("zebra_alr", dict(tvp, solver=2), capi.MODE_RED_BLACK)):   # solver 2 is TVdenoise8's default
+                lv = fl.TvLevel(prm, mode=mode)
                 lv.run(gI, gI)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
