@@ -99,3 +99,18 @@ def test_resident_cycle_and_driver(pdeip, oracle, solver, mode, order, omega, cy
     gU, gV = fas.FasFmgFlow(param, mode=mode).run(dev.to_device(I0), dev.to_device(I1))
     same(dev.to_matlab(gU), wU, "driver U")
     same(dev.to_matlab(gV), wV, "driver V")
+
+
+@pytest.mark.parametrize("shape,C,solver", [((12, 14), 1, 2), ((11, 23), 2, 1), ((21, 10), 1, 2), ((5, 7), 1, 2)])
+def test_driver_on_tiny_frames(pdeip, oracle, shape, C, solver):
+    """Two-scale pyramids with 3..7-pixel coarse sides: every halving, restriction and prolongation index at its edge."""
+    ms, dev, fas, py = matlab_side(), sub("device"), sub("fas"), sub("pyramid")
+    I0, I1 = frames255(90 + shape[0], shape[0], shape[1], C)
+    param = dict(alpha=0.035, omega=1.9 if solver == 2 else 1.0, firstLoop=2, iter=2, b1=0.03, b2=0.97, scl_factor=0.5, solver=solver,
+                 cycle_index=2, order=0)
+    wU, wV = statement_fmg(ms, py, oracle, I0, I1, param)
+    drv = fas.FasFmgFlow(param, mode=0)
+    gU, gV = drv.run(dev.to_device(I0), dev.to_device(I1))
+    assert len(drv.planes) == 2 and tuple(drv.planes[1].shape[-2:]) == ((shape[1] + 1) // 2, (shape[0] + 1) // 2)
+    same(dev.to_matlab(gU), wU, "tiny driver U %s" % (shape,))
+    same(dev.to_matlab(gV), wV, "tiny driver V %s" % (shape,))

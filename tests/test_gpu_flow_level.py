@@ -360,3 +360,33 @@ def test_resident_symmetric_stereo_level(pdeip, oracle, solver, mode, order):
     same(dev.to_matlab(g0), w0, "symmetric level, left view (solver %d mode %d)" % (solver, mode))
     same(dev.to_matlab(g1), w1, "symmetric level, right view (solver %d mode %d)" % (solver, mode))
     assert np.isfinite(w0).all() and np.isfinite(w1).all()
+
+
+@pytest.mark.parametrize("shape", [(4, 4), (4, 9), (8, 4), (5, 6)])
+def test_levels_on_minimal_frames(pdeip, oracle, shape):
+    """The smallest frames the 5-tap derivative filters accept (4 pixels a side): every clamp, wrap and border rule at once."""
+    ms, dev, fl = matlab_side(), sub("device"), sub("flow_level")
+    nrows, ncols = shape
+    I0, I1 = frames(95 + nrows, nrows, ncols, 2)
+    Z = np.zeros(shape, dtype=np.float32, order="F")
+    dZ, d0, d1 = dev.to_device(Z), dev.to_device(I0), dev.to_device(I1)
+    p = dict(firstLoop=2, secondLoop=2, iter=2, omega=1.5, solver=2, alpha=0.4, b1=0.7, b2=0.3, beta=0.4, quantile=0.9, diffusion="flow",
+             sndTerm="gradmag", outer_iter=2, inner_iter=2, order=0)
+    wU, wV = ms.flow_level(oracle, I0, I1, Z, Z, p, I2t0=I0, I2t1=I1)
+    gU, gV = fl.FlowLlinLevel(p).run(d0, d1, dZ, dZ, d0, d1)
+    same(dev.to_matlab(gU), wU, "isotropic U %s" % (shape,)); same(dev.to_matlab(gV), wV, "isotropic V %s" % (shape,))
+    wU, wV = ms.flow_ad_level(oracle, I0, I1, Z, Z, p, I0, I0, I1)
+    gU, gV = fl.FlowAdLevel(p).run(d0, d1, dZ, dZ, d0, d0, d1)
+    same(dev.to_matlab(gU), wU, "anisotropic U %s" % (shape,)); same(dev.to_matlab(gV), wV, "anisotropic V %s" % (shape,))
+    same(dev.to_matlab(fl.DispLlinLevel(p).run(d0, d1, dZ, d0, d1)), ms.disp_level(oracle, I0, I1, Z, p, I2t0=I0, I2t1=I1), "disparity %s" % (shape,))
+    w0, w1 = ms.disp_sym_level(oracle, I0, I1, Z, Z, p, 2.0)
+    g0, g1 = fl.DispSymLevel(p).run(d0, d1, dZ, dZ, 2.0)
+    same(dev.to_matlab(g0), w0, "symmetric left %s" % (shape,)); same(dev.to_matlab(g1), w1, "symmetric right %s" % (shape,))
+    noisy = np.asfortranarray(np.clip(I0 * 0.3 + 0.5, 0, 1).astype(np.float32))
+    tp = dict(p, alpha=5.0, omega=1.75)
+    same(dev.to_matlab(fl.Tv4Level(tp).run(dev.to_device(noisy), dev.to_device(noisy))), ms.tv4_level(oracle, noisy, noisy, tp), "TV-4 %s" % (shape,))
+    same(dev.to_matlab(fl.TvLevel(tp).run(dev.to_device(noisy), dev.to_device(noisy))), ms.tv_level(oracle, noisy, noisy, tp), "TV-8 %s" % (shape,))
+    hp = dict(alpha=0.2, b1=0.25, b2=0.75, iter=4, omega=1.5, solver=2, order=0)
+    wU, wV = ms.hs_level(oracle, I0, I1, Z, Z, hp)
+    gU, gV = fl.FlowHsLevel(hp).run(d0, d1, dZ, dZ)
+    same(dev.to_matlab(gU), wU, "Horn-Schunck U %s" % (shape,)); same(dev.to_matlab(gV), wV, "Horn-Schunck V %s" % (shape,))
