@@ -987,9 +987,9 @@ constexpr int Z3_TILE = ZB_LW * Z3_LSF;            // floats per tile
 constexpr size_t Z3_LDS_BYTES = (size_t)2 * ZB_NM * Z3_TILE * sizeof(float);
 
 template <class Mdl, bool VERT, int MODE>
-__global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, float *x, float *__restrict__ cp,
-                                                           float *__restrict__ dv, float *__restrict__ dp, int nrows, int ncols,
-                                                           size_t frame_stride, int first, int lastc, int lstep, float omega)
+__device__ __forceinline__ void alr_zebra3_body(typename Mdl::Ctx q, float *x, float *__restrict__ cp, float *__restrict__ dv,
+                                                float *__restrict__ dp, int nrows, int ncols, size_t frame_stride, int first, int lastc,
+                                                int lstep, float omega)
 {
     extern __shared__ float z3_lds[]; // [2][ZB_NM][Z3_TILE]
     const size_t fo = (size_t)blockIdx.y * frame_stride;
@@ -1310,6 +1310,25 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
         grab(0, false);
         put(0, false);
     }
+}
+
+template <class Mdl, bool VERT, int MODE>
+__global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, float *x, float *__restrict__ cp,
+                                                           float *__restrict__ dv, float *__restrict__ dp, int nrows, int ncols,
+                                                           size_t frame_stride, int first, int lastc, int lstep, float omega)
+{
+    alr_zebra3_body<Mdl, VERT, MODE>(q, x, cp, dv, dp, nrows, ncols, frame_stride, first, lastc, lstep, omega);
+}
+
+// The factor passes of the two fields of a coupled solver in one launch (blockIdx.z = field): they are independent and each
+// is bound by its recurrence, so side by side they take the time of one.
+template <class Mdl, bool VERT>
+__global__ void __launch_bounds__(ZB_THREADS) k_alr_factor_pair(typename Mdl::Ctx q0, typename Mdl::Ctx q1, float *__restrict__ cp0,
+                                                                float *__restrict__ dv0, float *__restrict__ cp1, float *__restrict__ dv1,
+                                                                int nrows, int ncols, size_t frame_stride, int first, int lastc)
+{
+    if (blockIdx.z == 0) alr_zebra3_body<Mdl, VERT, ZB_FACTOR>(q0, nullptr, cp0, dv0, nullptr, nrows, ncols, frame_stride, first, lastc, 1, 0.0f);
+    else alr_zebra3_body<Mdl, VERT, ZB_FACTOR>(q1, nullptr, cp1, dv1, nullptr, nrows, ncols, frame_stride, first, lastc, 1, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------

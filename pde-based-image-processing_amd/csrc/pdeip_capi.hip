@@ -751,6 +751,25 @@ static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, const typename 
         for (int d = 0; d < 2; d++) {
             f->cp[c][d] = base + plane * (size_t)((c * 2 + d) * 2);
             f->dv[c][d] = f->cp[c][d] + plane;
+        }
+    static const bool old = getenv("PDEIP_ALR_ZEBRA2") != nullptr;
+    if (nch == 2 && !old) { // both fields of a coupled solver in one launch per direction
+        for (int d = 0; d < 2; d++) {
+            const int hi = (d == 0 ? ncols : nrows) - 1 - lo, count = hi - lo + 1;
+            const dim3 grid((unsigned)((count + ZB_LW - 1) / ZB_LW), (unsigned)nframes, 2);
+            if (d == 0)
+                hipLaunchKernelGGL((k_alr_factor_pair<Mdl, true>), grid, dim3(ZB_THREADS), Z3_LDS_BYTES, s, q[0], q[1], f->cp[0][0], f->dv[0][0],
+                                   f->cp[1][0], f->dv[1][0], nrows, ncols, fs, lo, hi);
+            else
+                hipLaunchKernelGGL((k_alr_factor_pair<Mdl, false>), grid, dim3(ZB_THREADS), Z3_LDS_BYTES, s, qt[0], qt[1], f->cp[0][1], f->dv[0][1],
+                                   f->cp[1][1], f->dv[1][1], nrows, ncols, fs, lo, hi);
+            g.last_launches++;
+        }
+        HIPCHK(hipGetLastError());
+        return PDEIP_OK;
+    }
+    for (int c = 0; c < nch; c++)
+        for (int d = 0; d < 2; d++) {
             const int hi = (d == 0 ? ncols : nrows) - 1 - lo;
             if (d == 0) RC((zebra3_launch<Mdl, true, ZB_FACTOR>(s, q[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
             else RC((zebra3_launch<Mdl, false, ZB_FACTOR>(s, qt[c], nullptr, f->cp[c][d], f->dv[c][d], nullptr, nrows, ncols, nframes, lo, hi, 1, 0.0f)));
