@@ -54,6 +54,34 @@ __global__ void __launch_bounds__(256) k_alr_transpose(float *__restrict__ out, 
     }
 }
 
+// Several planes in one launch (a coarse multigrid scale's call is bound by its number of launches): blockIdx.z = plane * F + frame.
+constexpr int ALR_TB_MAX = 16;
+struct AlrTransposeBatch {
+    float *out[ALR_TB_MAX];
+    const float *in[ALR_TB_MAX];
+};
+
+__global__ void __launch_bounds__(256) k_alr_transpose_batch(AlrTransposeBatch B, int na, int nb, int nframes)
+{
+    __shared__ float tile[32][33];
+    const int plane = blockIdx.z / nframes, frame = blockIdx.z % nframes;
+    const float *__restrict__ in = B.in[plane] + (size_t)frame * na * nb;
+    float *__restrict__ out = B.out[plane] + (size_t)frame * na * nb;
+    const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int a = a0 + tx, b = b0 + ty + r;
+        if (a < na && b < nb) tile[ty + r][tx] = in[(size_t)b * na + a];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int b = b0 + tx, a = a0 + ty + r;
+        if (a < na && b < nb) out[(size_t)a * nb + b] = tile[tx][ty + r];
+    }
+}
+
 // 16-byte load at 4-byte alignment (a vector type with reduced alignment keeps it one global_load_dwordx4)
 typedef float alr_v4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void alr_ld4(const float *p, float (&v)[4])

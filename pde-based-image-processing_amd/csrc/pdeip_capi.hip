@@ -877,6 +877,24 @@ static int alr_transpose(hipStream_t s, float *out, const float *in, int na, int
     return PDEIP_OK;
 }
 
+// up to ALR_TB_MAX planes per launch
+static int alr_transpose_many(hipStream_t s, float *const *out, const float *const *in, int count, int na, int nb, int nframes)
+{
+    for (int k0 = 0; k0 < count; k0 += ALR_TB_MAX) {
+        AlrTransposeBatch B{};
+        const int m = count - k0 < ALR_TB_MAX ? count - k0 : ALR_TB_MAX;
+        for (int k = 0; k < m; k++) {
+            B.out[k] = out[k0 + k];
+            B.in[k] = in[k0 + k];
+        }
+        hipLaunchKernelGGL(k_alr_transpose_batch, dim3((unsigned)((na + 31) / 32), (unsigned)((nb + 31) / 32), (unsigned)(m * nframes)), dim3(256), 0,
+                           s, B, na, nb, nframes);
+        g.last_launches++;
+    }
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 template <class Ctx>
 static int alr_make_twins(hipStream_t s, const Ctx *q, Ctx *qt, int nch, float *const *x, float **xt, int nrows, int ncols, int nframes,
                           AlrTwin *tw)
@@ -895,12 +913,19 @@ static int alr_make_twins(hipStream_t s, const Ctx *q, Ctx *qt, int nch, float *
     }
     float *base;
     RC(ws_get(WS_ALR_T, plane * tw->count * sizeof(float), &base));
+    float *outs[AlrTwin::MAXP];
+    const float *ins[AlrTwin::MAXP];
+    int nco = 0;
     for (int k = 0; k < tw->count; k++) {
         tw->twin[k] = base + plane * k;
         bool iterate = false;
         for (int c = 0; c < nch; c++) iterate = iterate || tw->orig[k] == x[c];
-        if (!iterate) RC(alr_transpose(s, tw->twin[k], tw->orig[k], nrows, ncols, nframes)); // coefficient plane: once per call
+        if (!iterate) { // coefficient plane: once per call
+            outs[nco] = tw->twin[k];
+            ins[nco++] = tw->orig[k];
+        }
     }
+    RC(alr_transpose_many(s, outs, ins, nco, nrows, ncols, nframes));
     for (int c = 0; c < nch; c++) {
         const float *tp[NP];
         for (int k = 0; k < NP; k++) tp[k] = ptrs[c][k] ? tw->find(ptrs[c][k]) : nullptr;
@@ -936,12 +961,12 @@ static int run_alr(const char *who, hipStream_t s, const typename Mdl::Ctx *q, f
             RC(alr_lex_pass<Mdl>(s, q, x, f, fwd, nch, nrows, ncols, nframes, true, omega));
         else
             for (int c = 0; c < nch; c++) RC(alr_zebra_pass<Mdl>(s, q[c], x[c], f.cp[c][0], f.dv[c][0], nrows, ncols, nframes, true, omega));
-        for (int c = 0; c < nch; c++) RC(alr_transpose(s, xt[c], x[c], nrows, ncols, nframes));
+        RC(alr_transpose_many(s, xt, x, nch, nrows, ncols, nframes));
         if (mode == PDEIP_MODE_EXACT_ORDER)
             RC(alr_lex_pass<Mdl>(s, qt, xt, f, nch == 2 ? rev : fwd, nch, nrows, ncols, nframes, false, omega));
         else
             for (int c = nch - 1; c >= 0; c--) RC(alr_zebra_pass<Mdl>(s, qt[c], xt[c], f.cp[c][1], f.dv[c][1], nrows, ncols, nframes, false, omega));
-        for (int c = 0; c < nch; c++) RC(alr_transpose(s, x[c], xt[c], ncols, nrows, nframes));
+        RC(alr_transpose_many(s, x, xt, nch, ncols, nrows, nframes));
     }
     timer.stop(iter);
     return PDEIP_OK;
