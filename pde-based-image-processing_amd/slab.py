@@ -8,10 +8,10 @@ in BASELINE.json's wording, seen from the transposed image the kernels work on).
 Why a wide halo.  A red-black sweep moves information by at most two columns, so a slab that
 carries H = 2k halo columns on each cut side can run k sweeps with no communication and still
 have bit-exact values in the columns it owns; the halo's outer columns go stale and are simply
-refreshed by the next exchange.  One exchange per solver call (k = iter, typically 4) replaces
-the 2*iter per-colour exchanges a one-column halo would need: the messages (H*nrows*4 B per
-field, 69 KB at 2160 rows and iter=4) stay latency-bound either way, so fewer is better on
-point-to-point xGMI.  The exact-order (lexicographic) mode does not decompose this way -- its
+refreshed by the next exchange.  One exchange per k sweeps (k = iter = 4, or a multiple: the budget
+carries across solver calls) replaces the 2*iter per-colour exchanges a one-column halo would need:
+the messages (H*nrows*4 B per field, 69 KB at 2160 rows and H = 8) stay latency-bound either way, so
+fewer is better on point-to-point xGMI; the price is 2H extra columns of work per interior slab.  The exact-order (lexicographic) mode does not decompose this way -- its
 dependency front crosses the whole frame -- so it is single-GPU (replicas) only.
 
 Exchange = torch.distributed batched isend/irecv (backend "nccl" is RCCL on ROCm; "gloo" in the
@@ -159,11 +159,22 @@ class SlabSolver:
             raise ValueError("halo %d < 2 * sweeps_per_exchange (%d)" % (domain.halo, sweeps_per_exchange))
         self.dom, self.k = domain, sweeps_per_exchange
         self.sweep_fn = sweep_fn if sweep_fn is not None else HIP_SWEEPS[kind]
+        self.since = None  # sweeps relaxed since the halo was last refreshed; None: unknown, exchange first
+
+    def invalidate(self):
+        """The iterate planes were changed from outside (or are different tensors): refresh the halo before the next sweep."""
+        self.since = None
 
     def solve(self, iterate, coef, iters, omega):
+        """The halo budget carries over from call to call: with sweeps_per_exchange = 8 and iters = 4 every second call
+        exchanges (the owned columns are exact as long as no more than halo/2 sweeps ran since the last refresh)."""
         done = 0
         while done < iters:
-            k = min(self.k, iters - done)
-            self.dom.exchange(iterate)
+            room = 0 if self.since is None else self.k - self.since
+            if room <= 0:
+                self.dom.exchange(iterate)
+                self.since, room = 0, self.k
+            k = min(room, iters - done)
             self.sweep_fn(iterate, coef, k, omega, self.dom.col0)
+            self.since += k
             done += k
