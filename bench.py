@@ -147,9 +147,10 @@ def main():
         return dt, ms, nl
 
     # ---- RED_BLACK ordering: value ----------------------------------------------------------------
-    # N > 1: a 2k-column halo lets k sweeps run between two halo exchanges; k = 8 = two solver calls (the step is 0.2 ms of
-    # kernel time at N = 1, an RCCL exchange is latency-bound: fewer, wider ones).  Owned columns stay bit-exact.
-    k_ex = max(ITER, env_int_py("PDEIP_SLAB_SWEEPS_PER_EXCHANGE", 2 * ITER))
+    # N > 1: a 2k-column halo lets k sweeps run between two halo exchanges; k = 16 = four solver calls (the step is 0.2 ms of
+    # kernel time at N = 1 and ~55 us split eight ways, an RCCL exchange is latency-bound: fewer, wider ones; 64 extra columns
+    # of work per interior slab).  Owned columns stay bit-exact.
+    k_ex = max(ITER, env_int_py("PDEIP_SLAB_SWEEPS_PER_EXCHANGE", 4 * ITER))
     dom = slab.SlabDomain(NCOLS, NROWS, rank, world, halo=2 * k_ex)
     U, V = dom.slice_local(U0), dom.slice_local(V0)
     coef = [dom.slice_local(t) for t in coef_full]
