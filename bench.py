@@ -295,6 +295,27 @@ def main():
                                  "secondLoop=4, iter=4; solver 1 (exact / red-black) and solver 2 zebra")
             del dG0, dG1
             out["flow_level"] = level
+            # ---- BASELINE config C5: one level of the disparity drivers at 1988x2880x3, as runme.m:20/28 configures them ----
+            jj, ii = np.meshgrid(np.arange(2880), np.arange(1988))
+            tex5 = lambda dj, c: (np.sin(0.021 * ii + c) * np.cos(0.017 * (jj + dj) - c) + 0.3 * np.sin(0.11 * ii + 0.07 * (jj + dj))).astype(np.float32)
+            dL = dev.to_device(np.stack([tex5(0, c) for c in range(3)], axis=2))
+            dR = dev.to_device(np.stack([tex5(1.3, c) for c in range(3)], axis=2))
+            gL, gR = dev.rgb2grad(dL), dev.rgb2grad(dR)
+            dZ5 = torch.zeros((2880, 1988), device=device)
+            dp = dict(firstLoop=1, secondLoop=4, iter=4, omega=1.9, alpha=0.15, b1=0.25, b2=0.72, beta=0.4, sndTerm="gradmag")
+            dl = {"workload": "firstLoop body at 1988x2880x3, secondLoop=4, iter=4: DispEminND_llin_2D ('grad','gradmag': 6 + 3 planes) and "
+                              "DispEminND_llin_sym_2D (both views)", "unit": "ms"}
+            for name, prm, mode in (("red_black", dict(dp, solver=1, omega=1.5), capi.MODE_RED_BLACK), ("zebra_alr", dict(dp, solver=2, omega=1.5), capi.MODE_RED_BLACK)):
+                for tag, run in (("disparity_", lambda lv=fl.DispLlinLevel(prm, mode=mode): lv.run(gL, gR, dZ5, dL, dR)),
+                                 ("symmetric_", lambda lv=fl.DispSymLevel(prm, mode=mode): lv.run(dL, dR, dZ5, dZ5, 2.0))):
+                    run(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        run()
+                    torch.cuda.synchronize()
+                    dl[tag + name] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+            out["disparity_level"] = dl
+            del dL, dR, gL, gR, dZ5
             # ---- the lagged-diffusivity loop of the TV denoiser resident in HBM (BASELINE config C3: 2160x3840 gray) ----
             tvp = dict(alpha=500.0, omega=1.75, outer_iter=20, inner_iter=4, solver=1)
             gI = torch.empty((NCOLS, NROWS), device=device, dtype=torch.float32).uniform_(0, 1)
