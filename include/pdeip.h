@@ -308,6 +308,11 @@ int pdeip_flow_assemble_gradmag_dev(void *stream, const float *It1, const float 
 int pdeip_disp_assemble_gradmag_dev(void *stream, const float *It1, const float *Ix1, int C1, float b1, const float *Ixt,
                                     const float *Iyt, const float *Ixx, const float *Ixy, int C2, float b2, const float *dU, float alpha,
                                     int nrows, int ncols, float *CuGd, float *DuGd);
+/* The spatial a-priori slice of that assembly (:262-270, :301-318; param.Us / param.Vs, gammaS): appends ASCu.*gSu to CGd and
+ * 1.*gSu to DGd (nansum).  Us: the constraint field of the scale, a MATLAB double array; as_diff = 2*(1/scl_factor)^-(scl-1);
+ * u_double: U is still the double array of the coarsest scale's first firstLoop; du_double: first inner iteration (dU = zeros). */
+int pdeip_flow_apriori_dev(void *stream, const double *Us, const float *U, const float *dU, double gammaS, double alpha,
+                           double as_diff, int u_double, int du_double, int nrows, int ncols, float *CGd, float *DGd);
 /* rgb2grad (FlowEminND_llin_2D_v10.m:368-381; fstTerm 'grad'): out [.. x 2*nframes], frames 2f-1 / 2f (1-based) = the [1 0 -1]
  * differences of input frame f along x / y, replicate borders */
 int pdeip_rgb2grad_dev(void *stream, const float *in, int nrows, int ncols, int nframes, float *out);

@@ -71,6 +71,27 @@ def flow_assemble(term1, term2, dU, dV, alpha):
     return outs
 
 
+def apriori_slices(Us, U, dU, gammaS, alpha, as_diff, u_double, du_double):
+    """[ASCu.*gSu, ASDu.*gSu] as the single slices cat() makes of them (:262-270, :301-318).  Us: float64 constraint field.
+    u_double: U is still MATLAB's double array (coarsest scale, first firstLoop); du_double: dU is the double zeros of :272."""
+    Us = Us.astype(np.float64)
+    asd2 = as_diff * as_diff
+    if u_double and du_double:
+        asc = Us - U.astype(np.float64)
+        t = asc - dU.astype(np.float64)
+        gS = gammaS / (alpha * (1.0 + (t * t) / asd2))
+        return (asc * gS).astype(F32), gS.astype(F32)
+    asc = (Us - U.astype(np.float64)).astype(F32) if u_double else (Us.astype(F32) - U.astype(F32)).astype(F32)
+    t = (asc - dU.astype(F32)).astype(F32)
+    gS = (F32(gammaS) / (F32(alpha) * (F32(1) + ((t * t).astype(F32) / F32(asd2)).astype(F32)).astype(F32)).astype(F32)).astype(F32)
+    return (asc * gS).astype(F32), gS
+
+
+def nan_append(acc, v):
+    """One more slice of a nansum"""
+    return np.where(np.isnan(v), acc, (acc + v).astype(F32))
+
+
 def _shift(A, di, dj):
     """circshift(A, [di dj]): element (i,j) takes A(i-di, j-dj), wrapping."""
     return np.roll(np.roll(A, di, axis=0), dj, axis=1)
@@ -113,12 +134,12 @@ def median3_sum(A, B=None):
     return np.sort(stack, axis=0)[4].astype(F32)
 
 
-def flow_level(orc, I1t0, I1t1, U, V, param, I2t0=None, I2t1=None):
+def flow_level(orc, I1t0, I1t1, U, V, param, I2t0=None, I2t1=None, Us=None, Vs=None, as_diff=None, u_double=False):
     """One pyramid level (:208-356, without the pyramid's imresize): firstLoop x [warp, derivatives,
     secondLoop x (assembly, diffusion weights, Oflow_sor_llin4_2d)], median.  `orc` = tests/oracle_lib.
     param: firstLoop, secondLoop, iter, omega, solver, alpha, b1, b2, order (oracle sweep/line order)."""
     U, V = U.astype(F32), V.astype(F32)
-    for _ in range(param["firstLoop"]):
+    for first in range(param["firstLoop"]):
         X, Y = flow_coords(U, V)
         w1 = orc.BilinInterp_2d(I1t1, X, Y)
         t1 = orc.FstDerivatives5(I1t0, w1) + (param["b1"],)
@@ -128,8 +149,14 @@ def flow_level(orc, I1t0, I1t1, U, V, param, I2t0=None, I2t1=None):
             snd = param.get("sndTerm", "rgb") == "gradmag"
             t2 = (orc.SndDerivatives5(I2t0, w2) if snd else orc.FstDerivatives5(I2t0, w2)) + (param["b2"],)
         dU, dV = np.zeros_like(U), np.zeros_like(V)
-        for _ in range(param["secondLoop"]):
+        for k in range(param["secondLoop"]):
             MGd, CuGd, CvGd, DuGd, DvGd = flow_assemble(t1, t2, dU, dV, param["alpha"])
+            if Us is not None:
+                c, d = apriori_slices(Us, U, dU, param["gammaS"], param["alpha"], as_diff, u_double and first == 0, k == 0)
+                CuGd, DuGd = nan_append(CuGd, c), nan_append(DuGd, d)
+            if Vs is not None:
+                c, d = apriori_slices(Vs, V, dV, param["gammaS"], param["alpha"], as_diff, u_double and first == 0, k == 0)
+                CvGd, DvGd = nan_append(CvGd, c), nan_append(DvGd, d)
             wW, wN, wS, wE = op_diff_weights(U, V, dU, dV)
             dU, dV = orc.Oflow_sor_llin4_2d(U, V, dU, dV, MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wE, wS, param["iter"],
                                             param["omega"], solver=param["solver"], order=param["order"])
@@ -562,8 +589,8 @@ def fas_fmg(orc, I0, I1, param, max_scales=None):
 # ---------------------------------------------------------------------------------------------------------
 # Anisotropic-diffusion flow with late linearisation (matlab/optical_flow/FlowEminAD_llin_2D_v10.m)
 # ---------------------------------------------------------------------------------------------------------
-def flow_ad_level(orc, I1t0, I1t1, U, V, param, It0, I2t0=None, I2t1=None):
-    """One pyramid level (:198-366, without imresize, the GRADMAG second term and the spatial a-priori terms):
+def flow_ad_level(orc, I1t0, I1t1, U, V, param, It0, I2t0=None, I2t1=None, Us=None, Vs=None, as_diff=None, u_double=False):
+    """One pyramid level (:198-366, without imresize):
     anisotropic weights from the image It0 ('image', once per level) or from U+dU+V+dV ('flow', every inner iteration),
     robust assembly as in the isotropic driver, Oflow_sor_llin8_2d, median.
     param: firstLoop, secondLoop, iter, omega, solver, alpha, b1, b2, quantile, diffusion, order."""
@@ -571,7 +598,7 @@ def flow_ad_level(orc, I1t0, I1t1, U, V, param, It0, I2t0=None, I2t1=None):
     single = lambda ws: [np.asfortranarray(w.astype(F32)) for w in ws]
     if param["diffusion"] == "image":
         w8 = single(ad_diff_weights(It0, param["quantile"])[0])
-    for _ in range(param["firstLoop"]):
+    for first in range(param["firstLoop"]):
         X, Y = flow_coords(U, V)
         t1 = orc.FstDerivatives5(I1t0, orc.BilinInterp_2d(I1t1, X, Y)) + (param["b1"],)
         t2 = None
@@ -580,8 +607,14 @@ def flow_ad_level(orc, I1t0, I1t1, U, V, param, It0, I2t0=None, I2t1=None):
             w2 = orc.BilinInterp_2d(I2t1, X, Y)
             t2 = (orc.SndDerivatives5(I2t0, w2) if snd else orc.FstDerivatives5(I2t0, w2)) + (param["b2"],)
         dU, dV = np.zeros_like(U), np.zeros_like(V)
-        for _ in range(param["secondLoop"]):
+        for k in range(param["secondLoop"]):
             MGd, CuGd, CvGd, DuGd, DvGd = flow_assemble(t1, t2, dU, dV, param["alpha"])
+            if Us is not None:
+                c, d = apriori_slices(Us, U, dU, param["gammaS"], param["alpha"], as_diff, u_double and first == 0, k == 0)
+                CuGd, DuGd = nan_append(CuGd, c), nan_append(DuGd, d)
+            if Vs is not None:
+                c, d = apriori_slices(Vs, V, dV, param["gammaS"], param["alpha"], as_diff, u_double and first == 0, k == 0)
+                CvGd, DvGd = nan_append(CvGd, c), nan_append(DvGd, d)
             if param["diffusion"] == "flow":
                 w8 = single(ad_diff_weights((((U + dU).astype(F32) + V).astype(F32) + dV).astype(F32), param["quantile"])[0])
             dU, dV = orc.Oflow_sor_llin8_2d(U, V, dU, dV, MGd, CuGd, CvGd, DuGd, DvGd, *w8, param["iter"], param["omega"],

@@ -88,6 +88,36 @@ __global__ void k_flow_assemble(float *MGd, float *CuGd, float *CvGd, float *DuG
     DvGd[pos] = Dv;
 }
 
+// Spatial a-priori slice of the assembly (:262-270, :301-318, :321-325): with a constraint field Us (a MATLAB double array)
+//   ASCu = Us - U;  APUnorm = (Us - U - dU).^2;  gSu = gammaS./(alpha*(1 + APUnorm/ASdiff^2))
+// and nansum(cat(3, ..., ASCu.*gSu), 3) / nansum(cat(3, ..., 1.*gSu), 3) append one more slice to CuGd / DuGd.  MATLAB's
+// typing decides the arithmetic: U is double only before the first median of the coarsest scale (u_double), dU is the double
+// zeros of :272 in the first inner iteration (du_double) and single afterwards; a double meeting a single is rounded first.
+__global__ void k_flow_apriori(float *CGd, float *DGd, const double *Us, const float *U, const float *dU, double gammaS, double alpha,
+                               double asd2, int u_double, int du_double, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    float cS, dS;
+    if (u_double && du_double) {
+        const double asc = Us[pos] - (double)U[pos];
+        const double t = asc - (double)dU[pos];
+        const double gS = gammaS / (alpha * (1.0 + (t * t) / asd2));
+        cS = (float)(asc * gS);
+        dS = (float)gS;
+    } else {
+        const float asc = u_double ? (float)(Us[pos] - (double)U[pos]) : (float)Us[pos] - U[pos];
+        const float t = asc - dU[pos];
+        const float gS = (float)gammaS / ((float)alpha * (1.0f + (t * t) / (float)asd2));
+        cS = asc * gS;
+        dS = gS;
+    }
+    float c = CGd[pos], d = DGd[pos];
+    nan_add(c, cS);
+    nan_add(d, dS);
+    CGd[pos] = c;
+    DGd[pos] = d;
+}
+
 // Disparity twin of the assembly (matlab/disparity/DispEminND_llin_2D.m:258-293): one unknown, and a plain
 // sum() over the channels -- a NaN (out-of-range warp) propagates into CuGd/DuGd, where the solver's
 // isnan(Cu) test picks it up (disparitySolvers.c:66).

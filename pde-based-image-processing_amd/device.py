@@ -399,3 +399,12 @@ def sym_assemble(d, sym, dU, b1, b2, alpha, kS, sr2, first, CuG, DuG):
     nrows, ncols, C = _dims(d[0])
     capi.call("pdeip_sym_assemble_dev", _stream(), *_p(*d), C, *_p(*sym), dU.data_ptr(), float(b1), float(b2), float(alpha), float(kS),
               float(sr2), int(bool(first)), nrows, ncols, *_p(CuG, DuG))
+
+
+def flow_apriori(Us, U, dU, gammaS, alpha, as_diff, u_double, du_double, CGd, DGd):
+    """Adds the spatial a-priori slice (FlowEminND_llin_2D_v10.m:301-325) to CGd / DGd in place; Us float64."""
+    _chk(U, dU, CGd, DGd)
+    _chk64(Us)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_flow_apriori_dev", _stream(), Us.data_ptr(), U.data_ptr(), dU.data_ptr(), float(gammaS), float(alpha), float(as_diff),
+              int(bool(u_double)), int(bool(du_double)), nrows, ncols, CGd.data_ptr(), DGd.data_ptr())

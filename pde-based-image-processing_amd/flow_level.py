@@ -23,9 +23,11 @@ class FlowLlinLevel:
         fn = dev.oflow_sor_llin4 if int(self.p["solver"]) == 1 else dev.oflow_alr_llin4
         fn(U, V, dU, dV, *coef, int(self.p["iter"]), float(self.p["omega"]), self.mode)
 
-    def run(self, I1t0, I1t1, U, V, I2t0=None, I2t1=None):
+    def run(self, I1t0, I1t1, U, V, I2t0=None, I2t1=None, Us=None, Vs=None, as_diff=None, u_double=False):
         """I*: [C, ncols, nrows] images of the two frames (first / optional second constancy term);
-        U, V: [ncols, nrows] flow entering the level.  Returns the flow leaving it (new tensors)."""
+        U, V: [ncols, nrows] flow entering the level.  Returns the flow leaving it (new tensors).
+        Us, Vs: optional spatial a-priori fields of this scale (float64, param.Us / param.Vs with gammaS in param) with
+        as_diff = 2*(1/scl_factor)^-(scl-1); u_double: this is the coarsest scale (U is still a MATLAB double in its first firstLoop)."""
         p = self.p
         new = lambda like: torch.empty_like(like)
         X, Y = new(U), new(U)
@@ -35,7 +37,7 @@ class FlowLlinLevel:
         coef = [new(U) for _ in range(9)]  # MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wE, wS
         U, V = U.clone(), V.clone()
         Un, Vn = new(U), new(U)
-        for _ in range(int(p["firstLoop"])):
+        for first in range(int(p["firstLoop"])):
             dev.flow_coords(U, V, X, Y)
             dev.warp_bilinear(I1t1, X, Y, w1)
             dev.fst_derivatives5(I1t0, w1, *d1)                      # Idt, Idx, Idy
@@ -49,8 +51,12 @@ class FlowLlinLevel:
                     dev.fst_derivatives5(I2t0, w2, *d2)
                     t2 = (d2[0], d2[1], d2[2], p["b2"])
             dU, dV = torch.zeros_like(U), torch.zeros_like(V)
-            for _ in range(int(p["secondLoop"])):
+            for k in range(int(p["secondLoop"])):
                 dev.flow_assemble(t1, t2, dU, dV, p["alpha"], *coef[:5])
+                if Us is not None:
+                    dev.flow_apriori(Us, U, dU, p["gammaS"], p["alpha"], as_diff, u_double and first == 0, k == 0, coef[1], coef[3])
+                if Vs is not None:
+                    dev.flow_apriori(Vs, V, dV, p["gammaS"], p["alpha"], as_diff, u_double and first == 0, k == 0, coef[2], coef[4])
                 dev.flow_opdiffweights(U, V, dU, dV, coef[5], coef[6], coef[8], coef[7])   # returns wW wN wS wE
                 self._solve(U, V, dU, dV, coef)
             dev.median3(U, dU, Un)
@@ -63,13 +69,14 @@ class FlowLlinLevel:
 class FlowAdLevel:
     """The anisotropic-diffusion twin (matlab/optical_flow/FlowEminAD_llin_2D_v10.m:198-366): eight ADdiffWeights from
     the image (`diffusion` 'image', once per level) or from U+dU+V+dV ('flow', every inner iteration), and
-    Oflow_sor_llin8_2d.  Not built: the GRADMAG second term and the spatial a-priori terms.
+    Oflow_sor_llin8_2d.
     param: firstLoop, secondLoop, iter, omega, solver, alpha, b1, b2, quantile, diffusion."""
 
     def __init__(self, param, mode=capi.MODE_EXACT_ORDER):
         self.p, self.mode = dict(param), mode
 
-    def run(self, I1t0, I1t1, U, V, It0, I2t0=None, I2t1=None):
+    def run(self, I1t0, I1t1, U, V, It0, I2t0=None, I2t1=None, Us=None, Vs=None, as_diff=None, u_double=False):
+        """Us, Vs, as_diff, u_double: the spatial a-priori fields as in FlowLlinLevel.run."""
         p = self.p
         new = lambda like: torch.empty_like(like)
         X, Y, S = new(U), new(U), new(U)
@@ -87,7 +94,7 @@ class FlowAdLevel:
             dev.ad_weights(It0, p["quantile"], w8)
         U, V = U.clone(), V.clone()
         Un, Vn = new(U), new(U)
-        for _ in range(int(p["firstLoop"])):
+        for first in range(int(p["firstLoop"])):
             dev.flow_coords(U, V, X, Y)
             dev.warp_bilinear(I1t1, X, Y, w1)
             dev.fst_derivatives5(I1t0, w1, *d1)
@@ -101,8 +108,12 @@ class FlowAdLevel:
                     dev.fst_derivatives5(I2t0, w2, *d2)
                     t2 = (d2[0], d2[1], d2[2], p["b2"])
             dU, dV = torch.zeros_like(U), torch.zeros_like(V)
-            for _ in range(int(p["secondLoop"])):
+            for k in range(int(p["secondLoop"])):
                 dev.flow_assemble(t1, t2, dU, dV, p["alpha"], *coef)
+                if Us is not None:
+                    dev.flow_apriori(Us, U, dU, p["gammaS"], p["alpha"], as_diff, u_double and first == 0, k == 0, coef[1], coef[3])
+                if Vs is not None:
+                    dev.flow_apriori(Vs, V, dV, p["gammaS"], p["alpha"], as_diff, u_double and first == 0, k == 0, coef[2], coef[4])
                 if p["diffusion"] == "flow":
                     dev.add(U, dU, S); dev.add(S, V, S); dev.add(S, dV, S)      # U+dU+V+dV, left to right
                     dev.ad_weights(S, p["quantile"], w8)

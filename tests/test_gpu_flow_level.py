@@ -390,3 +390,52 @@ def test_levels_on_minimal_frames(pdeip, oracle, shape):
     wU, wV = ms.hs_level(oracle, I0, I1, Z, Z, hp)
     gU, gV = fl.FlowHsLevel(hp).run(d0, d1, dZ, dZ)
     same(dev.to_matlab(gU), wU, "Horn-Schunck U %s" % (shape,)); same(dev.to_matlab(gV), wV, "Horn-Schunck V %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (6, 90)])
+def test_spatial_apriori_slice(pdeip, shape):
+    import torch
+    ms, dev = matlab_side(), sub("device")
+    rng = np.random.default_rng(shape[0])
+    f = lambda lo, hi: np.asfortranarray(rng.uniform(lo, hi, size=shape).astype(np.float32))
+    U, dU, C0, D0 = f(-2, 2), f(-.5, .5), f(-1, 1), f(0, 2)
+    C0[1, 2] = np.nan                                         # an all-NaN data stack gives nansum 0 there; here: a NaN carried in
+    Us = np.asfortranarray(rng.uniform(-2, 2, size=shape))    # float64, not single-representable
+    dUs = torch.from_numpy(np.ascontiguousarray(Us.T)).cuda()
+    for u_double in (False, True):
+        for du_double in (False, True):
+            dUx = np.zeros(shape, np.float32) if du_double else dU
+            gC, gD = dev.to_device(C0), dev.to_device(D0)
+            dev.flow_apriori(dUs, dev.to_device(U), dev.to_device(dUx), 0.01, 0.042, 1.125, u_double, du_double, gC, gD)
+            c, d = ms.apriori_slices(Us, U, dUx, 0.01, 0.042, 1.125, u_double, du_double)
+            wC, wD = ms.nan_append(C0, c), ms.nan_append(D0, d)
+            got = dev.to_matlab(gC)
+            assert np.array_equal(np.isnan(got), np.isnan(wC))
+            same(got, wC, "a-priori Cu (u_double=%s du_double=%s)" % (u_double, du_double))
+            same(dev.to_matlab(gD), wD, "a-priori Du (u_double=%s du_double=%s)" % (u_double, du_double))
+
+
+@pytest.mark.parametrize("solver,mode,order,u_double", [(2, 0, 0, True), (1, 1, 1, False)])
+def test_resident_levels_with_spatial_apriori(pdeip, oracle, solver, mode, order, u_double):
+    import torch
+    ms, dev, fl = matlab_side(), sub("device"), sub("flow_level")
+    I0, I1 = frames(73, 40, 52, 2)
+    rng = np.random.default_rng(12)
+    Us = np.asfortranarray(rng.uniform(-1, 1, size=(40, 52)))
+    Vs = np.asfortranarray(rng.uniform(-1, 1, size=(40, 52)))
+    U0 = np.asfortranarray(Us.astype(np.float32)) if not u_double else np.asfortranarray(np.round(Us * 4) / 4).astype(np.float32)
+    V0 = np.zeros((40, 52), dtype=np.float32, order="F")
+    param = dict(firstLoop=2, secondLoop=2, iter=3, omega=1.9 if solver == 2 else 1.0, solver=solver, alpha=0.3, b1=0.6, b2=0.4, gammaS=0.01,
+                 quantile=0.9, diffusion="image", order=order)
+    t64 = lambda A: torch.from_numpy(np.ascontiguousarray(A.T)).cuda()
+    d0, d1 = dev.to_device(I0), dev.to_device(I1)
+    for only_u in (False, True):
+        vs, dvs = (None, None) if only_u else (Vs, t64(Vs))
+        wU, wV = ms.flow_level(oracle, I0, I1, U0, V0, param, Us=Us, Vs=vs, as_diff=1.5, u_double=u_double)
+        gU, gV = fl.FlowLlinLevel(param, mode=mode).run(d0, d1, dev.to_device(U0), dev.to_device(V0), Us=t64(Us), Vs=dvs, as_diff=1.5,
+                                                        u_double=u_double)
+        same(dev.to_matlab(gU), wU, "a-priori level U (only_u=%s)" % only_u); same(dev.to_matlab(gV), wV, "a-priori level V (only_u=%s)" % only_u)
+    wU, wV = ms.flow_ad_level(oracle, I0, I1, U0, V0, param, I0, Us=Us, Vs=Vs, as_diff=1.5, u_double=u_double)
+    gU, gV = fl.FlowAdLevel(param, mode=mode).run(d0, d1, dev.to_device(U0), dev.to_device(V0), d0, Us=t64(Us), Vs=t64(Vs), as_diff=1.5,
+                                                  u_double=u_double)
+    same(dev.to_matlab(gU), wU, "anisotropic a-priori level U"); same(dev.to_matlab(gV), wV, "anisotropic a-priori level V")

@@ -210,3 +210,21 @@ def test_symmetric_stereo_statement():
     assert inner.any() and np.all(Udt[inner] == 0)
     flat = np.isfinite(Udx)
     assert np.allclose(Udx[flat], 0, atol=1e-12) and np.allclose(DuS[flat], 1.0)
+
+
+def test_spatial_apriori_slices():
+    """At the constraint itself (U + dU == Us) the influence function is gammaS/alpha and ASCu vanishes with dU = 0; the
+    double and single evaluations agree to single precision."""
+    Us = np.random.default_rng(3).uniform(-1, 1, (5, 6))
+    U = Us.astype(np.float32)
+    Z = np.zeros((5, 6), np.float32)
+    c, d = ms.apriori_slices(U.astype(np.float64), U, Z, 0.01, 0.042, 2.0, False, True)
+    assert np.all(c == 0) and np.all(d == np.float32(0.01) / np.float32(0.042))
+    dU = np.full((5, 6), 0.25, np.float32)
+    outs = [ms.apriori_slices(Us, U, dU, 0.01, 0.042, 2.0, ud, False) for ud in (False, True)]
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=1e-7); np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-6)
+    A = ms.apriori_slices(Us, U, Z, 0.01, 0.042, 2.0, True, True)
+    np.testing.assert_allclose(A[1], outs[1][1] * 0 + A[1], rtol=0)          # finite
+    assert np.isfinite(A[0]).all() and np.all(A[1] > 0)
+    acc = ms.nan_append(np.array([1.0, np.nan], np.float32), np.array([np.nan, 2.0], np.float32))
+    assert acc[0] == 1.0 and np.isnan(acc[1])
