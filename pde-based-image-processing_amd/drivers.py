@@ -1,0 +1,184 @@
+"""The MATLAB drivers as Python functions: same names, arguments and default parameters, every pyramid level resident on the
+device (flow_level.py, fas.py), the pyramid around them on the host (pyramid.py: our definitions of imresize / imfilter /
+fspecial, there being no IPT to compare with).  Inputs and outputs are MATLAB-shaped numpy arrays ([nrows, ncols(, C)],
+images in 0..255 as the drivers expect); `mode` selects the ordering (capi.MODE_EXACT_ORDER reproduces the reference's order,
+capi.MODE_RED_BLACK the parallel one).
+
+    FlowEminND_llin_2D_v10      matlab/optical_flow/FlowEminND_llin_2D_v10.m      isotropic late-linearisation flow
+    FlowEminAD_llin_2D_v10      matlab/optical_flow/FlowEminAD_llin_2D_v10.m      anisotropic diffusion
+    FlowEminHS_elin_2D_v10      matlab/optical_flow/FlowEminHS_elin_2D_v10.m      Horn-Schunck, early linearisation
+    FlowEminNDFASFMG_elin_2D_v10 matlab/optical_flow/FlowEminNDFASFMG_elin_2D_v10.m FAS full multigrid
+    DispEminND_llin_2D          matlab/disparity/DispEminND_llin_2D.m             stereo disparity
+    DispEminND_llin_sym_2D      matlab/disparity/DispEminND_llin_sym_2D.m         symmetric stereo
+    TVdenoise8 / TVdenoise4     matlab/denoising/TVdenoise{8,4}.m                 total-variation denoising
+
+Not carried over: the spatial a-priori inputs at driver level (the levels take them: Us=, Vs=) and `scales` limits.
+"""
+import math
+
+import numpy as np
+
+from . import capi, device as dev, fas, flow_level as fl, pyramid
+
+
+def _frames(Iin, channels):
+    I = np.asarray(Iin, dtype=np.float32)
+    I = I if I.ndim == 3 else I[:, :, None]
+    return np.asfortranarray(I[:, :, :channels]), np.asfortranarray(I[:, :, channels:2 * channels])
+
+
+def _c3(I):
+    I = np.asarray(I, dtype=np.float32)
+    return np.asfortranarray(I if I.ndim == 3 else I[:, :, None])
+
+
+def _terms(d0, d1, fst, snd):
+    """First / second constancy images of one scale on the device (:133-170 of the ND driver)."""
+    fst, snd = fst.upper(), snd.upper()
+    if fst not in ("RGB", "GRAD") or snd not in ("NONE", "RGB", "GRADMAG"):
+        raise ValueError("No such fstTerm / sndTerm")
+    I1 = (d0, d1) if fst == "RGB" else (dev.rgb2grad(d0), dev.rgb2grad(d1))
+    I2 = (None, None) if snd == "NONE" else (d0, d1)
+    return I1, I2
+
+
+def _flow_llin(level_cls, Iin, channels, fstTerm, sndTerm, defaults, mode, param):
+    p = dict(defaults, **param)
+    p["sndTerm"] = sndTerm.lower()
+    I0, I1 = _frames(Iin, channels)
+    P0, P1 = pyramid.build(I0 / np.float32(255), I1 / np.float32(255), p["scl_factor"], 20)
+    level = level_cls(p, mode=mode)
+    U = np.zeros(P0[-1].shape[:2], dtype=np.float32)
+    V = np.zeros_like(U)
+    for scl in range(len(P0) - 1, -1, -1):
+        d0, d1 = dev.to_device(P0[scl]), dev.to_device(P1[scl])
+        (a0, a1), (b0, b1) = _terms(d0, d1, fstTerm, sndTerm)
+        args = (a0, a1, dev.to_device(U), dev.to_device(V)) + ((d0,) if level_cls is fl.FlowAdLevel else ()) + (b0, b1)
+        gU, gV = level.run(*args)
+        U, V = dev.to_matlab(gU), dev.to_matlab(gV)
+        if scl > 0:
+            rows, cols = P0[scl - 1].shape[:2]
+            inv = np.float32(1.0 / p["scl_factor"])
+            U, V = pyramid.resize(U * inv, rows, cols), pyramid.resize(V * inv, rows, cols)
+    return U, V
+
+
+ND_DEFAULTS = dict(alpha=0.042, omega=1.9, gammaS=0.01, firstLoop=4, secondLoop=4, iter=4, b1=1.4843, b2=0.2915, scl_factor=0.75, solver=2)
+AD_DEFAULTS = dict(ND_DEFAULTS, quantile=0.9, diffusion="image")
+
+
+def FlowEminND_llin_2D_v10(Iin, channels, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, **param):
+    """[U V] = FlowEminND_llin_2D_v10(Iin, channels, fstTerm, sndTerm, ...): Iin = cat(3, frame0, frame1)."""
+    return _flow_llin(fl.FlowLlinLevel, Iin, channels, fstTerm, sndTerm, ND_DEFAULTS, mode, param)
+
+
+def FlowEminAD_llin_2D_v10(Iin, channels, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, **param):
+    return _flow_llin(fl.FlowAdLevel, Iin, channels, fstTerm, sndTerm, AD_DEFAULTS, mode, param)
+
+
+HS_DEFAULTS = dict(alpha=0.2, omega=1.9, iter=20, b1=0.25, b2=0.75, scl_factor=0.75, solver=2)
+
+
+def FlowEminHS_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
+    p = dict(HS_DEFAULTS, **param)
+    I0, I1 = _frames(Iin, channels)
+    P0, P1 = pyramid.build(I0 / np.float32(255), I1 / np.float32(255), p["scl_factor"], 20)
+    level = fl.FlowHsLevel(p, mode=mode)
+    U = np.zeros(P0[-1].shape[:2], dtype=np.float32)
+    V = np.zeros_like(U)
+    for scl in range(len(P0) - 1, -1, -1):
+        gU, gV = level.run(dev.to_device(P0[scl]), dev.to_device(P1[scl]), dev.to_device(U), dev.to_device(V))
+        U, V = dev.to_matlab(gU), dev.to_matlab(gV)
+        if scl > 0:   # imresize(medfilt2(U.*(1/scl_factor), [3 3], 'symmetric'), 'OutputSize', ...): the default, bicubic, method (:189-190)
+            rows, cols = P0[scl - 1].shape[:2]
+            inv = np.float32(1.0 / p["scl_factor"])
+            U = pyramid.resize(pyramid.median3(U * inv), rows, cols, method="bicubic")
+            V = pyramid.resize(pyramid.median3(V * inv), rows, cols, method="bicubic")
+    return U, V
+
+
+def FlowEminNDFASFMG_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
+    I0, I1 = _frames(Iin, channels)
+    gU, gV = fas.FasFmgFlow(param, mode=mode).run(dev.to_device(I0), dev.to_device(I1))
+    return dev.to_matlab(gU), dev.to_matlab(gV)
+
+
+DISP_DEFAULTS = dict(alpha=0.042, gammaS=0.005, omega=1.9, firstLoop=4, secondLoop=6, iter=4, b1=1.48, b2=0.29, scl_factor=0.75, solver=2)   # DispEminND_llin_2D.m:51-63
+
+
+def DispEminND_llin_2D(Il, Ir, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, **param):
+    p = dict(DISP_DEFAULTS, **param)
+    p["sndTerm"] = sndTerm.lower()
+    P0, P1 = pyramid.build(_c3(Il) / np.float32(255), _c3(Ir) / np.float32(255), p["scl_factor"], 10)
+    level = fl.DispLlinLevel(p, mode=mode)
+    U = np.zeros(P0[-1].shape[:2], dtype=np.float32)
+    for scl in range(len(P0) - 1, -1, -1):
+        d0, d1 = dev.to_device(P0[scl]), dev.to_device(P1[scl])
+        (a0, a1), (b0, b1) = _terms(d0, d1, fstTerm, sndTerm)
+        U = dev.to_matlab(level.run(a0, a1, dev.to_device(U), b0, b1))
+        if scl > 0:
+            rows, cols = P0[scl - 1].shape[:2]
+            U = pyramid.resize(U * np.float32(1.0 / p["scl_factor"]), rows, cols)
+    return U
+
+
+SYM_DEFAULTS = dict(alpha=0.035, beta=0.4, omega=1.9, firstLoop=3, secondLoop=4, iter=4, b1=0.25, b2=0.72, scl_factor=0.75, solver=2)
+
+
+def DispEminND_llin_sym_2D(Il, Ir, mode=capi.MODE_EXACT_ORDER, **param):
+    """-> U [nrows, ncols, 2] (left-to-right and right-to-left disparity)."""
+    p = dict(SYM_DEFAULTS, **param)
+    P0, P1 = [_c3(Il)], [_c3(Ir)]                                 # no /255 in this driver (:81-82)
+    G = pyramid.gaussian(3, 1.0)
+    while True:
+        rows, cols = P0[-1].shape[:2]
+        nr, nc = int(math.ceil(rows * p["scl_factor"])), int(math.ceil(cols * p["scl_factor"]))
+        P0.append(pyramid.resize(P0[-1], nr, nc)); P1.append(pyramid.resize(P1[-1], nr, nc))
+        P0[-2], P1[-2] = pyramid.smooth(P0[-2], G), pyramid.smooth(P1[-2], G)
+        if nr <= 10 or nc <= 10:                                  # the last scale stays unsmoothed here (:94-98)
+            break
+    level = fl.DispSymLevel(p, mode=mode)
+    U0 = np.zeros(P0[-1].shape[:2], dtype=np.float32)
+    U1 = np.zeros_like(U0)
+    for scl in range(len(P0) - 1, -1, -1):
+        sr = 2.0 * (1.0 / p["scl_factor"]) ** (-scl)              # srDiff = 2*(1/scl_factor)^-(scl-1), scl 1-based there
+        g0, g1 = level.run(dev.to_device(P0[scl]), dev.to_device(P1[scl]), dev.to_device(U0), dev.to_device(U1), sr)
+        U0, U1 = dev.to_matlab(g0), dev.to_matlab(g1)
+        if scl > 0:
+            rows, cols = P0[scl - 1].shape[:2]
+            inv = np.float32(1.0 / p["scl_factor"])
+            U0, U1 = pyramid.resize(U0 * inv, rows, cols), pyramid.resize(U1 * inv, rows, cols)
+    return np.stack([U0, U1], axis=2)
+
+
+def _tv(I_in, level_cls, p, G, smooth_last):
+    Iin = [np.asfortranarray(np.asarray(I_in, dtype=np.float32))]
+    rows, cols = Iin[0].shape[:2]
+    ds_rows, ds_cols = math.ceil(rows * p["scl"]), math.ceil(cols * p["scl"])
+    while True:
+        r, c = Iin[-1].shape[:2]
+        nr, nc = int(math.ceil(r * p["scl_factor"])), int(math.ceil(c * p["scl_factor"]))
+        Iin.append(pyramid.resize(Iin[-1], nr, nc))
+        Iin[-2] = pyramid.smooth(Iin[-2], G)
+        if nr <= ds_rows or nc <= ds_cols:
+            if smooth_last:
+                Iin[-1] = pyramid.smooth(Iin[-1], G)
+            break
+    level = level_cls(p, mode=p["mode"])
+    Iout = Iin[-1]
+    for scl in range(len(Iin) - 1, -1, -1):
+        Iout = dev.to_matlab(level.run(dev.to_device(Iin[scl]), dev.to_device(Iout)))
+        if scl > 0:
+            Iout = pyramid.resize(Iout, *Iin[scl - 1].shape[:2])
+    return Iout
+
+
+def TVdenoise8(I_in, mode=capi.MODE_EXACT_ORDER, **param):
+    """TVdenoise8.m; I_in in 0..1.  The coarsest scale is not smoothed: the driver writes that result to a misspelt variable (:72)."""
+    p = dict(dict(alpha=500.0, omega=1.75, outer_iter=20, inner_iter=4, solver=2, scl=0.75, scl_factor=0.75), mode=mode, **param)
+    return _tv(I_in, fl.TvLevel, p, pyramid.gaussian(5, 1.25), smooth_last=False)
+
+
+def TVdenoise4(I_in, mode=capi.MODE_EXACT_ORDER, **param):
+    p = dict(dict(alpha=5.0, omega=1.75, outer_iter=10, inner_iter=5, solver=2, scl=0.5, scl_factor=0.75), mode=mode, **param)
+    return _tv(I_in, fl.Tv4Level, p, pyramid.gaussian(7, 2.0), smooth_last=True)

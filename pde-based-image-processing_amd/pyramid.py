@@ -19,15 +19,24 @@ def gaussian5(sigma=1.25):
     return g / g.sum()
 
 
+def gaussian(size, sigma):
+    """fspecial('gaussian', [size size], sigma)"""
+    r = size // 2
+    ax = np.arange(-r, r + 1, dtype=np.float64)
+    g = np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / (2.0 * sigma * sigma))
+    return g / g.sum()
+
+
 def smooth(I, G=None):
-    """imfilter(I, G, 'replicate') for a 5x5 kernel, per channel."""
+    """imfilter(I, G, 'replicate') for an odd square kernel (default: the 5x5, sigma 1.25 one), per channel."""
     G = gaussian5() if G is None else G
+    r = G.shape[0] // 2
     I3 = I if I.ndim == 3 else I[:, :, None]
-    P = np.pad(I3.astype(np.float64), ((2, 2), (2, 2), (0, 0)), mode="edge")
+    P = np.pad(I3.astype(np.float64), ((r, r), (r, r), (0, 0)), mode="edge")
     out = np.zeros(I3.shape, dtype=np.float64)
     H, W = I3.shape[:2]
-    for a in range(5):
-        for b in range(5):
+    for a in range(G.shape[0]):
+        for b in range(G.shape[1]):
             out += G[a, b] * P[a:a + H, b:b + W, :]
     return out.astype(np.float32).reshape(I.shape)
 
@@ -68,7 +77,7 @@ def resize(I, out_rows, out_cols, method="bilinear"):
     return out.astype(np.float32).reshape((out_rows, out_cols) + I.shape[2:])
 
 
-def build(I0, I1, scl_factor=0.75, min_size=20):
+def build(I0, I1, scl_factor=0.75, min_size=20, G=None):
     """Image pyramids of the two frames (finest first), as the drivers build them (:100-127)."""
     P0, P1 = [I0.astype(np.float32)], [I1.astype(np.float32)]
     while True:
@@ -76,9 +85,9 @@ def build(I0, I1, scl_factor=0.75, min_size=20):
         nr, nc = int(math.ceil(rows * scl_factor)), int(math.ceil(cols * scl_factor))
         P0.append(resize(P0[-1], nr, nc))
         P1.append(resize(P1[-1], nr, nc))
-        P0[-2], P1[-2] = smooth(P0[-2]), smooth(P1[-2])    # the level just left is smoothed after it has been resized
+        P0[-2], P1[-2] = smooth(P0[-2], G), smooth(P1[-2], G)    # the level just left is smoothed after it has been resized
         if nr <= min_size or nc <= min_size:
-            P0[-1], P1[-1] = smooth(P0[-1]), smooth(P1[-1])
+            P0[-1], P1[-1] = smooth(P0[-1], G), smooth(P1[-1], G)
             return P0, P1
 
 
