@@ -327,6 +327,15 @@ int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, c
                                  int ncols, float *wW, float *wN, float *wS, float *wE);
 /* dU, dV may both be NULL: OPdiffWeights(U, V) of the early-linearisation drivers (FlowEminNDFASFMG_elin_2D_v10.m:392). */
 
+/* ---- the drivers' image pyramid.  IPT semantics have nothing to be checked against here: pyramid.py states our definition
+ * (tap lists at MATLAB's pixel-centre convention, antialiased when shrinking, replicate borders, double accumulation) and
+ * these entry points compute exactly that. ---- */
+/* imresize(in, [nrows_out ncols_out], 'bilinear' (cubic = 0) or 'bicubic' (1)) */
+int pdeip_pyr_resize_dev(void *stream, const float *in, int nrows, int ncols, int nframes, int nrows_out, int ncols_out, int cubic,
+                         float *out);
+/* imfilter(in, G, 'replicate'), G an odd size x size mask (row-major doubles in host memory, size <= 7) */
+int pdeip_pyr_smooth_dev(void *stream, const float *in, int nrows, int ncols, int nframes, const double *G, int size, float *out);
+
 /* ---- symmetric stereo (matlab/disparity/DispEminND_llin_sym_2D.m): the stages the other drivers do not have.  Planes marked
  * double are MATLAB doubles there (U, the warped disparities and what is derived from them). ---- */
 /* out = interp2(X, Y, U, X+Uq, Y) (:140-141): linear along x, NaN outside the grid */

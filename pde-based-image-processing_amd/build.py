@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpdeip.so")
 SOURCES = ["pdeip_capi.hip"]
-HEADERS = ["pdeip_alr.hpp", "pdeip_fas.hpp", "pdeip_sym.hpp", "pdeip_flow.hpp", "pdeip_tv.hpp", "pdeip_models.hpp", "pdeip_pointwise.hpp", "pdeip_sor_exact.hpp", "pdeip_sor_pde8.hpp",
+HEADERS = ["pdeip_alr.hpp", "pdeip_fas.hpp", "pdeip_sym.hpp", "pdeip_pyr.hpp", "pdeip_flow.hpp", "pdeip_tv.hpp", "pdeip_models.hpp", "pdeip_pointwise.hpp", "pdeip_sor_exact.hpp", "pdeip_sor_pde8.hpp",
            "pdeip_sor_rb.hpp", os.path.join("..", "..", "include", "pdeip.h")]
 # -ffp-contract=off is part of the parity contract (the reference is FMA-free C).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",

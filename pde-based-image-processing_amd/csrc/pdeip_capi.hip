@@ -18,6 +18,7 @@
 #include "pdeip_flow.hpp"
 #include "pdeip_fas.hpp"
 #include "pdeip_sym.hpp"
+#include "pdeip_pyr.hpp"
 #include "pdeip_tv.hpp"
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
@@ -1373,6 +1374,47 @@ extern "C" int pdeip_tv_assemble_dev(void *stream, const float *Iout, const floa
     hipLaunchKernelGGL(k_tv_lambda, dim3(1), dim3(64), 0, s, lambda, sorted, n, -1.0);
     hipLaunchKernelGGL(k_tv_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, TRACE, B, aW, aNW, aN, aNE, aE, aSE, aS, aSW, gx, gy,
                        nrm, lambda, Iout, Iin, alpha, nrows, ncols, nframes);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+// ---- image pyramid (pdeip_pyr.hpp) ---------------------------------------------------------------------
+static int pyr_axis(const char *who, int n_in, int n_out, int cubic, PyrAxis *A)
+{
+    A->scale = (double)n_out / (double)n_in;
+    A->stretch = A->scale >= 1.0 ? 1.0 : 1.0 / A->scale;
+    A->width = (cubic ? 2.0 : 1.0) * A->stretch;
+    A->T = (int)ceil(2.0 * A->width) + 2;
+    A->cubic = cubic;
+    if (A->T > PYR_TMAX) return set_err(PDEIP_ERR_UNSUPPORTED, "%s: shrinking %d -> %d needs %d taps (at most %d)", who, n_in, n_out, A->T, PYR_TMAX);
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_pyr_resize_dev(void *stream, const float *in, int nrows, int ncols, int nframes, int nrows_out, int ncols_out, int cubic,
+                                    float *out)
+{
+    const char *who = "pdeip_pyr_resize_dev";
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(check_dims(who, nrows_out, ncols_out, nframes));
+    if (in == out) return set_err(PDEIP_ERR_ARG, "%s: output must not alias the input", who);
+    PyrAxis R, C;
+    RC(pyr_axis(who, nrows, nrows_out, cubic != 0, &R));
+    RC(pyr_axis(who, ncols, ncols_out, cubic != 0, &C));
+    hipLaunchKernelGGL(k_pyr_resize, pixel_grid(nrows_out, ncols_out, nframes), dim3(256), 0, static_cast<hipStream_t>(stream), out, in, R, C, nrows,
+                       ncols, nrows_out, ncols_out);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_pyr_smooth_dev(void *stream, const float *in, int nrows, int ncols, int nframes, const double *G, int size, float *out)
+{
+    const char *who = "pdeip_pyr_smooth_dev";
+    RC(check_dims(who, nrows, ncols, nframes));
+    if (!G || size < 1 || size > 7 || size % 2 == 0 || in == out) return set_err(PDEIP_ERR_ARG, "%s: odd mask of at most 7x7, output distinct from input", who);
+    PyrMask M;
+    for (int k = 0; k < size * size; k++) M.g[k] = G[k];
+    M.size = size;
+    hipLaunchKernelGGL(k_pyr_smooth, pixel_grid(nrows, ncols, nframes), dim3(256), 0, static_cast<hipStream_t>(stream), out, in, M, nrows, ncols);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

@@ -408,3 +408,25 @@ def flow_apriori(Us, U, dU, gammaS, alpha, as_diff, u_double, du_double, CGd, DG
     nrows, ncols, _ = _dims(U)
     capi.call("pdeip_flow_apriori_dev", _stream(), Us.data_ptr(), U.data_ptr(), dU.data_ptr(), float(gammaS), float(alpha), float(as_diff),
               int(bool(u_double)), int(bool(du_double)), nrows, ncols, CGd.data_ptr(), DGd.data_ptr())
+
+
+# ---- the drivers' image pyramid on the device (csrc/pdeip_pyr.hpp; definitions in pyramid.py) -------------
+
+def pyr_resize(I, nrows_out, ncols_out, method="bilinear"):
+    """pyramid.resize on the device: [(C,) ncols, nrows] -> [(C,) ncols_out, nrows_out]"""
+    _chk(I)
+    nrows, ncols, F = _dims(I)
+    out = torch.empty(I.shape[:-2] + (ncols_out, nrows_out), dtype=I.dtype, device=I.device)
+    capi.call("pdeip_pyr_resize_dev", _stream(), I.data_ptr(), nrows, ncols, F, int(nrows_out), int(ncols_out), int(method == "bicubic"),
+              out.data_ptr())
+    return out
+
+
+def pyr_smooth(I, G):
+    """pyramid.smooth on the device; G: odd square numpy mask (float64)"""
+    _chk(I)
+    nrows, ncols, F = _dims(I)
+    g = np.ascontiguousarray(G, dtype=np.float64)
+    out = torch.empty_like(I)
+    capi.call("pdeip_pyr_smooth_dev", _stream(), I.data_ptr(), nrows, ncols, F, g.ctypes.data, int(g.shape[0]), out.data_ptr())
+    return out

@@ -1,6 +1,7 @@
 """The MATLAB drivers as Python functions: same names, arguments and default parameters, every pyramid level resident on the
-device (flow_level.py, fas.py), the pyramid around them on the host (pyramid.py: our definitions of imresize / imfilter /
-fspecial, there being no IPT to compare with).  Inputs and outputs are MATLAB-shaped numpy arrays ([nrows, ncols(, C)],
+device (flow_level.py, fas.py) and so is the pyramid around them (pyramid.py states our definitions of imresize / imfilter /
+fspecial, there being no IPT to compare with; csrc/pdeip_pyr.hpp computes exactly those): the frames go up once, the result
+comes down once.  Inputs and outputs are MATLAB-shaped numpy arrays ([nrows, ncols(, C)],
 images in 0..255 as the drivers expect); `mode` selects the ordering (capi.MODE_EXACT_ORDER reproduces the reference's order,
 capi.MODE_RED_BLACK the parallel one).
 
@@ -17,8 +18,18 @@ Not carried over: the spatial a-priori inputs at driver level (the levels take t
 import math
 
 import numpy as np
+import torch
 
 from . import capi, device as dev, fas, flow_level as fl, pyramid
+
+
+def _up(t, inv, nrows, ncols, method="bilinear"):
+    """imresize(t.*inv, [nrows ncols], method) on the device"""
+    return dev.pyr_resize(t * np.float32(inv), nrows, ncols, method)
+
+
+def _zeros_like_plane(t):
+    return torch.zeros(t.shape[-2:], dtype=torch.float32, device=t.device)
 
 
 def _frames(Iin, channels):
@@ -46,21 +57,19 @@ def _flow_llin(level_cls, Iin, channels, fstTerm, sndTerm, defaults, mode, param
     p = dict(defaults, **param)
     p["sndTerm"] = sndTerm.lower()
     I0, I1 = _frames(Iin, channels)
-    P0, P1 = pyramid.build(I0 / np.float32(255), I1 / np.float32(255), p["scl_factor"], 20)
+    P0, P1 = pyramid.build_dev(dev.to_device(I0 / np.float32(255)), dev.to_device(I1 / np.float32(255)), p["scl_factor"], 20)
     level = level_cls(p, mode=mode)
-    U = np.zeros(P0[-1].shape[:2], dtype=np.float32)
-    V = np.zeros_like(U)
+    U = _zeros_like_plane(P0[-1])
+    V = torch.zeros_like(U)
     for scl in range(len(P0) - 1, -1, -1):
-        d0, d1 = dev.to_device(P0[scl]), dev.to_device(P1[scl])
+        d0, d1 = P0[scl], P1[scl]
         (a0, a1), (b0, b1) = _terms(d0, d1, fstTerm, sndTerm)
-        args = (a0, a1, dev.to_device(U), dev.to_device(V)) + ((d0,) if level_cls is fl.FlowAdLevel else ()) + (b0, b1)
-        gU, gV = level.run(*args)
-        U, V = dev.to_matlab(gU), dev.to_matlab(gV)
+        args = (a0, a1, U, V) + ((d0,) if level_cls is fl.FlowAdLevel else ()) + (b0, b1)
+        U, V = level.run(*args)
         if scl > 0:
-            rows, cols = P0[scl - 1].shape[:2]
-            inv = np.float32(1.0 / p["scl_factor"])
-            U, V = pyramid.resize(U * inv, rows, cols), pyramid.resize(V * inv, rows, cols)
-    return U, V
+            cols, rows = P0[scl - 1].shape[-2:]
+            U, V = _up(U, 1.0 / p["scl_factor"], rows, cols), _up(V, 1.0 / p["scl_factor"], rows, cols)
+    return dev.to_matlab(U), dev.to_matlab(V)
 
 
 ND_DEFAULTS = dict(alpha=0.042, omega=1.9, gammaS=0.01, firstLoop=4, secondLoop=4, iter=4, b1=1.4843, b2=0.2915, scl_factor=0.75, solver=2)
@@ -82,19 +91,20 @@ HS_DEFAULTS = dict(alpha=0.2, omega=1.9, iter=20, b1=0.25, b2=0.75, scl_factor=0
 def FlowEminHS_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
     p = dict(HS_DEFAULTS, **param)
     I0, I1 = _frames(Iin, channels)
-    P0, P1 = pyramid.build(I0 / np.float32(255), I1 / np.float32(255), p["scl_factor"], 20)
+    P0, P1 = pyramid.build_dev(dev.to_device(I0 / np.float32(255)), dev.to_device(I1 / np.float32(255)), p["scl_factor"], 20)
     level = fl.FlowHsLevel(p, mode=mode)
-    U = np.zeros(P0[-1].shape[:2], dtype=np.float32)
-    V = np.zeros_like(U)
+    U = _zeros_like_plane(P0[-1])
+    V = torch.zeros_like(U)
     for scl in range(len(P0) - 1, -1, -1):
-        gU, gV = level.run(dev.to_device(P0[scl]), dev.to_device(P1[scl]), dev.to_device(U), dev.to_device(V))
-        U, V = dev.to_matlab(gU), dev.to_matlab(gV)
+        U, V = level.run(P0[scl], P1[scl], U, V)
         if scl > 0:   # imresize(medfilt2(U.*(1/scl_factor), [3 3], 'symmetric'), 'OutputSize', ...): the default, bicubic, method (:189-190)
-            rows, cols = P0[scl - 1].shape[:2]
+            cols, rows = P0[scl - 1].shape[-2:]
             inv = np.float32(1.0 / p["scl_factor"])
-            U = pyramid.resize(pyramid.median3(U * inv), rows, cols, method="bicubic")
-            V = pyramid.resize(pyramid.median3(V * inv), rows, cols, method="bicubic")
-    return U, V
+            mU, mV = torch.empty_like(U), torch.empty_like(V)
+            dev.median3(U * inv, None, mU)
+            dev.median3(V * inv, None, mV)
+            U, V = dev.pyr_resize(mU, rows, cols, "bicubic"), dev.pyr_resize(mV, rows, cols, "bicubic")
+    return dev.to_matlab(U), dev.to_matlab(V)
 
 
 def FlowEminNDFASFMG_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
@@ -109,17 +119,16 @@ DISP_DEFAULTS = dict(alpha=0.042, gammaS=0.005, omega=1.9, firstLoop=4, secondLo
 def DispEminND_llin_2D(Il, Ir, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, **param):
     p = dict(DISP_DEFAULTS, **param)
     p["sndTerm"] = sndTerm.lower()
-    P0, P1 = pyramid.build(_c3(Il) / np.float32(255), _c3(Ir) / np.float32(255), p["scl_factor"], 10)
+    P0, P1 = pyramid.build_dev(dev.to_device(_c3(Il) / np.float32(255)), dev.to_device(_c3(Ir) / np.float32(255)), p["scl_factor"], 10)
     level = fl.DispLlinLevel(p, mode=mode)
-    U = np.zeros(P0[-1].shape[:2], dtype=np.float32)
+    U = _zeros_like_plane(P0[-1])
     for scl in range(len(P0) - 1, -1, -1):
-        d0, d1 = dev.to_device(P0[scl]), dev.to_device(P1[scl])
-        (a0, a1), (b0, b1) = _terms(d0, d1, fstTerm, sndTerm)
-        U = dev.to_matlab(level.run(a0, a1, dev.to_device(U), b0, b1))
+        (a0, a1), (b0, b1) = _terms(P0[scl], P1[scl], fstTerm, sndTerm)
+        U = level.run(a0, a1, U, b0, b1)
         if scl > 0:
-            rows, cols = P0[scl - 1].shape[:2]
-            U = pyramid.resize(U * np.float32(1.0 / p["scl_factor"]), rows, cols)
-    return U
+            cols, rows = P0[scl - 1].shape[-2:]
+            U = _up(U, 1.0 / p["scl_factor"], rows, cols)
+    return dev.to_matlab(U)
 
 
 SYM_DEFAULTS = dict(alpha=0.035, beta=0.4, omega=1.9, firstLoop=3, secondLoop=4, iter=4, b1=0.25, b2=0.72, scl_factor=0.75, solver=2)
@@ -128,49 +137,41 @@ SYM_DEFAULTS = dict(alpha=0.035, beta=0.4, omega=1.9, firstLoop=3, secondLoop=4,
 def DispEminND_llin_sym_2D(Il, Ir, mode=capi.MODE_EXACT_ORDER, **param):
     """-> U [nrows, ncols, 2] (left-to-right and right-to-left disparity)."""
     p = dict(SYM_DEFAULTS, **param)
-    P0, P1 = [_c3(Il)], [_c3(Ir)]                                 # no /255 in this driver (:81-82)
-    G = pyramid.gaussian(3, 1.0)
-    while True:
-        rows, cols = P0[-1].shape[:2]
-        nr, nc = int(math.ceil(rows * p["scl_factor"])), int(math.ceil(cols * p["scl_factor"]))
-        P0.append(pyramid.resize(P0[-1], nr, nc)); P1.append(pyramid.resize(P1[-1], nr, nc))
-        P0[-2], P1[-2] = pyramid.smooth(P0[-2], G), pyramid.smooth(P1[-2], G)
-        if nr <= 10 or nc <= 10:                                  # the last scale stays unsmoothed here (:94-98)
-            break
+    # no /255 in this driver (:81-82); its coarsest scale stays unsmoothed (:94-98)
+    P0, P1 = pyramid.build_dev(dev.to_device(_c3(Il)), dev.to_device(_c3(Ir)), p["scl_factor"], 10, pyramid.gaussian(3, 1.0), smooth_last=False)
     level = fl.DispSymLevel(p, mode=mode)
-    U0 = np.zeros(P0[-1].shape[:2], dtype=np.float32)
-    U1 = np.zeros_like(U0)
+    U0 = _zeros_like_plane(P0[-1])
+    U1 = torch.zeros_like(U0)
     for scl in range(len(P0) - 1, -1, -1):
         sr = 2.0 * (1.0 / p["scl_factor"]) ** (-scl)              # srDiff = 2*(1/scl_factor)^-(scl-1), scl 1-based there
-        g0, g1 = level.run(dev.to_device(P0[scl]), dev.to_device(P1[scl]), dev.to_device(U0), dev.to_device(U1), sr)
-        U0, U1 = dev.to_matlab(g0), dev.to_matlab(g1)
+        U0, U1 = level.run(P0[scl], P1[scl], U0, U1, sr)
         if scl > 0:
-            rows, cols = P0[scl - 1].shape[:2]
-            inv = np.float32(1.0 / p["scl_factor"])
-            U0, U1 = pyramid.resize(U0 * inv, rows, cols), pyramid.resize(U1 * inv, rows, cols)
-    return np.stack([U0, U1], axis=2)
+            cols, rows = P0[scl - 1].shape[-2:]
+            U0, U1 = _up(U0, 1.0 / p["scl_factor"], rows, cols), _up(U1, 1.0 / p["scl_factor"], rows, cols)
+    return np.stack([dev.to_matlab(U0), dev.to_matlab(U1)], axis=2)
 
 
 def _tv(I_in, level_cls, p, G, smooth_last):
-    Iin = [np.asfortranarray(np.asarray(I_in, dtype=np.float32))]
-    rows, cols = Iin[0].shape[:2]
+    Iin = [dev.to_device(np.asarray(I_in, dtype=np.float32))]
+    cols, rows = Iin[0].shape[-2:]
     ds_rows, ds_cols = math.ceil(rows * p["scl"]), math.ceil(cols * p["scl"])
     while True:
-        r, c = Iin[-1].shape[:2]
+        c, r = Iin[-1].shape[-2:]
         nr, nc = int(math.ceil(r * p["scl_factor"])), int(math.ceil(c * p["scl_factor"]))
-        Iin.append(pyramid.resize(Iin[-1], nr, nc))
-        Iin[-2] = pyramid.smooth(Iin[-2], G)
+        Iin.append(dev.pyr_resize(Iin[-1], nr, nc))
+        Iin[-2] = dev.pyr_smooth(Iin[-2], G)
         if nr <= ds_rows or nc <= ds_cols:
             if smooth_last:
-                Iin[-1] = pyramid.smooth(Iin[-1], G)
+                Iin[-1] = dev.pyr_smooth(Iin[-1], G)
             break
     level = level_cls(p, mode=p["mode"])
     Iout = Iin[-1]
     for scl in range(len(Iin) - 1, -1, -1):
-        Iout = dev.to_matlab(level.run(dev.to_device(Iin[scl]), dev.to_device(Iout)))
+        Iout = level.run(Iin[scl], Iout)
         if scl > 0:
-            Iout = pyramid.resize(Iout, *Iin[scl - 1].shape[:2])
-    return Iout
+            c, r = Iin[scl - 1].shape[-2:]
+            Iout = dev.pyr_resize(Iout, r, c)
+    return dev.to_matlab(Iout)
 
 
 def TVdenoise8(I_in, mode=capi.MODE_EXACT_ORDER, **param):

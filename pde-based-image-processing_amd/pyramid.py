@@ -49,31 +49,54 @@ def _cubic(t):
     return -0.5 * t ** 3 + 2.5 * t ** 2 - 4 * t + 2 if t <= 2 else 0.0
 
 
-def _resize_matrix(n_in, n_out, method="bilinear"):
-    """[n_out, n_in] matrix (rows summing to one) of a triangle- or cubic-kernel resize, antialiased when shrinking."""
+def _resize_taps(n_in, n_out, method="bilinear"):
+    """For every output index the source indices (clamped: replicate at the ends) and normalised weights of a triangle- or
+    cubic-kernel resize at MATLAB's pixel-centre convention, the kernel stretched by 1/scale when shrinking (IPT's
+    antialiasing).  Arrays [n_out, T]; unused taps have weight 0.  This tap list, summed left to right, IS our definition of
+    imresize along one axis (the device kernel k_pyr_resize walks the same list)."""
     scale = n_out / n_in
     stretch = 1.0 if scale >= 1 else 1.0 / scale
     support = 1.0 if method == "bilinear" else 2.0
-    kern = (lambda t: max(0.0, 1.0 - abs(t))) if method == "bilinear" else _cubic
     width = support * stretch
+    T = int(math.ceil(2 * width)) + 2
+    x = (np.arange(n_out, dtype=np.float64) + 0.5) / scale - 0.5        # centre of each output pixel in input coordinates
+    first = np.floor(x - width).astype(np.int64)
+    idx = first[:, None] + np.arange(T, dtype=np.int64)[None, :]
+    t = (idx.astype(np.float64) - x[:, None]) / stretch
+    a = np.abs(t)
+    if method == "bilinear":
+        w = np.maximum(0.0, 1.0 - a)
+    else:
+        a2 = a * a
+        a3 = a2 * a
+        w = np.where(a <= 1.0, (1.5 * a3 - 2.5 * a2) + 1.0, np.where(a <= 2.0, ((-0.5 * a3 + 2.5 * a2) - 4.0 * a) + 2.0, 0.0))
+    total = w[:, 0].copy()
+    for k in range(1, T):
+        total = total + w[:, k]
+    return np.clip(idx, 0, n_in - 1), w / total[:, None]
+
+
+def _resize_matrix(n_in, n_out, method="bilinear"):
+    """The same as a dense [n_out, n_in] matrix (for tests)."""
+    idx, w = _resize_taps(n_in, n_out, method)
     M = np.zeros((n_out, n_in), dtype=np.float64)
-    for o in range(n_out):
-        x = (o + 0.5) / scale - 0.5                       # centre of output pixel o in input coordinates
-        lo, hi = int(math.floor(x - width)), int(math.ceil(x + width))
-        for i in range(lo, hi + 1):
-            w = kern((i - x) / stretch)
-            if w != 0:
-                M[o, min(max(i, 0), n_in - 1)] += w       # replicate at the ends
-        M[o] /= M[o].sum()
+    for k in range(idx.shape[1]):
+        np.add.at(M, (np.arange(n_out), idx[:, k]), w[:, k])
     return M
 
 
 def resize(I, out_rows, out_cols, method="bilinear"):
-    """imresize(I, [out_rows out_cols], method); method 'bilinear' or 'bicubic' (imresize's default)"""
-    I3 = I if I.ndim == 3 else I[:, :, None]
-    R, C = _resize_matrix(I3.shape[0], out_rows, method), _resize_matrix(I3.shape[1], out_cols, method)
-    out = np.einsum("or,rck->ock", R, I3.astype(np.float64))
-    out = np.einsum("pc,ock->opk", C, out)
+    """imresize(I, [out_rows out_cols], method); method 'bilinear' or 'bicubic' (imresize's default).  Rows first, then
+    columns, taps summed left to right in double, rounded to single once."""
+    I3 = (I if I.ndim == 3 else I[:, :, None]).astype(np.float64)
+    ri, rw = _resize_taps(I3.shape[0], out_rows, method)
+    ci, cw = _resize_taps(I3.shape[1], out_cols, method)
+    T1 = rw[:, 0][:, None, None] * I3[ri[:, 0]]
+    for k in range(1, ri.shape[1]):
+        T1 = T1 + rw[:, k][:, None, None] * I3[ri[:, k]]
+    out = cw[:, 0][None, :, None] * T1[:, ci[:, 0]]
+    for k in range(1, ci.shape[1]):
+        out = out + cw[:, k][None, :, None] * T1[:, ci[:, k]]
     return out.astype(np.float32).reshape((out_rows, out_cols) + I.shape[2:])
 
 
@@ -88,6 +111,24 @@ def build(I0, I1, scl_factor=0.75, min_size=20, G=None):
         P0[-2], P1[-2] = smooth(P0[-2], G), smooth(P1[-2], G)    # the level just left is smoothed after it has been resized
         if nr <= min_size or nc <= min_size:
             P0[-1], P1[-1] = smooth(P0[-1], G), smooth(P1[-1], G)
+            return P0, P1
+
+
+def build_dev(d0, d1, scl_factor=0.75, min_size=20, G=None, smooth_last=True):
+    """build() on the device: d0, d1 torch planes [C, ncols, nrows]; the same definitions, bit for bit (device.pyr_resize /
+    pyr_smooth).  smooth_last=False: the symmetric stereo driver leaves its coarsest scale unsmoothed."""
+    from . import device as dev
+    G = gaussian5() if G is None else G
+    P0, P1 = [d0], [d1]
+    while True:
+        ncols, nrows = P0[-1].shape[-2:]
+        nr, nc = int(math.ceil(nrows * scl_factor)), int(math.ceil(ncols * scl_factor))
+        P0.append(dev.pyr_resize(P0[-1], nr, nc))
+        P1.append(dev.pyr_resize(P1[-1], nr, nc))
+        P0[-2], P1[-2] = dev.pyr_smooth(P0[-2], G), dev.pyr_smooth(P1[-2], G)
+        if nr <= min_size or nc <= min_size:
+            if smooth_last:
+                P0[-1], P1[-1] = dev.pyr_smooth(P0[-1], G), dev.pyr_smooth(P1[-1], G)
             return P0, P1
 
 
