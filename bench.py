@@ -316,6 +316,20 @@ def main():
                     dl[tag + name] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
             out["disparity_level"] = dl
             del dL, dR, gL, gR, dZ5
+            # ---- whole drivers (pyramid + every level resident; host numpy frames in, flow out), as runme.m calls them --------
+            drivers = importlib.import_module("pde-based-image-processing_amd.drivers")
+            Iseq = np.concatenate([(I0 + 1.3) * 98.0, (I1 + 1.3) * 98.0], axis=2).astype(np.float32)   # 0..255, 1080x1920x(3+3)
+            dr = {"workload": "FlowEminND_llin_2D_v10(Iseq 1080x1920x3 pair, 'grad', 'gradmag'), 16 scales x firstLoop 4 x secondLoop 4 x iter 4; "
+                              "incl. H2D of the frames and D2H of the flow", "unit": "ms"}
+            for name, kw in (("red_black_sor", dict(mode=capi.MODE_RED_BLACK, solver=1, omega=1.5)), ("zebra_alr", dict(mode=capi.MODE_RED_BLACK, omega=1.5))):
+                drivers.FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", **kw)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                drivers.FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", **kw)
+                torch.cuda.synchronize()
+                dr[name] = round((time.perf_counter() - t0) * 1e3, 1)
+            out["driver_nd_1080p"] = dr
+            del Iseq
             # ---- the lagged-diffusivity loop of the TV denoiser resident in HBM (BASELINE config C3: 2160x3840 gray) ----
             tvp = dict(alpha=500.0, omega=1.75, outer_iter=20, inner_iter=4, solver=1)
             gI = torch.empty((NCOLS, NROWS), device=device, dtype=torch.float32).uniform_(0, 1)
