@@ -209,7 +209,7 @@ def main():
         out["exact_order"] = {
             "value": round(e_steps * ITER / edt, 2), "unit": "iterations/s", "ms_per_step": round(edt / e_steps * 1e3, 4),
             "launches_per_step": enl // e_steps,
-            "roofline": {"bound": "hbm", "kernel": "k_sor_exact<ModelElin4>", "achieved": round(e_bytes / e_launch_s / 1e9, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_sor_exact_persist<ModelElin4>", "achieved": round(e_bytes / e_launch_s / 1e9, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e_bytes / e_launch_s / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": None, "launch_us": round(e_launch_s * 1e6, 2)},
         }

@@ -219,11 +219,11 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         const int B = (ncols - 2 + 63) / 64;
         const int last_m = (A - 1) + 2 * (B - 1) + 3 * (iter - 1);
         for (int f = 0; f < NIT; f++) P.it_in[f] = P.it_out[f];
-        // Launch-per-front or persistent?  Measured at 4K: equal at iter=4 (each strip has to trail its west
-        // neighbour by 64 rows plus the hand-off latency either way), persistent 1.4x faster at iter=20 (no
-        // per-front cold start, sweeps overlap more tightly).  PDEIP_EXACT_PERSIST = 0 never, 1 always, unset: auto.
-        const int persist_pref = env_int("PDEIP_EXACT_PERSIST", -1);
-        const bool persist = (persist_pref == 1) || (persist_pref < 0 && iter >= 8);
+        // Launch-per-front or persistent?  The persistent form wins at every iter and frame size (tools/time_exact_persist.py:
+        // 4K 2.70 vs 2.87 ms at iter=4 -- each strip has to trail its west neighbour by 64 rows plus the hand-off latency either
+        // way --, 1.4x at iter=20, 1.3x at 1080p, 2.4x at 34x60: no per-front launch, sweeps overlap more tightly).
+        // PDEIP_EXACT_PERSIST = 0 falls back to one launch per front.
+        const bool persist = env_int("PDEIP_EXACT_PERSIST", 1) != 0;
         if (persist && B <= 0xffff && iter <= 0x7fff && n * sizeof(float) < 0xffffffffull) {
             // ---- persistent form: one launch, progress counters instead of one launch per front ----
             const int NC = (nrows - 2 + 63 + EX_CH - 1) / EX_CH;

@@ -1,6 +1,7 @@
 """GPU: the persistent exact-order kernel (one launch, progress counters, write-through hand-off) against the
 oracle, bit for bit, forced on with PDEIP_EXACT_PERSIST=1 -- small/odd/large frames, NaN-laced data, every
-5-point model, multi-frame -- and its abort word stays clear.  Also the automatic policy (iter >= 8)."""
+5-point model, multi-frame -- and its abort word stays clear.  It is the default form; the launch-per-front form
+(PDEIP_EXACT_PERSIST=0) is kept and checked against the same answers."""
 import os
 
 import numpy as np
@@ -54,7 +55,7 @@ def test_persistent_other_models(pdeip, oracle, persist_on, shape):
 
 
 def test_auto_policy_uses_persistent_for_long_calls(pdeip, oracle):
-    """Without the override, iter >= 8 takes the persistent kernel (few launches), iter < 8 one launch per front."""
+    """Without the override every call takes the persistent kernel (few launches)."""
     os.environ.pop("PDEIP_EXACT_PERSIST", None)
     pdeip.mex_api.set_mode(0)
     p = pb.elin4(831, 388, 584)
@@ -64,5 +65,39 @@ def test_auto_policy_uses_persistent_for_long_calls(pdeip, oracle):
     _ok(pdeip)
     for g, w in zip(got, oracle.Oflow_sor_elin4_2d(*p.values(), 20, 1.9)):
         assert pb.bit_equal(g, w)
-    pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(4), np.float32(1.9), np.float32(1))
-    assert lib.pdeip_last_launch_count() > 10
+    got = pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(4), np.float32(1.9), np.float32(1))
+    assert lib.pdeip_last_launch_count() <= 3
+    for g, w in zip(got, oracle.Oflow_sor_elin4_2d(*p.values(), 4, 1.9)):
+        assert pb.bit_equal(g, w)
+
+
+@pytest.fixture()
+def persist_off():
+    old = os.environ.get("PDEIP_EXACT_PERSIST")
+    os.environ["PDEIP_EXACT_PERSIST"] = "0"
+    yield
+    if old is None:
+        os.environ.pop("PDEIP_EXACT_PERSIST", None)
+    else:
+        os.environ["PDEIP_EXACT_PERSIST"] = old
+
+
+@pytest.mark.parametrize("shape", [(32, 48), (97, 131), (5, 300), (260, 7), (388, 584)])
+def test_launch_per_front_form(pdeip, oracle, persist_off, shape):
+    """The older schedule, one launch per wavefront: same bits, many launches."""
+    api = pdeip.mex_api
+    api.set_mode(0)
+    for it in (1, 4, 9):
+        p = pb.elin4(841, *shape, nan_frac=0.01)
+        got = api.Oflow_sor_elin4_2d(*p.values(), np.float32(it), np.float32(1.9), np.float32(1))
+        if min(shape) > 64:
+            assert pdeip.capi.load().pdeip_last_launch_count() > 3
+        for g, w in zip(got, oracle.Oflow_sor_elin4_2d(*p.values(), it, 1.9)):
+            assert pb.bit_equal(g, w), "elin4 %s it=%d: %s" % (shape, it, pb.describe_mismatch(g, w))
+    q = pb.llin4(842, *shape, nan_frac=0.02)
+    for g, w in zip(api.Oflow_sor_llin4_2d(*q.values(), np.float32(5), np.float32(1.9), np.float32(1)), oracle.Oflow_sor_llin4_2d(*q.values(), 5, 1.9)):
+        assert pb.bit_equal(g, w)
+    d = pb.disp4(843, *shape, nan_frac=0.02)
+    assert pb.bit_equal(api.Disp_sor_llin4_2d(*d.values(), np.float32(6), np.float32(1.9), np.float32(1)), oracle.Disp_sor_llin4_2d(*d.values(), 6, 1.9))
+    e = pb.pde4(844, *shape, nframes=2, nan_frac=0.02)
+    assert pb.bit_equal(api.PDEsolver4(*e.values(), np.float32(5), np.float32(1.75), np.float32(1)), oracle.PDEsolver4(*e.values(), 5, 1.75))
