@@ -178,7 +178,7 @@ int pick_rb2_tj(int nrows, int ncols, int nframes, int ntiles_r)
     }
     int best = 12;
     long best_cost = -1;
-    for (int tj = 4; tj <= 64; tj++) {
+    for (int tj = 2; tj <= 64; tj++) {
         const long units = (long)ntiles_r * ((ncols + tj - 1) / tj) * nframes;
         const long cost = ((units + slots - 1) / slots) * (tj + 6);
         if (best_cost < 0 || cost <= best_cost) { // ties: the wider strip re-reads fewer halo columns
