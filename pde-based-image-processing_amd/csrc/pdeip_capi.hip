@@ -638,7 +638,7 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
         if (forced > 0) TJ2 = forced < 2 ? 2 : forced;
         else {
             long best_cost = -1;
-            for (int tj = 4; tj <= 64; tj++) {
+            for (int tj = 2; tj <= 64; tj++) {
                 const long units = (long)ntiles2 * ((ncols + tj - 1) / tj) * nframes;
                 const long cost = ((units + slots - 1) / slots) * (tj + 6);
                 if (best_cost < 0 || cost <= best_cost) {
