@@ -60,7 +60,7 @@ typedef tri_t (*coef_fn)(const void *ctx, int i, int j, int vertical);
  * (opticalflowSolvers.c:1890-1958 for a column, :2219-2296 for a row).  x points at element 0 of the
  * line, consecutive elements are `stride` floats apart. */
 static void thomas_line(float *x, ptrdiff_t stride, int n, coef_fn coef, const void *ctx, int fixed, int vertical,
-                        float omega, float *cp, float *dp)
+                        float omega, float *cp, float *dp, int truediv)
 {
     int k;
     tri_t t;
@@ -72,9 +72,17 @@ static void thomas_line(float *x, ptrdiff_t stride, int n, coef_fn coef, const v
     dp[0] = t.d / t.b;
     for (k = 1; k <= n - 2; k++) {
         t = vertical ? coef(ctx, k, fixed, 1) : coef(ctx, fixed, k, 0);
-        div = 1 / (t.b - cp[k - 1] * t.a);
-        cp[k] = t.c * div;
-        dp[k] = (t.d - dp[k - 1] * t.a) * div;
+        if (truediv) {
+            /* southRow_llin4 (opticalflowSolvers.c:3059-3060), southRow_llin8 (:3871-3872), southRow4
+             * (disparitySolvers.c:1986-1987): the only line functions whose middle elements divide
+             * instead of multiplying by a reciprocal (audit table: DESIGN.md section 5.5). */
+            cp[k] = t.c / (t.b - cp[k - 1] * t.a);
+            dp[k] = (t.d - dp[k - 1] * t.a) / (t.b - cp[k - 1] * t.a);
+        } else {
+            div = 1 / (t.b - cp[k - 1] * t.a);
+            cp[k] = t.c * div;
+            dp[k] = (t.d - dp[k - 1] * t.a) * div;
+        }
     }
     t = vertical ? coef(ctx, k, fixed, 1) : coef(ctx, fixed, k, 0);
     dp[k] = (t.d - dp[k - 1] * t.a) / (t.b - cp[k - 1] * t.a);
@@ -92,8 +100,9 @@ static void thomas_line(float *x, ptrdiff_t stride, int n, coef_fn coef, const v
 }
 
 /* All lines [lo, hi] of one direction over the plane x (nrows x ncols), in the given order. */
+/* south_div: the model's south-row function (the row pass on line nrows-1) uses true division. */
 static void line_pass(float *x, int nrows, int ncols, int vertical, int lo, int hi, int order, coef_fn coef,
-                      const void *ctx, float omega, float *cp, float *dp)
+                      const void *ctx, float omega, float *cp, float *dp, int south_div)
 {
     int pass, l;
     int colour = order & 1;
@@ -102,9 +111,9 @@ static void line_pass(float *x, int nrows, int ncols, int vertical, int lo, int 
             if (colour && (l & 1) != pass)
                 continue;
             if (vertical)
-                thomas_line(x + (size_t)l * nrows, 1, nrows, coef, ctx, l, 1, omega, cp, dp);
+                thomas_line(x + (size_t)l * nrows, 1, nrows, coef, ctx, l, 1, omega, cp, dp, 0);
             else
-                thomas_line(x + l, nrows, ncols, coef, ctx, l, 0, omega, cp, dp);
+                thomas_line(x + l, nrows, ncols, coef, ctx, l, 0, omega, cp, dp, south_div && l == nrows - 1);
         }
     }
 }
@@ -175,10 +184,10 @@ void orc_oflow_alr_elin4(float *U, float *V, const float *M, const float *Cu, co
     if (nrows < 2 || ncols < 2 || !alloc_scratch(nrows, ncols, &cp, &dp))
         return;
     for (it = 0; it < iter; it++) { /* :231-258: columns U then V, rows V then U */
-        line_pass(U, nrows, ncols, 1, 0, ncols - 1, order, elin4_coef, &qu, omega, cp, dp);
-        line_pass(V, nrows, ncols, 1, 0, ncols - 1, order, elin4_coef, &qv, omega, cp, dp);
-        line_pass(V, nrows, ncols, 0, 0, nrows - 1, order, elin4_coef, &qv, omega, cp, dp);
-        line_pass(U, nrows, ncols, 0, 0, nrows - 1, order, elin4_coef, &qu, omega, cp, dp);
+        line_pass(U, nrows, ncols, 1, 0, ncols - 1, order, elin4_coef, &qu, omega, cp, dp, 0);
+        line_pass(V, nrows, ncols, 1, 0, ncols - 1, order, elin4_coef, &qv, omega, cp, dp, 0);
+        line_pass(V, nrows, ncols, 0, 0, nrows - 1, order, elin4_coef, &qv, omega, cp, dp, 0);
+        line_pass(U, nrows, ncols, 0, 0, nrows - 1, order, elin4_coef, &qu, omega, cp, dp, 0);
     }
     free(cp);
     free(dp);
@@ -246,10 +255,10 @@ void orc_oflow_alr_llin4(const float *U, const float *V, float *dU, float *dV, c
     if (nrows < 2 || ncols < 2 || !alloc_scratch(nrows, ncols, &cp, &dp))
         return;
     for (it = 0; it < iter; it++) { /* :728-755 */
-        line_pass(dU, nrows, ncols, 1, 0, ncols - 1, order, llin4_coef, &qu, omega, cp, dp);
-        line_pass(dV, nrows, ncols, 1, 0, ncols - 1, order, llin4_coef, &qv, omega, cp, dp);
-        line_pass(dV, nrows, ncols, 0, 0, nrows - 1, order, llin4_coef, &qv, omega, cp, dp);
-        line_pass(dU, nrows, ncols, 0, 0, nrows - 1, order, llin4_coef, &qu, omega, cp, dp);
+        line_pass(dU, nrows, ncols, 1, 0, ncols - 1, order, llin4_coef, &qu, omega, cp, dp, 1);
+        line_pass(dV, nrows, ncols, 1, 0, ncols - 1, order, llin4_coef, &qv, omega, cp, dp, 1);
+        line_pass(dV, nrows, ncols, 0, 0, nrows - 1, order, llin4_coef, &qv, omega, cp, dp, 1);
+        line_pass(dU, nrows, ncols, 0, 0, nrows - 1, order, llin4_coef, &qu, omega, cp, dp, 1);
     }
     free(cp);
     free(dp);
@@ -265,8 +274,8 @@ void orc_disp_alr_llin4(const float *U, float *dU, const float *Cu, const float 
     if (nrows < 2 || ncols < 2 || !alloc_scratch(nrows, ncols, &cp, &dp))
         return;
     for (it = 0; it < iter; it++) { /* disparitySolvers.c:186-204: columns, then rows */
-        line_pass(dU, nrows, ncols, 1, 0, ncols - 1, order, llin4_coef, &q, omega, cp, dp);
-        line_pass(dU, nrows, ncols, 0, 0, nrows - 1, order, llin4_coef, &q, omega, cp, dp);
+        line_pass(dU, nrows, ncols, 1, 0, ncols - 1, order, llin4_coef, &q, omega, cp, dp, 1);
+        line_pass(dU, nrows, ncols, 0, 0, nrows - 1, order, llin4_coef, &q, omega, cp, dp, 1);
     }
     free(cp);
     free(dp);
@@ -376,10 +385,10 @@ void orc_oflow_alr_llin8(const float *U, const float *V, float *dU, float *dV, c
     if (nrows < 2 || ncols < 2 || !alloc_scratch(nrows, ncols, &cp, &dp))
         return;
     for (it = 0; it < iter; it++) { /* :1718-1746 */
-        line_pass(dU, nrows, ncols, 1, 0, ncols - 1, order, llin8_coef, &qu, omega, cp, dp);
-        line_pass(dV, nrows, ncols, 1, 0, ncols - 1, order, llin8_coef, &qv, omega, cp, dp);
-        line_pass(dV, nrows, ncols, 0, 0, nrows - 1, order, llin8_coef, &qv, omega, cp, dp);
-        line_pass(dU, nrows, ncols, 0, 0, nrows - 1, order, llin8_coef, &qu, omega, cp, dp);
+        line_pass(dU, nrows, ncols, 1, 0, ncols - 1, order, llin8_coef, &qu, omega, cp, dp, 1);
+        line_pass(dV, nrows, ncols, 1, 0, ncols - 1, order, llin8_coef, &qv, omega, cp, dp, 1);
+        line_pass(dV, nrows, ncols, 0, 0, nrows - 1, order, llin8_coef, &qv, omega, cp, dp, 1);
+        line_pass(dU, nrows, ncols, 0, 0, nrows - 1, order, llin8_coef, &qu, omega, cp, dp, 1);
     }
     free(cp);
     free(dp);
@@ -439,12 +448,12 @@ void orc_pde_alr4(float *X, const float *TRACE, const float *B, const float *wW,
         for (k = 0; k < nframes; k++) {
             size_t o = (size_t)k * nrows * ncols;
             pde_ctx q = {X + o, TRACE + o, B + o, wW + o, NULL, wN + o, NULL, wE + o, NULL, wS + o, NULL, nrows, ncols};
-            line_pass(X + o, nrows, ncols, 1, 0, ncols - 1, order, pde4_coef, &q, omega, cp, dp);
+            line_pass(X + o, nrows, ncols, 1, 0, ncols - 1, order, pde4_coef, &q, omega, cp, dp, 0);
         }
         for (k = 0; k < nframes; k++) {
             size_t o = (size_t)k * nrows * ncols;
             pde_ctx q = {X + o, TRACE + o, B + o, wW + o, NULL, wN + o, NULL, wE + o, NULL, wS + o, NULL, nrows, ncols};
-            line_pass(X + o, nrows, ncols, 0, 0, nrows - 1, order, pde4_coef, &q, omega, cp, dp);
+            line_pass(X + o, nrows, ncols, 0, 0, nrows - 1, order, pde4_coef, &q, omega, cp, dp, 0);
         }
     }
     free(cp);
@@ -497,12 +506,12 @@ void orc_pde_alr8(float *X, const float *TRACE, const float *B, const float *wW,
     for (k = 0; k < nframes; k++) { /* interior columns :1153, all their rows */
         size_t o = (size_t)k * nrows * ncols;
         pde_ctx q = {X + o, TRACE + o, B + o, wW + o, wNW + o, wN + o, wNE + o, wE + o, wSE + o, wS + o, wSW + o, nrows, ncols};
-        line_pass(X + o, nrows, ncols, 1, 1, ncols - 2, order, pde8_coef, &q, omega, cp, dp);
+        line_pass(X + o, nrows, ncols, 1, 1, ncols - 2, order, pde8_coef, &q, omega, cp, dp, 0);
     }
     for (k = 0; k < nframes; k++) { /* interior rows :1290, all their columns */
         size_t o = (size_t)k * nrows * ncols;
         pde_ctx q = {X + o, TRACE + o, B + o, wW + o, wNW + o, wN + o, wNE + o, wE + o, wSE + o, wS + o, wSW + o, nrows, ncols};
-        line_pass(X + o, nrows, ncols, 0, 1, nrows - 2, order, pde8_coef, &q, omega, cp, dp);
+        line_pass(X + o, nrows, ncols, 0, 1, nrows - 2, order, pde8_coef, &q, omega, cp, dp, 0);
     }
     free(cp);
     free(dp);

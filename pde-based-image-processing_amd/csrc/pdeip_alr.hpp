@@ -20,6 +20,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pdeip_models.hpp"
 
 namespace pdeip {
@@ -124,6 +126,7 @@ struct AlrElin4 {
         __device__ void shift(size_t) {}
     };
     static constexpr bool INTERIOR_LINES = false;
+    static constexpr bool SOUTH_TRUEDIV = false; // southRow_elin4 multiplies by a reciprocal like every other line (:2364-2366)
     struct In { // x1, x2: the two off-line neighbours of X in the order they enter d: W,E on a column; S,N on a row
         float wN, wS, wE, wW, x1, x2, C, D, M, O;
     };
@@ -193,6 +196,10 @@ template <bool COUPLED> struct AlrLlin4T {
         __device__ void shift(size_t) {}
     };
     static constexpr bool INTERIOR_LINES = false;
+    // southRow_llin4 (opticalflowSolvers.c:3059-3060) and southRow4 (disparitySolvers.c:1986-1987) DIVIDE in the forward
+    // elimination of their middle elements: cp = c / den, dp = (d - dp' a) / den.  Every other line function multiplies by
+    // div = 1 / den (audit: DESIGN.md section 5.5).
+    static constexpr bool SOUTH_TRUEDIV = true;
     struct In { // d1, d2: the increments of the two off-line neighbours: W,E on a column; S,N on a row
         float wN, wS, wE, wW, Uc, Uw, Ue, Us, Un, d1, d2, C, D, M, O;
     };
@@ -318,6 +325,7 @@ struct AlrLlin8 {
         __device__ void shift(size_t) {}
     };
     static constexpr bool INTERIOR_LINES = false;
+    static constexpr bool SOUTH_TRUEDIV = true; // southRow_llin8 (opticalflowSolvers.c:3871-3872) divides, like southRow_llin4
     __device__ __forceinline__ static int third(int k, int n) { return k == 0 ? 0 : (k == n - 1 ? 2 : 1); }
     // everything one pixel needs, by direction (DN..DSE): weight, base-flow difference U_nb - U_c, increment of the neighbour
     struct In {
@@ -475,6 +483,7 @@ struct AlrPde4 {
         }
     };
     static constexpr bool INTERIOR_LINES = false;
+    static constexpr bool SOUTH_TRUEDIV = false; // TDMA_srow_ALR_4 multiplies (pdeSolvers.c:1083-1085)
     struct In { // x1, x2: the two off-line neighbours in the order they enter d: W,E on a column; S,N on a row
         float wN, wS, wE, wW, x1, x2, T, B;
     };
@@ -543,6 +552,7 @@ struct AlrPde8 {
         }
     };
     static constexpr bool INTERIOR_LINES = true; // interior columns, then interior rows (pdeSolvers.c:1153, :1290)
+    static constexpr bool SOUTH_TRUEDIV = false; // TDMArow_ALR_8 multiplies (pdeSolvers.c:1347-1349)
     // X on the two neighbouring lines: same element (P, N) and the elements before / after it (Pb, Pa, Nb, Na).
     // On a column the previous line is the west column (P = W, Pb = NW, Pa = SW, N = E, Nb = NE, Na = SE); on a row
     // it is the north row (P = N, Pb = NW, Pa = NE, N = S, Nb = SW, Na = SE).
@@ -637,6 +647,7 @@ __global__ void __launch_bounds__(64) k_alr_zebra(typename Mdl::Ctx q, float *x,
     constexpr size_t stride = 1;
     const size_t base = (size_t)l * n;
     const float om1 = 1.0f - omega;
+    const bool tdiv = Mdl::SOUTH_TRUEDIV && !VERT && l == nrows - 1; // the south row of these models divides (see the model)
 
     // The recurrences are serial, the loads are not: fetch the coefficients of ZCH steps at once so that
     // one memory latency is paid per chunk instead of per step.
@@ -657,9 +668,15 @@ __global__ void __launch_bounds__(64) k_alr_zebra(typename Mdl::Ctx q, float *x,
         for (int u = 0; u < ZCH; ++u) {
             const int k = k0 + u;
             if (k <= n - 2) {
-                const float div = 1.0f / (c[u].b - cpv * c[u].a);
-                cpv = c[u].c * div;
-                dpv = (c[u].d - dpv * c[u].a) * div;
+                const float den = c[u].b - cpv * c[u].a;
+                if (tdiv) {
+                    cpv = c[u].c / den;
+                    dpv = (c[u].d - dpv * c[u].a) / den;
+                } else {
+                    const float div = 1.0f / den;
+                    cpv = c[u].c * div;
+                    dpv = (c[u].d - dpv * c[u].a) * div;
+                }
                 cp[base + k * stride] = cpv;
                 dp[base + k * stride] = dpv;
             }
@@ -716,15 +733,11 @@ __global__ void __launch_bounds__(64) k_alr_zebra(typename Mdl::Ctx q, float *x,
 constexpr int ZB_NM = 7;                        // mover waves = tiles per round
 constexpr int ZB_LW = 8;                        // lines per workgroup
 constexpr int ZB_TE = 32;                       // elements per tile
-constexpr int ZB_SB = 8;                        // elements the solver holds in registers at a time
 constexpr int ZB_GP = ZB_TE / 4;                // 4-element groups per line of a tile
 constexpr int ZB_LP = 64 / ZB_GP;               // lines one mover pass covers
 constexpr int ZB_NP = ZB_LW / ZB_LP;            // mover passes per tile
-constexpr int ZB_LS = ZB_TE + 1;                // float4 per line in a tile (padded)
-constexpr int ZB_TILE = ZB_LW * ZB_LS;          // float4 per tile
 constexpr int ZB_THREADS = 64 * (1 + ZB_NM);
-constexpr size_t ZB_LDS_BYTES = (size_t)2 * ZB_NM * ZB_TILE * sizeof(float4);
-static_assert(ZB_NP * ZB_LP == ZB_LW && ZB_TE % ZB_SB == 0, "zebra tile geometry");
+static_assert(ZB_NP * ZB_LP == ZB_LW, "zebra tile geometry");
 
 __device__ __forceinline__ void alr_st4(float *p, float a, float b, float c, float d)
 {
@@ -739,261 +752,6 @@ __device__ __forceinline__ void alr_st4(float *p, float a, float b, float c, flo
 // APPLY:  one relaxation of the lines first, first+lstep, ... <= lastc with those planes: the forward
 //         recurrence is down to dp = (d - dp' a) * dv -- three dependent instructions instead of a division.
 enum { ZB_FACTOR = 1, ZB_APPLY = 2 };
-
-template <class Mdl, bool VERT, int MODE>
-__global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra2(typename Mdl::Ctx q, float *x, float *__restrict__ cp,
-                                                           float *__restrict__ dv, float *__restrict__ dp, int nrows, int ncols,
-                                                           size_t frame_stride, int first, int lastc, int lstep, float omega)
-{
-    extern __shared__ float4 zb_lds[]; // [2][ZB_NM][ZB_TILE]
-    const size_t fo = (size_t)blockIdx.y * frame_stride;
-    q.shift(fo);
-    x += fo;
-    cp += fo;
-    dv += fo;
-    dp += fo;
-    const int n = VERT ? nrows : ncols, nlines = VERT ? ncols : nrows;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int line0 = first + lstep * ZB_LW * (int)blockIdx.x;     // workgroup line index L -> line0 + lstep * L
-    const float om1 = 1.0f - omega;
-    constexpr int RE = ZB_NM * ZB_TE;
-    const int nrounds = (n + RE - 1) / RE;
-
-    // mover: lane -> (line index within the workgroup, 4-element group of the tile), ZB_NP passes per tile
-    const int mslot = wave - 1;
-    const int mg = lane % ZB_GP, ml = lane / ZB_GP;
-    auto tile_of = [&](int buf, int slot) __attribute__((always_inline)) { return zb_lds + ((size_t)buf * ZB_NM + slot) * ZB_TILE; };
-
-    auto produce = [&](int r, int buf) __attribute__((always_inline)) { // operands of round r, slot mslot -> (a,b,c,d) rows
-        const int k0 = (r * ZB_NM + mslot) * ZB_TE;
-        if (k0 >= n) return;
-        float4 *T = tile_of(buf, mslot);
-        if (k0 + ZB_TE - 1 <= n - 1) { // whole tile inside the line (wave-uniform): all passes' loads go out together
-            Tri t[ZB_NP][4];
-            float fc[ZB_NP][4], fd[ZB_NP][4];
-#pragma unroll
-            for (int rr = 0; rr < ZB_NP; ++rr) {
-                const int l = min(line0 + lstep * (ml + ZB_LP * rr), lastc);
-                Mdl::template coef4<VERT>(q, l, k0 + 4 * mg, n, nlines, t[rr]);
-                if (MODE == ZB_APPLY) {
-                    alr_ld4(cp + (size_t)l * n + k0 + 4 * mg, fc[rr]);
-                    alr_ld4(dv + (size_t)l * n + k0 + 4 * mg, fd[rr]);
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < ZB_NP; ++rr)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    T[(ml + ZB_LP * rr) * ZB_LS + 4 * mg + e] = MODE == ZB_APPLY ? make_float4(t[rr][e].a, fd[rr][e], fc[rr][e], t[rr][e].d)
-                                                                                  : make_float4(t[rr][e].a, t[rr][e].b, t[rr][e].c, t[rr][e].d);
-            return;
-        }
-#pragma unroll
-        for (int rr = 0; rr < ZB_NP; ++rr) {
-            const int L = ml + ZB_LP * rr, k = k0 + 4 * mg;
-            const int l = min(line0 + lstep * L, lastc); // clamped: a workgroup past the last line still loads valid memory
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (k + e <= n - 1) {
-                    const Tri t = Mdl::template coef<VERT>(q, AlrAt(l, k + e, n, nlines));
-                    const size_t pos = (size_t)l * n + k + e;
-                    T[L * ZB_LS + 4 * mg + e] = MODE == ZB_APPLY ? make_float4(t.a, dv[pos], cp[pos], t.d) : make_float4(t.a, t.b, t.c, t.d);
-                }
-        }
-    };
-    // results of a finished tile: grabbed into registers first (the tile is about to be refilled), written
-    // to global after the next tile's loads have been consumed, so no store sits on the critical path
-    float ra[ZB_NP][4], rb[ZB_NP][4]; // forward: cp, dp; backward: blended x (ra)
-    auto grab = [&](int buf, bool fwd) __attribute__((always_inline)) {
-        const float4 *T = tile_of(buf, mslot);
-#pragma unroll
-        for (int rr = 0; rr < ZB_NP; ++rr)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float4 t = T[(ml + ZB_LP * rr) * ZB_LS + 4 * mg + e];
-                ra[rr][e] = fwd ? t.z : t.x;
-                rb[rr][e] = t.w;
-            }
-    };
-    auto put = [&](int r, bool fwd) __attribute__((always_inline)) { // FACTOR: ra -> cp, rb -> dv; APPLY forward: rb -> dp, backward: ra -> x
-        const int k0 = (r * ZB_NM + mslot) * ZB_TE;
-#pragma unroll
-        for (int rr = 0; rr < ZB_NP; ++rr) {
-            const int k = k0 + 4 * mg;
-            const int l = line0 + lstep * (ml + ZB_LP * rr);
-            const size_t pos = (size_t)min(l, lastc) * n + min(k, n - 1);
-            float *pa = fwd ? cp : x, *pb = MODE == ZB_FACTOR ? dv : dp;
-            const bool use_a = !fwd || MODE == ZB_FACTOR;
-            if (l <= lastc && k + 3 <= n - 1) {
-                if (use_a) alr_st4(pa + pos, ra[rr][0], ra[rr][1], ra[rr][2], ra[rr][3]);
-                if (fwd) alr_st4(pb + pos, rb[rr][0], rb[rr][1], rb[rr][2], rb[rr][3]);
-            } else if (l <= lastc) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (k + e <= n - 1) {
-                        if (use_a) pa[pos + e] = ra[rr][e];
-                        if (fwd) pb[pos + e] = rb[rr][e];
-                    }
-            }
-        }
-    };
-    auto load_bwd = [&](int r, int buf) __attribute__((always_inline)) { // (cp, dp, old x) of round r -> rows (., old x, cp, dp)
-        const int k0 = (r * ZB_NM + mslot) * ZB_TE;
-        if (k0 >= n) return;
-        float4 *T = tile_of(buf, mslot);
-        if (k0 + ZB_TE - 1 <= n - 1) {
-            float c[ZB_NP][4], d[ZB_NP][4], o[ZB_NP][4];
-#pragma unroll
-            for (int rr = 0; rr < ZB_NP; ++rr) {
-                const size_t pos = (size_t)min(line0 + lstep * (ml + ZB_LP * rr), lastc) * n + k0 + 4 * mg;
-                alr_ld4(cp + pos, c[rr]); alr_ld4(dp + pos, d[rr]); alr_ld4(x + pos, o[rr]);
-            }
-#pragma unroll
-            for (int rr = 0; rr < ZB_NP; ++rr)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) T[(ml + ZB_LP * rr) * ZB_LS + 4 * mg + e] = make_float4(0.0f, o[rr][e], c[rr][e], d[rr][e]);
-            return;
-        }
-#pragma unroll
-        for (int rr = 0; rr < ZB_NP; ++rr) {
-            const int L = ml + ZB_LP * rr, k = k0 + 4 * mg;
-            const size_t pos = (size_t)min(line0 + lstep * L, lastc) * n + min(k, n - 1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (k + e <= n - 1) T[L * ZB_LS + 4 * mg + e] = make_float4(0.0f, x[pos + e], cp[pos + e], dp[pos + e]);
-        }
-    };
-    // LDS hand-off only: global stores need not have landed (nothing re-reads them across threads in this
-    // kernel), so the barrier does not drain them as __syncthreads() would
-    auto lds_barrier = [&]() __attribute__((always_inline)) { __asm__ volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    // solver: the round is a sequence of ZB_NM * ZB_TE / ZB_SB sub-blocks of ZB_SB elements of this lane's line
-    constexpr int SPT = ZB_TE / ZB_SB, NSUB = ZB_NM * SPT;
-    auto sub_rows = [&](int buf, int j) __attribute__((always_inline)) { return tile_of(buf, j / SPT) + lane * ZB_LS + (j % SPT) * ZB_SB; };
-    const bool solver = wave == 0 && lane < ZB_LW;
-
-    // ---- forward elimination (opticalflowSolvers.c:1890-1950) -------------------------------------------
-    float cpv = 0.0f, dpv = 0.0f; // solver state (cp while factoring, dp while applying)
-    // one sub-block of the forward recurrence on rows already in registers; results back to LDS
-    auto fwd_block = [&](float4 (&row)[ZB_SB], float4 *T, int k0) __attribute__((always_inline)) {
-        if (k0 > n - 1) return; // past the end of the line (last round only); wave-uniform
-        if (MODE == ZB_APPLY) { // row = (a, divisor, cp, d): dp -> .w
-            if (k0 >= 1 && k0 + ZB_SB - 1 <= n - 2) {
-#pragma unroll
-                for (int e = 0; e < ZB_SB; ++e) {
-                    dpv = (row[e].w - dpv * row[e].x) * row[e].y;
-                    T[e].w = dpv;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < ZB_SB; ++e) {
-                    const int k = k0 + e; // wave-uniform
-                    if (k == 0) dpv = row[e].w / row[e].y;
-                    else if (k == n - 1) dpv = (row[e].w - dpv * row[e].x) / row[e].y;
-                    else if (k < n - 1) dpv = (row[e].w - dpv * row[e].x) * row[e].y;
-                    T[e].w = dpv;
-                }
-            }
-        } else if (k0 >= 1 && k0 + ZB_SB - 1 <= n - 2) { // FACTOR, no first / last element in this sub-block
-#pragma unroll
-            for (int e = 0; e < ZB_SB; ++e) {
-                const float div = 1.0f / (row[e].y - cpv * row[e].x);
-                cpv = row[e].z * div;
-                T[e].z = cpv;
-                T[e].w = div;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < ZB_SB; ++e) {
-                const int k = k0 + e; // wave-uniform
-                float dvv = 0.0f;
-                if (k == 0) {
-                    dvv = row[e].y; // the first element is divided by b
-                    cpv = row[e].z / row[e].y;
-                } else if (k == n - 1) { // ... and the last by its bare denominator; cp = 0 closes the back-substitution
-                    dvv = row[e].y - cpv * row[e].x;
-                    cpv = 0.0f;
-                } else if (k < n - 1) {
-                    dvv = 1.0f / (row[e].y - cpv * row[e].x);
-                    cpv = row[e].z * dvv;
-                }
-                T[e].z = cpv;
-                T[e].w = dvv;
-            }
-        }
-    };
-    auto fetch = [&](float4 (&row)[ZB_SB], int buf, int j) __attribute__((always_inline)) {
-        const float4 *T = sub_rows(buf, min(max(j, 0), NSUB - 1));
-#pragma unroll
-        for (int e = 0; e < ZB_SB; ++e) row[e] = T[e];
-    };
-    static_assert(NSUB % 2 == 0, "the solver ping-pongs two register sets");
-
-    if (wave > 0) produce(0, 0);
-    lds_barrier();
-    for (int r = 0; r < nrounds; ++r) {
-        if (solver) {
-            // two register sets: the next sub-block's rows are in flight from LDS while this one's steps run
-            float4 A[ZB_SB], B[ZB_SB];
-            const int kr = __builtin_amdgcn_readfirstlane(r * RE);
-            fetch(A, r & 1, 0);
-            for (int j = 0; j < NSUB; j += 2) {
-                fetch(B, r & 1, j + 1);
-                fwd_block(A, sub_rows(r & 1, j), kr + j * ZB_SB);
-                fetch(A, r & 1, j + 2);
-                fwd_block(B, sub_rows(r & 1, j + 1), kr + (j + 1) * ZB_SB);
-            }
-        } else if (wave > 0) {
-            if (r >= 1) grab((r - 1) & 1, true);
-            if (r + 1 < nrounds) produce(r + 1, (r + 1) & 1);
-            if (r >= 1) put(r - 1, true);
-        }
-        lds_barrier();
-    }
-    if (wave > 0) {
-        grab((nrounds - 1) & 1, true);
-        put(nrounds - 1, true);
-    }
-    if (MODE == ZB_FACTOR) return;
-    if (wave > 0) {
-        __threadfence_block(); // every dp this thread reloads below was stored by this thread: drain them once
-        // ---- back-substitution with the lagged SOR blend (:1951-1958): x_k = dp_k - cp_k x_{k+1} ----------
-        load_bwd(nrounds - 1, (nrounds - 1) & 1);
-    }
-    lds_barrier();
-    float xs = 0.0f;
-    auto bwd_block = [&](float4 (&row)[ZB_SB], float4 *T, int k0) __attribute__((always_inline)) { // row = (., old x, cp, dp)
-        if (k0 > n - 1) return;
-#pragma unroll
-        for (int e = ZB_SB - 1; e >= 0; --e) {
-            if (k0 + e <= n - 1) { // wave-uniform
-                xs = row[e].w - row[e].z * xs;
-                T[e].x = omega * xs + om1 * row[e].y;
-            }
-        }
-    };
-    for (int r = nrounds - 1; r >= 0; --r) {
-        if (solver) {
-            float4 A[ZB_SB], B[ZB_SB];
-            const int kr = __builtin_amdgcn_readfirstlane(r * RE);
-            fetch(A, r & 1, NSUB - 1);
-            for (int j = NSUB - 1; j >= 0; j -= 2) {
-                fetch(B, r & 1, j - 1);
-                bwd_block(A, sub_rows(r & 1, j), kr + j * ZB_SB);
-                fetch(A, r & 1, j - 2);
-                bwd_block(B, sub_rows(r & 1, j - 1), kr + (j - 1) * ZB_SB);
-            }
-        } else if (wave > 0) {
-            if (r + 1 <= nrounds - 1) grab((r + 1) & 1, false);
-            if (r - 1 >= 0) load_bwd(r - 1, (r - 1) & 1);
-            if (r + 1 <= nrounds - 1) put(r + 1, false);
-        }
-        lds_barrier();
-    }
-    if (wave > 0) {
-        grab(0, false);
-        put(0, false);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_alr_zebra3: k_alr_zebra2 (both modes) with the solver wave's instruction count cut to the bone.
@@ -1161,6 +919,17 @@ __device__ __forceinline__ void alr_zebra3_body(typename Mdl::Ctx q, float *x, f
 
     // ---- solver ---------------------------------------------------------------------------------
     const bool solver = wave == 0 && lane < ZB_LW;
+    // The south row of the late-linearisation models divides where every other line multiplies by a reciprocal
+    // (Mdl::SOUTH_TRUEDIV).  It is one lane of one workgroup of the row pass: that workgroup (wave-uniform `wg_south`) runs
+    // the SOUTH instantiation of the forward bodies, whose middle elements select per lane; its divisor plane holds the bare
+    // denominator for that line.  Everybody else runs the unchanged fast bodies.
+    constexpr bool CAN_SOUTH = Mdl::SOUTH_TRUEDIV && !VERT;
+    bool tdiv = false, wg_south = false;
+    if constexpr (CAN_SOUTH) {
+        const int lsolve = line0 + lstep * lane;
+        tdiv = lane < ZB_LW && lsolve <= lastc && lsolve == nlines - 1;
+        wg_south = __builtin_amdgcn_ballot_w64(tdiv) != 0;
+    }
     auto ld8 = [&](const float *p, float (&v)[8]) __attribute__((always_inline)) {
         const float4 lo = *reinterpret_cast<const float4 *>(p), hi = *reinterpret_cast<const float4 *>(p + 4);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
@@ -1173,7 +942,8 @@ __device__ __forceinline__ void alr_zebra3_body(typename Mdl::Ctx q, float *x, f
     // going down (opticalflowSolvers.c:1890-1950): dp_k = (d_k - dp_{k-1} a_k) * divisor_k; the first element is divided
     // by b, the last by its bare denominator.  Tiles that hold neither end of the line take the branch-free body.
     float dpv = 0.0f;
-    auto fwd_edge = [&](float *P, int kr, int s0, int s1) __attribute__((always_inline)) {
+    auto fwd_edge = [&](auto south, float *P, int kr, int s0, int s1) __attribute__((always_inline)) {
+        constexpr bool S = decltype(south)::value;
 #pragma unroll 1
         for (int j = s0 * (TE / 8); j < s1 * (TE / 8); ++j) {
             const int k0 = kr + 8 * j;
@@ -1187,6 +957,7 @@ __device__ __forceinline__ void alr_zebra3_body(typename Mdl::Ctx q, float *x, f
                     if (MODE == ZB_APPLY) {
                         if (k == 0) dpv = d / v;
                         else if (k == n - 1) dpv = (d - dpv * a) / v;
+                        else if (S && tdiv) dpv = (d - dpv * a) / v; // v = the bare denominator on this line
                         else dpv = (d - dpv * a) * v;
                     } else { // rows a | b | c; dpv carries cp.  The first element is divided by b, the last by its bare denominator
                         float dvv;
@@ -1196,6 +967,9 @@ __device__ __forceinline__ void alr_zebra3_body(typename Mdl::Ctx q, float *x, f
                         } else if (k == n - 1) {
                             dvv = v - dpv * a;
                             dpv = 0.0f; // cp = 0 closes the back-substitution
+                        } else if (S && tdiv) {
+                            dvv = v - dpv * a;
+                            dpv = d / dvv;
                         } else {
                             dvv = 1.0f / (v - dpv * a);
                             dpv = d * dvv;
@@ -1207,7 +981,28 @@ __device__ __forceinline__ void alr_zebra3_body(typename Mdl::Ctx q, float *x, f
             }
         }
     };
-    auto fwd_fast = [&](float *P, int s0, int s1) __attribute__((always_inline)) {
+    // one element of the branch-free body: (a, v, d) -> v (FACTOR: the divisor to store), d (dp / cp), dpv
+    auto fwd_step = [&](auto south, float a, float &v, float &d) __attribute__((always_inline)) {
+        constexpr bool S = decltype(south)::value;
+        if (MODE == ZB_APPLY) {
+            const float t = d - dpv * a;
+            if constexpr (S) dpv = tdiv ? t / v : t * v;
+            else dpv = t * v;
+        } else {
+            const float den = v - dpv * a;
+            const float r = 1.0f / den;
+            if constexpr (S) {
+                const float cq = d / den;
+                v = tdiv ? den : r;
+                dpv = tdiv ? cq : d * r;
+            } else {
+                v = r;
+                dpv = d * r;
+            }
+        }
+        d = dpv;
+    };
+    auto fwd_fast = [&](auto south, float *P, int s0, int s1) __attribute__((always_inline)) {
         if (s0 >= s1) return;
         float a0[8], v0[8], d0[8], a1[8], v1[8], d1[8];
         ld8(P + s0 * Z3_TILE, a0); ld8(P + s0 * Z3_TILE + TE, v0); ld8(P + s0 * Z3_TILE + 2 * TE, d0);
@@ -1219,29 +1014,13 @@ __device__ __forceinline__ void alr_zebra3_body(typename Mdl::Ctx q, float *x, f
             for (int h = 0; h < TE / 16; ++h) {
                 ld8(Q + 16 * h + 8, a1); ld8(Q + 16 * h + 8 + TE, v1); ld8(Q + 16 * h + 8 + 2 * TE, d1);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (MODE == ZB_APPLY) {
-                        dpv = (d0[e] - dpv * a0[e]) * v0[e];
-                    } else {
-                        v0[e] = 1.0f / (v0[e] - dpv * a0[e]);
-                        dpv = d0[e] * v0[e];
-                    }
-                    d0[e] = dpv;
-                }
+                for (int e = 0; e < 8; ++e) fwd_step(south, a0[e], v0[e], d0[e]);
                 st8(Q + 16 * h + 2 * TE, d0);
                 if (MODE == ZB_FACTOR) st8(Q + 16 * h + TE, v0);
                 const float *F = h == TE / 16 - 1 ? N : Q + 16 * (h + 1);
                 ld8(F, a0); ld8(F + TE, v0); ld8(F + 2 * TE, d0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (MODE == ZB_APPLY) {
-                        dpv = (d1[e] - dpv * a1[e]) * v1[e];
-                    } else {
-                        v1[e] = 1.0f / (v1[e] - dpv * a1[e]);
-                        dpv = d1[e] * v1[e];
-                    }
-                    d1[e] = dpv;
-                }
+                for (int e = 0; e < 8; ++e) fwd_step(south, a1[e], v1[e], d1[e]);
                 st8(Q + 16 * h + 8 + 2 * TE, d1);
                 if (MODE == ZB_FACTOR) st8(Q + 16 * h + 8 + TE, v1);
             }
@@ -1255,9 +1034,15 @@ __device__ __forceinline__ void alr_zebra3_body(typename Mdl::Ctx q, float *x, f
             const int kr = __builtin_amdgcn_readfirstlane(r * RE);
             const int s0 = kr == 0 ? 1 : 0;                                   // tile 0 of round 0 holds the first element
             const int s1 = max(s0, min(ZB_NM, (n - 1 - kr) / TE));            // tiles [s0, s1) end at or before element n-2
-            fwd_edge(P, kr, 0, s0);
-            fwd_fast(P, s0, s1);
-            fwd_edge(P, kr, s1, ZB_NM);
+            if (CAN_SOUTH && wg_south) {
+                fwd_edge(std::true_type{}, P, kr, 0, s0);
+                fwd_fast(std::true_type{}, P, s0, s1);
+                fwd_edge(std::true_type{}, P, kr, s1, ZB_NM);
+            } else {
+                fwd_edge(std::false_type{}, P, kr, 0, s0);
+                fwd_fast(std::false_type{}, P, s0, s1);
+                fwd_edge(std::false_type{}, P, kr, s1, ZB_NM);
+            }
         } else if (wave > 0) {
             if (r >= 1) grab((r - 1) & 1, true);
             if (r + 1 < nrounds) produce(r + 1, (r + 1) & 1);
@@ -1363,7 +1148,7 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_factor_pair(typename Mdl::Ct
 // Reference line order.
 //
 // cp[k] = c/(b - cp[k-1] a) depends on the coefficient planes only, not on the iterate, so it is the same
-// in every iteration of a call: k_alr_zebra2<ZB_FACTOR> runs that recurrence once per call for every line
+// in every iteration of a call: k_alr_zebra3<ZB_FACTOR> runs that recurrence once per call for every line
 // and stores cp and the per-element divisor (1/(b - cp a); b itself for
 // the first element, the plain denominator for the last -- those two are divided by, as in the
 // reference).  What is left per line and iteration is the right-hand side (parallel along the line)
@@ -1378,7 +1163,7 @@ constexpr int ALR_LEX_THREADS = 1024;
 template <class Mdl> struct AlrChain {
     typename Mdl::Ctx q;
     float *x;            // the plane this chain solves (q reads it too)
-    const float *cp, *dv; // the factor planes (k_alr_zebra2<ZB_FACTOR>) of this field and direction
+    const float *cp, *dv; // the factor planes (k_alr_zebra3<ZB_FACTOR>) of this field and direction
 };
 template <class Mdl, int NCH> struct AlrChains {
     AlrChain<Mdl> c[NCH];
@@ -1406,7 +1191,9 @@ __device__ __forceinline__ float alr_from_upper_lane(float v)
 // each with exactly the operands and the rounding of the serial loop.
 constexpr int ALR_BLK = 63;
 
-__device__ __forceinline__ void alr_serial_wave(float4 *L, int n, int lane)
+// `tdiv` (wave-uniform): the line is the south row of a model whose south-row function divides (Mdl::SOUTH_TRUEDIV); its
+// middle elements then carry the bare denominator in .y and dp = (d - dp' a) / den.
+__device__ __forceinline__ void alr_serial_wave(float4 *L, int n, int lane, bool tdiv)
 {
     float carry; // wave-uniform: dp of the element before the current block
     {
@@ -1426,7 +1213,9 @@ __device__ __forceinline__ void alr_serial_wave(float4 *L, int n, int lane)
         nxt = L[min(k + ALR_BLK, n - 2)]; // next block's operands, in flight during this block's passes
         if (lane == 0) e = make_float4(0.0f, 1.0f, 0.0f, carry);
         float dp = 0.0f;
-        if (cnt == ALR_BLK) {
+        if (tdiv) { // lane 0: (carry - 0 * 0) / 1 = carry exactly
+            for (int u = 0; u <= cnt; ++u) dp = (e.w - alr_from_lower_lane(dp) * e.x) / e.y;
+        } else if (cnt == ALR_BLK) {
 #pragma unroll
             for (int u = 0; u <= ALR_BLK; ++u) dp = (e.w - alr_from_lower_lane(dp) * e.x) * e.y;
         } else {
@@ -1507,7 +1296,7 @@ __global__ void __launch_bounds__(ALR_LEX_THREADS) k_alr_lex(AlrChains<Mdl, NCH>
         __syncthreads();
         if ((tid >> 6) < NCH) {
             const int c = tid >> 6, l = s - c;
-            if (l >= lo && l <= hi) alr_serial_wave(alr_lds + (size_t)c * n, n, tid & 63);
+            if (l >= lo && l <= hi) alr_serial_wave(alr_lds + (size_t)c * n, n, tid & 63, Mdl::SOUTH_TRUEDIV && !VERT && l == nrows - 1);
         } else {
             // The other waves have nothing to do while the recurrences run: they touch everything the next
             // step's build will read (with values that are still stale, hence discarded), so that build

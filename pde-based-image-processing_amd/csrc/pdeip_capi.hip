@@ -696,35 +696,15 @@ static int check_alr_line(const char *who, int mode, int nrows, int ncols)
     return PDEIP_OK;
 }
 
-// Workspace of one call: per (chain, direction) the cp and divisor planes (k_alr_zebra2<ZB_FACTOR>).
+// Workspace of one call: per (chain, direction) the cp and divisor planes (k_alr_zebra3<ZB_FACTOR>).
 struct AlrFactors {
     float *cp[2][2], *dv[2][2]; // [chain][vertical ? 0 : 1]
 };
 
 template <class Mdl, bool VERT, int MODE>
-static int zebra2_launch(hipStream_t s, const typename Mdl::Ctx &q, float *x, float *cp, float *dv, float *dp, int nrows, int ncols,
-                         int nframes, int first, int lastc, int lstep, float omega)
-{
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_alr_zebra2<Mdl, VERT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZB_LDS_BYTES));
-        attr_set = true;
-    }
-    const int count = (lastc - first) / lstep + 1;
-    hipLaunchKernelGGL((k_alr_zebra2<Mdl, VERT, MODE>), dim3((unsigned)((count + ZB_LW - 1) / ZB_LW), (unsigned)nframes), dim3(ZB_THREADS),
-                       ZB_LDS_BYTES, s, q, x, cp, dv, dp, nrows, ncols, (size_t)nrows * ncols, first, lastc, lstep, omega);
-    g.last_launches++;
-    HIPCHK(hipGetLastError());
-    return PDEIP_OK;
-}
-
-// k_alr_zebra3 unless PDEIP_ALR_ZEBRA2 asks for the older kernel (same results)
-template <class Mdl, bool VERT, int MODE>
 static int zebra3_launch(hipStream_t s, const typename Mdl::Ctx &q, float *x, float *cp, float *dv, float *dp, int nrows, int ncols, int nframes,
                          int first, int lastc, int lstep, float omega)
 {
-    static const bool old = getenv("PDEIP_ALR_ZEBRA2") != nullptr;
-    if (old) return zebra2_launch<Mdl, VERT, MODE>(s, q, x, cp, dv, dp, nrows, ncols, nframes, first, lastc, lstep, omega);
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_alr_zebra3<Mdl, VERT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Z3_LDS_BYTES));
@@ -753,8 +733,7 @@ static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, const typename 
             f->cp[c][d] = base + plane * (size_t)((c * 2 + d) * 2);
             f->dv[c][d] = f->cp[c][d] + plane;
         }
-    static const bool old = getenv("PDEIP_ALR_ZEBRA2") != nullptr;
-    if (nch == 2 && !old) { // both fields of a coupled solver in one launch per direction
+    if (nch == 2) { // both fields of a coupled solver in one launch per direction
         for (int d = 0; d < 2; d++) {
             const int hi = (d == 0 ? ncols : nrows) - 1 - lo, count = hi - lo + 1;
             const dim3 grid((unsigned)((count + ZB_LW - 1) / ZB_LW), (unsigned)nframes, 2);
@@ -821,7 +800,7 @@ static int alr_lex_pass(hipStream_t s, const typename Mdl::Ctx *q, float *const 
     return PDEIP_OK;
 }
 
-// One direction of one field in zebra order: even lines, then odd lines: k_alr_zebra2 with the per-call factor
+// One direction of one field in zebra order: even lines, then odd lines: k_alr_zebra3 with the per-call factor
 // planes (cpf, dvf); the others: one lane per line (k_alr_zebra).
 template <class Mdl>
 static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, const float *cpf, const float *dvf, int nrows, int ncols,
