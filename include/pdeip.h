@@ -64,9 +64,22 @@ const char *pdeip_version(void);
 const char *pdeip_last_error(void);
 int pdeip_set_mode(int mode);
 int pdeip_get_mode(void);
-/* Select the HIP device used by the host-pointer entry points (default 0). */
+/* Select the HIP device used by the host-pointer entry points (default 0) = pdeip_set_devices(1, &device_id). */
 int pdeip_set_device(int device_id);
-/* Release the cached device workspace (optional; the process exit also releases it). */
+/* Device group of the host-pointer entry points.  With n > 1, red-black (PDEIP_MODE_RED_BLACK) point-SOR solver calls
+ * are cut into n slabs of consecutive MATLAB columns, one per device, each slab relaxed by its device with a wide column
+ * halo that is exchanged device-to-device between sweep pairs (csrc/pdeip_multi.hip); results are bit-identical to the
+ * single-device red-black call.  Exact-order calls and line relaxation do not decompose (their dependency front crosses
+ * the frame) and run on ids[0].  Workspace is cached per device. */
+int pdeip_set_devices(int n, const int *ids);
+/* Writes up to `capacity` ids of the current group to ids (may be NULL) and returns the group size. */
+int pdeip_get_devices(int *ids, int capacity);
+/* Environment knobs, read once before the first call that needs them, so that an unchanged MATLAB session can opt in
+ * without touching a signature (explicit pdeip_set_mode / pdeip_set_device(s) calls made before that win):
+ *   PDEIP_MODE     exact | red_black        sweep ordering of the host entry points (default exact)
+ *   PDEIP_DEVICE   n                        = pdeip_set_device(n)
+ *   PDEIP_DEVICES  a,b,c,...                = pdeip_set_devices */
+/* Release the cached device workspace of every device (optional; the process exit also releases it). */
 int pdeip_release(void);
 /* Number of kernel launches the last *_dev solver call enqueued (diagnostic). */
 int pdeip_last_launch_count(void);

@@ -103,6 +103,8 @@ SIGNATURES = {
     "pdeip_set_mode": [_I],
     "pdeip_get_mode": [],
     "pdeip_set_device": [_I],
+    "pdeip_set_devices": [_I, ctypes.POINTER(ctypes.c_int)],
+    "pdeip_get_devices": [ctypes.POINTER(ctypes.c_int), _I],
     "pdeip_release": [],
     "pdeip_last_launch_count": [],
     "pdeip_persist_error": [],
@@ -167,6 +169,17 @@ def set_mode(mode):
 
 def get_mode():
     return load().pdeip_get_mode()
+
+
+def set_devices(ids):
+    ids = [int(i) for i in ids]
+    call("pdeip_set_devices", len(ids), (ctypes.c_int * len(ids))(*ids))
+
+
+def get_devices():
+    buf = (ctypes.c_int * 16)()
+    n = load().pdeip_get_devices(buf, 16)
+    return [buf[k] for k in range(n)]
 
 
 def profile_enable(on=True):

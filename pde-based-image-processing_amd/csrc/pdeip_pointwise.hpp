@@ -35,7 +35,7 @@ __global__ void k_derive(SweepPlanes<Mdl> P, float *out0, float *out1, int nrows
 }
 
 // pdeSolvers.c:217-237
-__global__ void k_pde8_divisors(float *bt, float *inv, const float *TRACE, const float *B,
+static __global__ void k_pde8_divisors(float *bt, float *inv, const float *TRACE, const float *B,
                                 const float *wW, const float *wNW, const float *wN,
                                 const float *wNE, const float *wE, const float *wSE,
                                 const float *wS, const float *wSW, int nrows, int ncols,
@@ -177,7 +177,7 @@ __device__ __forceinline__ float dw_inv_sqrt(float t, float eps)
     return 1.0f / sqrtf(s);
 }
 
-__global__ void k_diffweights6(float *wW, float *wN, float *wE, float *wS, const float *D,
+static __global__ void k_diffweights6(float *wW, float *wN, float *wE, float *wS, const float *D,
                                int nrows, int ncols, int nframes, float eps)
 {
     PDEIP_PIXEL_INDEX();
@@ -222,7 +222,7 @@ __global__ void k_diffweights6(float *wW, float *wN, float *wE, float *wS, const
 
 // ---- bilinear warp: bilinInterp2 (imageInterpolation.c:44-140) --------------------------------
 
-__global__ void k_warp_bilinear(float *Iout, const float *Iin, const float *X, const float *Y,
+static __global__ void k_warp_bilinear(float *Iout, const float *Iin, const float *X, const float *Y,
                                 int nrows, int ncols, int nframes)
 {
     PDEIP_PIXEL_INDEX();
@@ -308,7 +308,7 @@ __device__ __forceinline__ float v5_of_h5(const float *in, const float *op1, con
     return sum5(t);
 }
 
-__global__ void k_fst_derivatives5(float *Idt, float *Idx, float *Idy, const float *It0, const float *It1,
+static __global__ void k_fst_derivatives5(float *Idt, float *Idx, float *Idy, const float *It0, const float *It1,
                                    int nrows, int ncols, size_t frame_stride)
 {
     PDEIP_PIXEL_INDEX();
@@ -319,7 +319,7 @@ __global__ void k_fst_derivatives5(float *Idt, float *Idx, float *Idy, const flo
     Idy[fo + pos] = v5_of_h5(b, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);      // :380-382
 }
 
-__global__ void k_snd_derivatives5(float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy,
+static __global__ void k_snd_derivatives5(float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy,
                                    const float *It0, const float *It1, int nrows, int ncols, size_t frame_stride)
 {
     PDEIP_PIXEL_INDEX();

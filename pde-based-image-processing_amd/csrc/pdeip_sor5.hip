@@ -1,0 +1,318 @@
+// pdeip_sor5.hip -- libpdeip.so: point SOR, 5-point models: launch logic (red-black / exact order) and the *_dev entry points.
+//
+// Build (build.py): hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -c, one object per translation unit.
+// -ffp-contract=off is part of the parity contract: the reference is plain C built without FMA.
+#include "pdeip_ctx.hpp"
+
+#include "pdeip_models.hpp"
+#include "pdeip_pointwise.hpp"
+#include "pdeip_sor_exact.hpp"
+#include "pdeip_sor_rb.hpp"
+
+using namespace pdeip;
+
+namespace {
+
+// Strip width of the two-sweeps-per-launch kernel.  That kernel holds four column stages in registers
+// (one wave per SIMD) and is bound by its instruction stream, not by HBM: a launch takes
+// ceil(units / resident waves) rounds of (TJ + 6) steps, so the best TJ is the one that fills the last
+// round (4K: 12 -> 3 rounds of 18 steps, 133 us; 34 -> 1 round of 40 steps, 113 us; 33 -> 2 rounds, 182 us).
+template <class Mdl>
+int pick_rb2_tj(int nrows, int ncols, int nframes, int ntiles_r)
+{
+    (void)nrows;
+    const int forced = g.rb_tj > 0 ? g.rb_tj : env_int("PDEIP_RB_TJ", 0);
+    if (forced > 0) return forced < 2 ? 2 : forced;
+    // waves of this kernel the device holds at once
+    const int slots = resident_waves(reinterpret_cast<const void *>(&k_sor_rb<Mdl, true, false, true>), 64 * RB_WAVES_PER_BLOCK, RB_WAVES_PER_BLOCK);
+    int best = 12;
+    long best_cost = -1;
+    for (int tj = 2; tj <= 64; tj++) {
+        const long units = (long)ntiles_r * ((ncols + tj - 1) / tj) * nframes;
+        const long cost = ((units + slots - 1) / slots) * (tj + 6);
+        if (best_cost < 0 || cost <= best_cost) { // ties: the wider strip re-reads fewer halo columns
+            best_cost = cost;
+            best = tj;
+        }
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sweep drivers (5-point models)
+// ------------------------------------------------------------------------------------------------
+
+// Runs `iter` sweeps of model Mdl on the iterate buffers P.it_out (in place from the caller's
+// point of view).  P.ro and P.cf must be set, with the RAW planes in the two derived slots
+// (Mdl::D0, Mdl::D1); the derived planes (divisors) are built into workspace here.
+template <class Mdl>
+int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nframes, int iter,
+               float omega, int mode, int col0)
+{
+    constexpr int NIT = Mdl::NIT;
+    const size_t n = (size_t)nrows * ncols;
+    g.last_launches = 0;
+    if (iter <= 0) return PDEIP_OK;
+    float *aux0 = nullptr, *aux1 = nullptr;
+    RC(ws_get(WS_AUX0, n * nframes * sizeof(float), &aux0));
+    RC(ws_get(WS_AUX1, n * nframes * sizeof(float), &aux1));
+
+    if (mode == PDEIP_MODE_EXACT_ORDER) {
+        hipLaunchKernelGGL(k_derive<Mdl>, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, P, aux0, aux1, nrows, ncols, n);
+        g.last_launches++;
+        P.cf[Mdl::D0] = aux0;
+        P.cf[Mdl::D1] = aux1;
+        const int A = (nrows - 2 + 63 + EX_R - 1) / EX_R;
+        const int B = (ncols - 2 + 63) / 64;
+        const int last_m = (A - 1) + 2 * (B - 1) + 3 * (iter - 1);
+        for (int f = 0; f < NIT; f++) P.it_in[f] = P.it_out[f];
+        // Launch-per-front or persistent?  The persistent form wins at every iter and frame size (tools/time_exact_persist.py:
+        // 4K 2.70 vs 2.87 ms at iter=4 -- each strip has to trail its west neighbour by 64 rows plus the hand-off latency either
+        // way --, 1.4x at iter=20, 1.3x at 1080p, 2.4x at 34x60: no per-front launch, sweeps overlap more tightly).
+        // PDEIP_EXACT_PERSIST = 0 falls back to one launch per front.
+        const bool persist = env_int("PDEIP_EXACT_PERSIST", 1) != 0;
+        if (persist && B <= 0xffff && iter <= 0x7fff && n * sizeof(float) < 0xffffffffull) {
+            // ---- persistent form: one launch, progress counters instead of one launch per front ----
+            const int NC = (nrows - 2 + 63 + EX_CH - 1) / EX_CH;
+            float *ctl_f = nullptr, *order_f = nullptr;
+            const size_t nprog = (size_t)nframes * iter * B;
+            RC(ws_get(WS_CTL, (4 + nprog) * sizeof(unsigned), &ctl_f));
+            RC(ws_get(WS_ORDER, (size_t)B * iter * sizeof(int), &order_f));
+            DeviceState *dst = cur_dev(); // after the ws_get calls: a regrown WS_ORDER has dropped its cached shape
+            if (dst->order_B != B || dst->order_T != iter) { // (b,t) in an order where every dependency comes earlier
+                std::vector<int> ord;
+                ord.reserve((size_t)B * iter);
+                for (int key = 0; key <= (B - 1) + 2 * (iter - 1); key++)
+                    for (int t = 0; t < iter; t++) {
+                        const int b = key - 2 * t;
+                        if (b >= 0 && b < B) ord.push_back(b | (t << 16));
+                    }
+                HIPCHK(hipMemcpyAsync(order_f, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, s));
+                HIPCHK(hipStreamSynchronize(s)); // `ord` is about to go out of scope
+                dst->order_B = B;
+                dst->order_T = iter;
+            }
+            // word 0: abort (sticky: cleared only by pdeip_persist_error(), so a timed-out wait cannot be lost under the next
+            // call's reset); word 1: ticket; words 4..: progress counters
+            HIPCHK(hipMemsetAsync(reinterpret_cast<unsigned *>(ctl_f) + 1, 0, (3 + nprog) * sizeof(unsigned), s));
+            PersistCtl ctl;
+            ctl.abort_flag = reinterpret_cast<unsigned *>(ctl_f);
+            ctl.ticket = ctl.abort_flag + 1;
+            ctl.progress = ctl.abort_flag + 4;
+            ctl.order = reinterpret_cast<const int *>(order_f);
+            constexpr size_t plds = ExactLayout<Mdl>::LDS_BYTES + 16;
+            RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_exact_persist<Mdl>), plds));
+            dst->persist_used = true;
+            SweepTimer timer(s);
+            hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(B * iter * nframes)), dim3(128), plds, s, P, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
+            timer.stop(1);
+            g.last_launches++;
+            const int nb = 2 * ncols + 2 * (nrows - 2);
+            hipLaunchKernelGGL(k_fill_borders, dim3((nb + 255) / 256, nframes, NIT), dim3(256), 0, s,
+                               P.it_out[0], P.it_out[NIT - 1], NIT, nrows, ncols, n);
+            g.last_launches++;
+            HIPCHK(hipGetLastError());
+            return PDEIP_OK;
+        }
+        const dim3 grid((unsigned)(B * iter), (unsigned)nframes);
+        constexpr size_t lds = ExactLayout<Mdl>::LDS_BYTES;
+        RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_exact<Mdl>), lds)); // > 64 KiB of dynamic LDS needs an explicit opt-in
+        SweepTimer timer(s);
+        for (int m = 0; m <= last_m; m++) {
+            hipLaunchKernelGGL(k_sor_exact<Mdl>, grid, dim3(128), lds, s, P, nrows, ncols, A, B, iter, m, omega, n);
+            g.last_launches++;
+        }
+        timer.stop(last_m + 1);
+        const int nb = 2 * ncols + 2 * (nrows - 2);
+        hipLaunchKernelGGL(k_fill_borders, dim3((nb + 255) / 256, nframes, NIT), dim3(256), 0, s,
+                           P.it_out[0], P.it_out[NIT - 1], NIT, nrows, ncols, n);
+        g.last_launches++;
+        HIPCHK(hipGetLastError());
+        return PDEIP_OK;
+    }
+
+    // red-black: ping-pong between the caller's buffers and a scratch copy
+    float *scratch = nullptr;
+    int rc = ws_get(WS_PING, (size_t)NIT * n * nframes * sizeof(float), &scratch);
+    if (rc) return rc;
+    float *bufA[NIT], *bufB[NIT];
+    bool vec = (nrows % 4 == 0);
+    for (int f = 0; f < NIT; f++) {
+        bufA[f] = P.it_out[f];
+        bufB[f] = scratch + (size_t)f * n * nframes;
+        vec = vec && aligned16(bufA[f]) && aligned16(bufB[f]);
+    }
+    for (int f = 0; f < Mdl::NCF; f++) vec = vec && aligned16(P.cf[f]);
+    vec = vec && aligned16(aux0) && aligned16(aux1);
+    for (int f = 0; f < Mdl::NRO; f++) vec = vec && aligned16(P.ro[f]);
+
+    const int ntiles_r = (nrows + RB_OWN_ROWS - 1) / RB_OWN_ROWS;
+    const dim3 block(64 * RB_WAVES_PER_BLOCK);
+    // Two sweeps per launch where the model allows it (pdeip_sor_rb.hpp, rb_march2): same results, about
+    // two thirds of the traffic per sweep.  PDEIP_RB_FUSE=0 keeps one sweep per launch.
+    static const bool fuse_enabled = env_int("PDEIP_RB_FUSE", 1) != 0;
+    const bool fuse = fuse_enabled;
+    const int TJ1 = pick_rb_tj(nrows, ncols), TJ2 = fuse ? pick_rb2_tj<Mdl>(nrows, ncols, nframes, ntiles_r) : TJ1;
+    SweepTimer timer(s);
+    int nlaunch = 0, flips = 0; // flips: how many times the iterate changed buffers
+    for (int it = 0; it < iter;) {
+        const bool two = fuse && it + 2 <= iter;
+        const int TJ = two ? TJ2 : TJ1;
+        const int nunits = ntiles_r * ((ncols + TJ - 1) / TJ);
+        const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);
+        for (int f = 0; f < NIT; f++) {
+            P.it_in[f] = (flips & 1) ? bufB[f] : bufA[f];
+            P.it_out[f] = (flips & 1) ? bufA[f] : bufB[f];
+        }
+        const bool first = it == 0; // sweep 0 also builds the divisor planes
+        float *d0 = first ? aux0 : nullptr, *d1 = first ? aux1 : nullptr;
+#define PDEIP_RB_LAUNCH(V, F, T) hipLaunchKernelGGL((k_sor_rb<Mdl, V, F, T>), grid, block, 0, s, P, d0, d1, nrows, ncols, TJ, ntiles_r, nunits, omega, col0, n)
+        if (two) {
+            if (vec) { if (first) PDEIP_RB_LAUNCH(true, true, true); else PDEIP_RB_LAUNCH(true, false, true); }
+            else     { if (first) PDEIP_RB_LAUNCH(false, true, true); else PDEIP_RB_LAUNCH(false, false, true); }
+        } else {
+            if (vec) { if (first) PDEIP_RB_LAUNCH(true, true, false); else PDEIP_RB_LAUNCH(true, false, false); }
+            else     { if (first) PDEIP_RB_LAUNCH(false, true, false); else PDEIP_RB_LAUNCH(false, false, false); }
+        }
+#undef PDEIP_RB_LAUNCH
+        if (first) {
+            P.cf[Mdl::D0] = aux0;
+            P.cf[Mdl::D1] = aux1;
+        }
+        it += two ? 2 : 1;
+        flips++;
+        nlaunch++;
+        g.last_launches++;
+    }
+    timer.stop(nlaunch);
+    if (flips & 1) // the last launch wrote the scratch copy
+        for (int f = 0; f < NIT; f++)
+            HIPCHK(hipMemcpyAsync(bufA[f], bufB[f], n * nframes * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+} // namespace
+
+#ifdef PDEIP_EXACT_STAMPS
+extern "C" int pdeip_debug_read_stamps(unsigned long long *out)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_exact_stamps), 64 * sizeof(unsigned long long)));
+    return PDEIP_OK;
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// device-pointer entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int pdeip_oflow_sor_elin4_dev(void *stream, float *U, float *V, const float *M, const float *Cu,
+                                         const float *Cv, const float *Du, const float *Dv, const float *wW,
+                                         const float *wN, const float *wE, const float *wS, int nrows,
+                                         int ncols, int iter, float omega, int mode, int col0)
+{
+    const char *who = "pdeip_oflow_sor_elin4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (iter <= 0) return PDEIP_OK;
+    SweepPlanes<ModelElin4> P{};
+    P.it_out[0] = U;
+    P.it_out[1] = V;
+    const float *cf[9] = {M, Cu, Cv, Du, Dv, wW, wN, wE, wS}; // Du,Dv: raw planes in the divisor slots
+    for (int f = 0; f < 9; f++) P.cf[f] = cf[f];
+    RC(run_sweeps<ModelElin4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_oflow_sor_llin4_dev(void *stream, const float *U, const float *V, float *dU, float *dV,
+                                         const float *M, const float *Cu, const float *Cv, const float *Du,
+                                         const float *Dv, const float *wW, const float *wN, const float *wE,
+                                         const float *wS, int nrows, int ncols, int iter, float omega,
+                                         int mode, int col0)
+{
+    const char *who = "pdeip_oflow_sor_llin4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (iter <= 0) return PDEIP_OK;
+    SweepPlanes<ModelLlin4> P{};
+    P.it_out[0] = dU;
+    P.it_out[1] = dV;
+    P.ro[0] = U;
+    P.ro[1] = V;
+    const float *cf[9] = {M, Cu, Cv, Du, Dv, wW, wN, wE, wS}; // Du,Dv: raw planes in the divisor slots
+    for (int f = 0; f < 9; f++) P.cf[f] = cf[f];
+    RC(run_sweeps<ModelLlin4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_disp_sor_llin4_dev(void *stream, const float *U, float *dU, const float *Cu,
+                                        const float *Du, const float *wW, const float *wN, const float *wE,
+                                        const float *wS, int nrows, int ncols, int iter, float omega,
+                                        int mode, int col0)
+{
+    const char *who = "pdeip_disp_sor_llin4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (iter <= 0) return PDEIP_OK;
+    SweepPlanes<ModelDisp4> P{};
+    P.it_out[0] = dU;
+    P.ro[0] = U;
+    const float *cf[6] = {Cu, Du, wW, wN, wE, wS}; // Cu,Du: raw planes in the dividend/divisor slots
+    for (int f = 0; f < 6; f++) P.cf[f] = cf[f];
+    RC(run_sweeps<ModelDisp4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
+    return PDEIP_OK;
+}
+
+// Disp_sor_llin_sym4_2d: two disparity fields that do not read each other (disparitySolvers.c:301-548).
+// solver 1: ModelDispSym4 on each; solver 2: the line solvers are the plain disparity ones (:503-540).
+extern "C" int pdeip_disp_sor_llin_sym4_dev(void *stream, const float *U0, float *dU0, const float *Cu0, const float *Du0,
+                                            const float *wW0, const float *wN0, const float *wE0, const float *wS0,
+                                            const float *U1, float *dU1, const float *Cu1, const float *Du1,
+                                            const float *wW1, const float *wN1, const float *wE1, const float *wS1,
+                                            int nrows, int ncols, int iter, float omega, int solver, int mode, int col0)
+{
+    const char *who = "pdeip_disp_sor_llin_sym4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    RC(check_solver(who, solver));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (iter <= 0) return PDEIP_OK;
+    const float *U[2] = {U0, U1}, *cf[2][6] = {{Cu0, Du0, wW0, wN0, wE0, wS0}, {Cu1, Du1, wW1, wN1, wE1, wS1}};
+    float *dU[2] = {dU0, dU1};
+    int launches = 0;
+    for (int k = 0; k < 2; k++) {
+        if (solver == PDEIP_SOLVER_ALR) {
+            RC(pdeip_disp_alr_llin4_dev(stream, U[k], dU[k], cf[k][0], cf[k][1], cf[k][2], cf[k][3], cf[k][4], cf[k][5], nrows, ncols, iter, omega, mode));
+        } else {
+            SweepPlanes<ModelDispSym4> P{};
+            P.it_out[0] = dU[k];
+            P.ro[0] = U[k];
+            for (int f = 0; f < 6; f++) P.cf[f] = cf[k][f];
+            RC(run_sweeps<ModelDispSym4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
+        }
+        launches += g.last_launches;
+    }
+    g.last_launches = launches;
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_pde_sor4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
+                                  const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                                  int nframes, int iter, float omega, int mode, int col0)
+{
+    const char *who = "pdeip_pde_sor4_dev";
+    RC(check_dims(who, nrows, ncols, nframes));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (iter <= 0) return PDEIP_OK;
+    SweepPlanes<ModelPde4> P{};
+    P.it_out[0] = X;
+    const float *cf[6] = {B, TRACE, wW, wN, wE, wS}; // B,TRACE: raw planes in the derived slots
+    for (int f = 0; f < 6; f++) P.cf[f] = cf[f];
+    RC(run_sweeps<ModelPde4>(s, P, nrows, ncols, nframes, iter, omega, mode, col0));
+    return PDEIP_OK;
+}
+

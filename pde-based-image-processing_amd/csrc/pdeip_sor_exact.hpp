@@ -738,7 +738,7 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
 
 // Final border replicate of the iterate (rows first, then columns; opticalflowSolvers.c:161-179):
 // border cell <- nearest interior pixel.  Reads interior cells only, writes border cells only.
-__global__ void k_fill_borders(float *p0, float *p1, int nfields, int nrows, int ncols,
+static __global__ void k_fill_borders(float *p0, float *p1, int nfields, int nrows, int ncols,
                                size_t frame_stride)
 {
     const int n = 2 * ncols + 2 * (nrows - 2);

@@ -44,6 +44,14 @@ def _p(*ts):
     return [t.data_ptr() for t in ts]
 
 
+def sync_check():
+    """Wait for the device and raise if a bounded dependency wait of the persistent exact-order kernel timed out since
+    the last check (the abort word is sticky: later calls cannot clear it).  The resident drivers call this wherever
+    they hand results back to the host."""
+    torch.cuda.synchronize()
+    capi.call("pdeip_persist_error")
+
+
 def oflow_sor_elin4(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER, col0=0):
     """In place on U, V (GS_SOR_elin4_2d, opticalflowSolvers.c:41)."""
     _chk(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS)

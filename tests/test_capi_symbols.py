@@ -43,3 +43,29 @@ def test_state_calls_without_gpu(pdeip):
         raise AssertionError("unknown mode accepted")
     except capi.PdeipError as exc:
         assert exc.code == capi.PDEIP_ERR_ARG and "ordering" in str(exc)
+
+
+def _child(code, env):
+    import subprocess
+    import sys
+
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr
+    return out.stdout.strip().splitlines()[-1]
+
+
+_READ_MODE = ("import importlib, sys; sys.path.insert(0, '.'); capi = importlib.import_module('pde-based-image-processing_amd').capi; "
+              "%s print(capi.get_mode(), capi.get_devices())")
+
+
+def test_environment_knobs_reach_the_library(pdeip):
+    """PDEIP_MODE / PDEIP_DEVICE(S): what an unchanged MATLAB session sets before starting."""
+    assert _child(_READ_MODE % "", {"PDEIP_MODE": "red_black"}).startswith("1 ")
+    assert _child(_READ_MODE % "", {"PDEIP_MODE": "exact"}).startswith("0 ")
+    assert _child(_READ_MODE % "", {}).startswith("0 ")  # default: the reference's order
+    # an explicit call made before the first use wins over the environment
+    assert _child(_READ_MODE % "capi.set_mode(0);", {"PDEIP_MODE": "red_black"}).startswith("0 ")
+    # device ids that do not exist are refused with a message and the default group stays
+    assert _child(_READ_MODE % "", {"PDEIP_DEVICES": "97,98"}).endswith("[0]")

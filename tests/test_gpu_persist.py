@@ -101,3 +101,44 @@ def test_launch_per_front_form(pdeip, oracle, persist_off, shape):
     assert pb.bit_equal(api.Disp_sor_llin4_2d(*d.values(), np.float32(6), np.float32(1.9), np.float32(1)), oracle.Disp_sor_llin4_2d(*d.values(), 6, 1.9))
     e = pb.pde4(844, *shape, nframes=2, nan_frac=0.02)
     assert pb.bit_equal(api.PDEsolver4(*e.values(), np.float32(5), np.float32(1.75), np.float32(1)), oracle.PDEsolver4(*e.values(), 5, 1.75))
+
+
+def test_release_then_same_shape_again(pdeip, oracle, persist_on):
+    """pdeip_release() frees the schedule table of the persistent kernel; the cached (B, iter) shape must go with it, or
+    the next call of the same shape reads an uninitialised table (round-1 advisor finding)."""
+    api = pdeip.mex_api
+    api.set_mode(0)
+    p = pb.elin4(831, 97, 260, nan_frac=0.01)
+    want = oracle.Oflow_sor_elin4_2d(*p.values(), 4, 1.9)
+    for _ in range(2):
+        got = api.Oflow_sor_elin4_2d(*p.values(), np.float32(4), np.float32(1.9), np.float32(1))
+        _ok(pdeip)
+        for g, w in zip(got, want):
+            assert pb.bit_equal(g, w), pb.describe_mismatch(g, w)
+        assert pdeip.capi.load().pdeip_release() == 0
+    # the device-pointer callers share the same per-device cache
+    dev = pdeip.device
+    d = {k: dev.to_device(v) for k, v in p.items()}
+    dev.oflow_sor_elin4(*d.values(), 4, 1.9, 0)
+    assert pdeip.capi.load().pdeip_release() == 0
+    d = {k: dev.to_device(v) for k, v in p.items()}
+    dev.oflow_sor_elin4(*d.values(), 4, 1.9, 0)
+    assert pb.bit_equal(dev.to_matlab(d["U"]), want[0]) and pb.bit_equal(dev.to_matlab(d["V"]), want[1])
+    _ok(pdeip)
+
+
+def test_set_device_keeps_working(pdeip, oracle):
+    """pdeip_set_device() to the same / an invalid device, then a solve (per-device caches, not process-wide statics)."""
+    api = pdeip.mex_api
+    api.set_mode(1)
+    capi = pdeip.capi
+    capi.call("pdeip_set_device", 0)
+    assert capi.get_devices() == [0]
+    with pytest.raises(capi.PdeipError):
+        capi.call("pdeip_set_device", 99)
+    p = pb.elin4(832, 64, 80)
+    got = api.Oflow_sor_elin4_2d(*p.values(), np.float32(4), np.float32(1.9), np.float32(1))
+    want = oracle.Oflow_sor_elin4_2d(*p.values(), 4, 1.9, order=oracle.COLOUR)
+    for g, w in zip(got, want):
+        assert pb.bit_equal(g, w)
+    api.set_mode(0)
