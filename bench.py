@@ -6,7 +6,8 @@ torch.distributed.run, one rank per GPU).  Prints ONE JSON line on rank 0.
 
 Workload (BASELINE.md row "M"/"C4"; BASELINE.json metric): the early-linearization (Horn-Schunck
 type) point solver `Oflow_sor_elin4_2d` / GS_SOR_elin4_2d on one 2160 x 3840 float32 frame
-(nrows=2160, ncols=3840), synthetic motion-tensor coefficients, weights U(0.5,5), omega 1.9.
+(nrows=2160, ncols=3840), synthetic motion-tensor coefficients, symmetric weights U(0.5,5) (wE of a
+pixel = wW of its east neighbour, as the drivers' diffusion weights are: a convergent problem), omega 1.9.
 One STEP = one solver call of iter=4 sweeps on buffers resident in HBM (what the FMG smoother
 issues per call, FlowEminNDFASFMG_elin_2D_v10.m:55-56,398-411), so value = 4*K / time.
 
@@ -17,9 +18,17 @@ issues per call, FlowEminNDFASFMG_elin_2D_v10.m:55-56,398-411), so value = 4*K /
                  library's default and the bit-parity mode, reported beside it.
   * roofline     algorithmic bytes (52 B/pixel/sweep: 11 planes read + 2 written) / average
                  sweep-kernel launch duration, measured with HIP events on the launch stream
-                 inside this run (pdeip_profile_*), vs 8 TB/s HBM3E peak.
+                 inside this run (pdeip_profile_*), vs 8 TB/s HBM3E peak; beside it frac_hbm =
+                 measured HBM traffic of the same launch (PMC, profiles/traffic.json) / time / peak
+                 and overfetch = traffic / the bytes a perfectly fused launch needs.
+  * parity_rb    how far the timed ordering is from the reference's result: RMS / max of RED_BLACK
+                 vs the CPU oracle's lexicographic result after the first iter=4 call, and the
+                 sweep count from which the two orderings agree to 1e-4 RMS on this frame.
+  * host_call    wall time of pdeip_oflow_sor_elin4 with HOST pointers (what a MEX stub calls):
+                 PCIe-inclusive, both orderings; never `value`.
   * cpu_baseline the CPU oracle (plain-C port of the reference loop, lexicographic order) on
-                 the same frame on ONE host core, a bounded number of calls.
+                 the same frame on ONE host core, a bounded number of calls; plus the oracle's
+                 red-black order on all host cores (OpenMP), the like-for-like comparator of value.
 """
 import argparse
 import ctypes
@@ -55,10 +64,16 @@ def make_planes(torch, device, nrows, ncols, seed=0):
     def u(lo, hi):
         return torch.empty((ncols, nrows), device=device, dtype=torch.float32).uniform_(lo, hi, generator=g)
 
-    # image-gradient sized data terms (|Ix|,|Iy| <= 0.5) against weights in [0.5, 5]: the relaxation
-    # converges at omega = 1.9, so the in-place iterate stays finite over any number of timed steps
+    # image-gradient sized data terms (|Ix|,|Iy| <= 0.5) against weights in [0.5, 5]
     a, b, c = u(-0.5, 0.5), u(-0.5, 0.5), u(-1.0, 1.0)
-    coef = [a * b, -a * c, -b * c, a * a, b * b] + [u(0.5, 5.0) for _ in range(4)]  # M,Cu,Cv,Du,Dv,wW,wN,wE,wS
+    wW, wN, wE, wS = [u(0.5, 5.0) for _ in range(4)]
+    # a symmetric operator, as OPdiffWeights / DdiffWeights produce: wE(i,j) = wW(i,j+1), wS(i,j) = wN(i+1,j)
+    # (tensor layout [ncols, nrows]: dim 0 = image column j, dim 1 = image row i).  With independently drawn
+    # weights SOR at omega = 1.9 diverges in either ordering; this problem converges (tests/test_oracle_math.py
+    # checks the same recipe on the CPU) and main() asserts the iterate is finite after the timed loop.
+    wE[:-1, :] = wW[1:, :]
+    wS[:, :-1] = wN[:, 1:]
+    coef = [a * b, -a * c, -b * c, a * a, b * b, wW, wN, wE, wS]  # M,Cu,Cv,Du,Dv,wW,wN,wE,wS
     U, V = u(-1.0, 1.0), u(-1.0, 1.0)
     return U, V, [t.contiguous() for t in coef]
 
@@ -80,6 +95,43 @@ def cpu_baseline(U, V, coef, calls):
             first = (hu.copy(), hv.copy())
     dt = time.perf_counter() - t0
     return calls * ITER / dt, first
+
+
+def cpu_red_black_all_cores(U, V, coef, calls):
+    """The oracle's red-black order on every host core (OpenMP): the like-for-like CPU comparator of `value`."""
+    import oracle_lib
+
+    lib = oracle_lib.lib()
+    hu, hv = U.cpu().numpy().copy(), V.cpu().numpy().copy()
+    hc = [t.cpu().numpy() for t in coef]
+    args = [hu.ctypes.data, hv.ctypes.data] + [a.ctypes.data for a in hc] + [NROWS, NCOLS, ITER, ctypes.c_float(OMEGA), 0]
+    used = lib.orc_oflow_sor_elin4_rb_omp(*args)  # warm-up: thread pool, page placement
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        used = lib.orc_oflow_sor_elin4_rb_omp(*args)
+    return calls * ITER / (time.perf_counter() - t0), int(used)
+
+
+def host_call(capi, U, V, coef, mode, reps=3):
+    """Median wall time of pdeip_oflow_sor_elin4 (host pointers in, host pointers out) for one iter=4 call at 4K."""
+    lib = capi.load()
+    hu, hv = U.cpu().numpy().copy(), V.cpu().numpy().copy()
+    hc = [t.cpu().numpy() for t in coef]
+    ou, ov = np.empty_like(hu), np.empty_like(hv)
+    old = capi.get_mode()
+    capi.set_mode(mode)
+    times = []
+    try:
+        for k in range(reps + 1):
+            t0 = time.perf_counter()
+            rc = lib.pdeip_oflow_sor_elin4(hu.ctypes.data, hv.ctypes.data, *[a.ctypes.data for a in hc], NROWS, NCOLS, 1, ITER,
+                                           ctypes.c_float(OMEGA), 1, ou.ctypes.data, ov.ctypes.data, None, None)
+            capi.check(rc)
+            if k:
+                times.append(time.perf_counter() - t0)
+    finally:
+        capi.set_mode(old)
+    return sorted(times)[len(times) // 2] * 1e3, ou, ov
 
 
 def main():
@@ -156,11 +208,25 @@ def main():
     coef = [dom.slice_local(t) for t in coef_full]
     solver = slab.SlabSolver(dom, "elin4", sweeps_per_exchange=k_ex)
 
-    def step_rb():
-        solver.solve([U, V], coef, ITER, OMEGA)
+    if world == 1:
+        # one GPU: every step relaxes the current iterate into the other of two plane sets (pdeip_oflow_sor_elin4_dev_to: what a
+        # gateway does -- input read, output written -- and no device-to-device copy of the iterate after the launch)
+        sets, cur = [(U, V), (torch.empty_like(U), torch.empty_like(V))], [0]
+
+        def step_rb():
+            a, b = sets[cur[0]], sets[1 - cur[0]]
+            dev.oflow_sor_elin4(a[0], a[1], *coef, ITER, OMEGA, capi.MODE_RED_BLACK, out=b)
+            cur[0] ^= 1
+    else:
+        def step_rb():
+            solver.solve([U, V], coef, ITER, OMEGA)
 
     dt, ms, nl = timed(step_rb, args.steps, args.warmup)
     value = args.steps * ITER / dt
+    if world == 1:
+        U, V = sets[cur[0]]
+    if not (bool(torch.isfinite(U).all()) and bool(torch.isfinite(V).all())):
+        raise SystemExit("bench.py: the iterate is not finite after the timed loop (the workload must converge)")
     # per launch: this rank's pixels (owned + halo columns are all relaxed by the launch; count owned only)
     own_px = (dom.c1 - dom.c0) * NROWS
     launch_s = ms * 1e-3 / max(nl, 1)
@@ -176,22 +242,30 @@ def main():
         "config": {"workload": "Oflow_sor_elin4_2d point SOR, 2160x3840 f32 frame, iter=4/call, omega=1.9, resident in HBM",
                    "ordering": "red_black", "decomposition": "column slabs, %d-column halo, 1 RCCL exchange per %d sweeps" % (2 * k_ex, k_ex)
                    if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": "k_sor_rb<ModelElin4, TWO=%s>" % ("true" if sweeps_per_launch > 1.5 else "false"),
+        "roofline": {"bound": "hbm", "kernel": "k_sor_rb<ModelElin4, sweeps per launch = %d>" % round(sweeps_per_launch),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "launch_us": round(launch_s * 1e6, 2), "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "sweeps_per_launch": round(sweeps_per_launch, 3)},
+                     "sweeps_per_launch": round(sweeps_per_launch, 3),
+                     "note": "achieved/frac = ALGORITHMIC bytes (52 B x pixels x sweeps in the launch) / launch time: an effective rate -- a "
+                             "launch that fuses k sweeps reads the nine coefficient planes once for all k, so it can exceed what HBM "
+                             "delivers; frac_hbm = measured traffic / time / peak is the HBM utilisation"},
     }
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if world == 1 and os.path.exists(tr):
         try:
-            key = "k_sor_rb2_elin4_2160x3840_bytes_per_launch" if sweeps_per_launch > 1.5 else "k_sor_rb_elin4_2160x3840_bytes_per_launch"
-            out["roofline"]["traffic"] = json.load(open(tr)).get(key)
-            if out["roofline"]["traffic"]:
-                # `achieved` is ALGORITHMIC bytes / time (each plane once per sweep); a launch that fuses two sweeps
-                # reads the coefficient planes once for both, so it can exceed what HBM delivers: the measured
-                # traffic of the same launch is what the memory system actually moved
-                out["roofline"]["hbm_gbs_from_traffic"] = round(out["roofline"]["traffic"] / launch_s / 1e9, 1)
+            table = json.load(open(tr))
+            k_fused = int(round(sweeps_per_launch))
+            key = "k_sor_rb%s_elin4_2160x3840_bytes_per_launch" % ("" if k_fused == 1 else k_fused)
+            traffic = table.get(key)
+            out["roofline"]["traffic"] = traffic
+            if traffic:
+                # what the memory system actually moved for this launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
+                fused_min = (9 + 2 + 2) * 4.0 * own_px   # a perfectly fused launch: every plane once, whatever the sweep count
+                out["roofline"]["hbm_gbs_from_traffic"] = round(traffic / launch_s / 1e9, 1)
+                out["roofline"]["frac_hbm"] = round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4)
+                out["roofline"]["overfetch"] = round(traffic / fused_min, 3)
+                out["roofline"]["traffic_source"] = table.get("source", "profiles/traffic.json")
         except (ValueError, OSError):
             pass
 
@@ -236,6 +310,49 @@ def main():
                                    "host_cpus": os.cpu_count()}
             out["parity"] = {"mode": "exact_order vs cpu oracle, first call", "rms_u": float(np.sqrt((du * du).mean())),
                              "rms_v": float(np.sqrt((dv * dv).mean())), "max_abs": float(max(np.abs(du).max(), np.abs(dv).max()))}
+            # the like-for-like CPU comparator of `value`: the same red-black order on every host core
+            omp_rate, omp_threads = cpu_red_black_all_cores(U0, V0, coef_full, max(3, args.cpu_calls))
+            out["cpu_baseline"]["red_black_all_cores"] = {"value": round(omp_rate, 2), "unit": "iterations/s", "cores": omp_threads,
+                                                          "kind": "port", "sample": "%d calls x iter=%d, oracle red-black order, OpenMP over "
+                                                          "the columns of a colour pass; not in the reference (its flow solvers are "
+                                                          "single-threaded)" % (max(3, args.cpu_calls), ITER)}
+            # ---- how far the timed ordering is from the reference's result ---------------------------------
+            Ur, Vr = U0.clone(), V0.clone()
+            dev.oflow_sor_elin4(Ur, Vr, *coef_full, ITER, OMEGA, capi.MODE_RED_BLACK)
+            torch.cuda.synchronize()
+            du = Ur.cpu().numpy().astype(np.float64) - first[0]
+            dv = Vr.cpu().numpy().astype(np.float64) - first[1]
+            prb = {"mode": "red_black (the timed ordering) vs cpu oracle in the reference's lexicographic order, after the first iter=%d call" % ITER,
+                   "rms_u": float(np.sqrt((du * du).mean())), "rms_v": float(np.sqrt((dv * dv).mean())),
+                   "max_abs": float(max(np.abs(du).max(), np.abs(dv).max()))}
+            # sweeps until the two orderings agree to 1e-4 RMS on this frame (exact order on the GPU is the oracle bit for bit)
+            Ux, Vx = U0.clone(), V0.clone()
+            Ur, Vr = U0.clone(), V0.clone()
+            done, trace = 0, {}
+            for target in (4, 8, 16, 32, 64, 128, 256, 512, 1024):
+                dev.oflow_sor_elin4(Ux, Vx, *coef_full, target - done, OMEGA, capi.MODE_EXACT_ORDER)
+                dev.oflow_sor_elin4(Ur, Vr, *coef_full, target - done, OMEGA, capi.MODE_RED_BLACK)
+                done = target
+                r = float(torch.sqrt(((Ux.double() - Ur.double()) ** 2).mean()).item())
+                trace[str(target)] = r
+                if r < 1e-4:
+                    break
+            prb["rms_u_by_sweeps"] = trace
+            prb["sweeps_to_1e-4_rms"] = done if trace[str(done)] < 1e-4 else None
+            capi.call("pdeip_persist_error")
+            out["parity_rb"] = prb
+            # ---- the host-pointer call a MEX stub makes: H2D of 13 planes, solve, D2H of 2 (PCIe-inclusive) -------
+            hc = {}
+            for name, mode in (("exact_order", capi.MODE_EXACT_ORDER), ("red_black", capi.MODE_RED_BLACK)):
+                ms_call, ou, ov = host_call(capi, U0, V0, coef_full, mode)
+                hc[name + "_ms"] = round(ms_call, 3)
+                hc[name + "_iterations_per_s"] = round(ITER / (ms_call * 1e-3), 1)
+                if mode == capi.MODE_EXACT_ORDER:
+                    hc["exact_order_max_abs_vs_cpu"] = float(max(np.abs(ou.astype(np.float64) - first[0]).max(), np.abs(ov.astype(np.float64) - first[1]).max()))
+            hc["bytes_over_pcie"] = (13 + 2) * 4 * N
+            hc["workload"] = "pdeip_oflow_sor_elin4, host pointers, 2160x3840, iter=4, median of 3 calls"
+            out["host_call"] = hc
+            del Ur, Vr, Ux, Vx
             # ---- solver 2 (alternating line relaxation, the MATLAB drivers' default), same frame ----------
             # one ALR iteration = column lines of U,V then row lines of V,U.  exact = reference line order
             # (bit-identical, serial by construction), zebra = even/odd lines concurrently.

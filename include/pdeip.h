@@ -232,6 +232,25 @@ int pdeip_disp_sor_llin_sym4_dev(void *stream, const float *U0, float *dU0, cons
 int pdeip_pde_sor4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
                        const float *wN, const float *wE, const float *wS, int nrows, int ncols,
                        int nframes, int iter, float omega, int mode, int col0);
+/* Out-of-place forms of the four 5-point point solvers: the iterate planes are only READ and the relaxed iterate is written to
+ * the `_out` planes (iter <= 0: a copy) -- the shape of the gateways themselves (copy the input in, solve on the output:
+ * Oflow_sor_elin4_2d.c:341-346).  The red-black launches ping-pong between buffers, so this form never needs the
+ * device-to-device copy that an in-place call with an odd number of launches ends with; `_out` == the inputs is the in-place
+ * call.  Callers that relax the same planes again and again alternate between two sets. */
+int pdeip_oflow_sor_elin4_dev_to(void *stream, const float *U, const float *V, float *U_out, float *V_out, const float *M,
+                                 const float *Cu, const float *Cv, const float *Du, const float *Dv, const float *wW,
+                                 const float *wN, const float *wE, const float *wS, int nrows, int ncols, int iter,
+                                 float omega, int mode, int col0);
+int pdeip_oflow_sor_llin4_dev_to(void *stream, const float *U, const float *V, const float *dU, const float *dV,
+                                 float *dU_out, float *dV_out, const float *M, const float *Cu, const float *Cv,
+                                 const float *Du, const float *Dv, const float *wW, const float *wN, const float *wE,
+                                 const float *wS, int nrows, int ncols, int iter, float omega, int mode, int col0);
+int pdeip_disp_sor_llin4_dev_to(void *stream, const float *U, const float *dU, float *dU_out, const float *Cu,
+                                const float *Du, const float *wW, const float *wN, const float *wE, const float *wS,
+                                int nrows, int ncols, int iter, float omega, int mode, int col0);
+int pdeip_pde_sor4_dev_to(void *stream, const float *X, float *X_out, const float *TRACE, const float *B, const float *wW,
+                          const float *wN, const float *wE, const float *wS, int nrows, int ncols, int nframes, int iter,
+                          float omega, int mode, int col0);
 int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
                        const float *wNW, const float *wN, const float *wNE, const float *wE,
                        const float *wSE, const float *wS, const float *wSW, int nrows, int ncols,

@@ -14,6 +14,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_ISNAN(x) ((x) != (x)) /* opticalflowSolvers.c:31-33 */
 
@@ -68,6 +71,54 @@ static void oflow_divisors(float *divU, float *divV, const float *Du, const floa
         }
 }
 
+/* One pixel of GS_SOR_elin4_2d (opticalflowSolvers.c:89-152), in place. */
+static inline void elin4_pixel(float *U, float *V, const float *M, const float *Cu, const float *Cv, const float *divU,
+                               const float *divV, const float *wW, const float *wN, const float *wE, const float *wS,
+                               size_t pos, int nrows, float omega)
+{
+    float nbU, nbV, t1, t2, t3, Unew, Vnew;
+    /* opticalflowSolvers.c:89-97 */
+    nbU = U[pos - nrows] * wW[pos];
+    t1 = U[pos + nrows] * wE[pos];
+    nbU += t1;
+    t2 = U[pos - 1] * wN[pos];
+    t3 = U[pos + 1] * wS[pos];
+    t2 += t3;
+    nbU += t2;
+    /* :100-108 */
+    nbV = V[pos - nrows] * wW[pos];
+    t1 = V[pos + nrows] * wE[pos];
+    nbV += t1;
+    t2 = V[pos - 1] * wN[pos];
+    t3 = V[pos + 1] * wS[pos];
+    t2 += t3;
+    nbV += t2;
+    /* :129-149 -- both new values use the pre-update U[pos], V[pos] */
+    if (ORC_ISNAN(Cu[pos])) {
+        Unew = nbU * divU[pos];
+    } else {
+        t1 = nbU + Cu[pos];
+        t2 = M[pos] * V[pos];
+        t1 = t1 - t2;
+        Unew = t1 * divU[pos];
+    }
+    if (ORC_ISNAN(Cv[pos])) {
+        Vnew = nbV * divV[pos];
+    } else {
+        t1 = nbV + Cv[pos];
+        t2 = M[pos] * U[pos];
+        t1 = t1 - t2;
+        Vnew = t1 * divV[pos];
+    }
+    /* :151-152 */
+    t1 = (1.0f - omega) * U[pos];
+    t2 = omega * Unew;
+    U[pos] = t1 + t2;
+    t1 = (1.0f - omega) * V[pos];
+    t2 = omega * Vnew;
+    V[pos] = t1 + t2;
+}
+
 void orc_oflow_sor_elin4(float *U, float *V, const float *M, const float *Cu, const float *Cv,
                          const float *Du, const float *Dv, const float *wW, const float *wN,
                          const float *wE, const float *wS, int nrows, int ncols, int iter,
@@ -84,54 +135,59 @@ void orc_oflow_sor_elin4(float *U, float *V, const float *M, const float *Cu, co
 
     for (it = 0; it < iter; it++) {
         FOR_INTERIOR(order, 2, ((i + j + ORC_CPAR(order)) & 1), {
-            size_t pos = (size_t)j * nrows + i;
-            float nbU, nbV, t1, t2, t3, Unew, Vnew;
-            /* opticalflowSolvers.c:89-97 */
-            nbU = U[pos - nrows] * wW[pos];
-            t1 = U[pos + nrows] * wE[pos];
-            nbU += t1;
-            t2 = U[pos - 1] * wN[pos];
-            t3 = U[pos + 1] * wS[pos];
-            t2 += t3;
-            nbU += t2;
-            /* :100-108 */
-            nbV = V[pos - nrows] * wW[pos];
-            t1 = V[pos + nrows] * wE[pos];
-            nbV += t1;
-            t2 = V[pos - 1] * wN[pos];
-            t3 = V[pos + 1] * wS[pos];
-            t2 += t3;
-            nbV += t2;
-            /* :129-149 -- both new values use the pre-update U[pos], V[pos] */
-            if (ORC_ISNAN(Cu[pos])) {
-                Unew = nbU * divU[pos];
-            } else {
-                t1 = nbU + Cu[pos];
-                t2 = M[pos] * V[pos];
-                t1 = t1 - t2;
-                Unew = t1 * divU[pos];
-            }
-            if (ORC_ISNAN(Cv[pos])) {
-                Vnew = nbV * divV[pos];
-            } else {
-                t1 = nbV + Cv[pos];
-                t2 = M[pos] * U[pos];
-                t1 = t1 - t2;
-                Vnew = t1 * divV[pos];
-            }
-            /* :151-152 */
-            t1 = (1.0f - omega) * U[pos];
-            t2 = omega * Unew;
-            U[pos] = t1 + t2;
-            t1 = (1.0f - omega) * V[pos];
-            t2 = omega * Vnew;
-            V[pos] = t1 + t2;
+            elin4_pixel(U, V, M, Cu, Cv, divU, divV, wW, wN, wE, wS, (size_t)j * nrows + i, nrows, omega);
         });
         fill_borders(U, nrows, ncols);
         fill_borders(V, nrows, ncols);
     }
     free(divU);
     free(divV);
+}
+
+/* The red-black ordering of orc_oflow_sor_elin4 (order = ORC_ORDER_COLOUR) on `nthreads` host threads: pixels of one
+ * colour do not read each other, so the columns of a colour pass are relaxed concurrently -- same arithmetic, same
+ * results bit for bit as the serial colour-ordered loop.  NOT in the reference (its flow solvers are single-threaded
+ * lexicographic loops; its only OpenMP code is the level-set library): it exists as the reported all-core CPU
+ * comparator of the GPU's red-black number (bench.py cpu_baseline.red_black_all_cores).
+ * Returns the number of threads actually used (0: built without OpenMP, ran serially). */
+int orc_oflow_sor_elin4_rb_omp(float *U, float *V, const float *M, const float *Cu, const float *Cv, const float *Du,
+                               const float *Dv, const float *wW, const float *wN, const float *wE, const float *wS,
+                               int nrows, int ncols, int iter, float omega, int nthreads)
+{
+    size_t n = (size_t)nrows * ncols;
+    float *divU, *divV;
+    int it, colour, used = 0;
+    if (iter <= 0) return 0;
+    divU = (float *)malloc(n * sizeof(float));
+    divV = (float *)malloc(n * sizeof(float));
+    if (!divU || !divV) { free(divU); free(divV); return -1; }
+    oflow_divisors(divU, divV, Du, Dv, wW, wN, wE, wS, nrows, ncols);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    for (it = 0; it < iter; it++) {
+        for (colour = 0; colour < 2; colour++) {
+            int j;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+            for (j = 1; j < ncols - 1; j++) {
+                int i;
+#ifdef _OPENMP
+                if (j == 1) used = omp_get_num_threads();
+#endif
+                for (i = 1 + ((1 + j + colour) & 1); i < nrows - 1; i += 2)
+                    elin4_pixel(U, V, M, Cu, Cv, divU, divV, wW, wN, wE, wS, (size_t)j * nrows + i, nrows, omega);
+            }
+        }
+        fill_borders(U, nrows, ncols);
+        fill_borders(V, nrows, ncols);
+    }
+    free(divU);
+    free(divV);
+    return used;
 }
 
 /* Neighbourhood term of the late-linearization solvers (opticalflowSolvers.c:563-580):

@@ -42,6 +42,12 @@ void orc_oflow_sor_elin4(float *U, float *V, const float *M, const float *Cu, co
                          const float *wE, const float *wS, int nrows, int ncols, int iter,
                          float omega, int order);
 
+/* The colour order of orc_oflow_sor_elin4 on `nthreads` host threads (OpenMP; <= 0: the runtime's default), bit-identical
+ * to it.  Not in the reference; the all-core CPU comparator of bench.py.  Returns the threads used. */
+int orc_oflow_sor_elin4_rb_omp(float *U, float *V, const float *M, const float *Cu, const float *Cv, const float *Du,
+                               const float *Dv, const float *wW, const float *wN, const float *wE, const float *wS,
+                               int nrows, int ncols, int iter, float omega, int nthreads);
+
 /* opticalflowSolvers.c:504-680 (GS_SOR_llin4_2d) == :1487-1667 (GS_SOR_llin8_2d); dU,dV in place. */
 void orc_oflow_sor_llin4(const float *U, const float *V, float *dU, float *dV, const float *M,
                          const float *Cu, const float *Cv, const float *Du, const float *Dv,

@@ -19,7 +19,7 @@ COMMON = ["pdeip_ctx.hpp", PUBLIC]
 # translation unit -> the headers it includes (besides COMMON)
 UNITS = {
     "pdeip_ctx.hip": [],
-    "pdeip_sor5.hip": ["pdeip_models.hpp", "pdeip_pointwise.hpp", "pdeip_sor_exact.hpp", "pdeip_sor_rb.hpp", "pdeip_sor_small.hpp"],
+    "pdeip_sor5.hip": ["pdeip_models.hpp", "pdeip_pointwise.hpp", "pdeip_sor_exact.hpp", "pdeip_sor_rb.hpp", "pdeip_sor_rbp.hpp"],
     "pdeip_sor9.hip": ["pdeip_models.hpp", "pdeip_pointwise.hpp", "pdeip_sor_pde8.hpp", "pdeip_sor_rb.hpp"],
     "pdeip_line.hip": ["pdeip_alr.hpp", "pdeip_models.hpp"],
     "pdeip_stages.hip": ["pdeip_models.hpp", "pdeip_pointwise.hpp", "pdeip_flow.hpp", "pdeip_fas.hpp", "pdeip_sym.hpp", "pdeip_pyr.hpp",
@@ -28,7 +28,7 @@ UNITS = {
     "pdeip_multi.hip": [],
 }
 # -ffp-contract=off is part of the parity contract (the reference is FMA-free C).
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
 def _mtime(path):

@@ -53,6 +53,10 @@ SIGNATURES = {
     "pdeip_snd_derivatives5": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     # device-pointer entry points (first argument: hipStream_t)
     "pdeip_oflow_sor_elin4_dev": _sig(1 + 11, [_I, _I, _I, _F, _I, _I]),
+    "pdeip_oflow_sor_elin4_dev_to": _sig(1 + 13, [_I, _I, _I, _F, _I, _I]),
+    "pdeip_oflow_sor_llin4_dev_to": _sig(1 + 15, [_I, _I, _I, _F, _I, _I]),
+    "pdeip_disp_sor_llin4_dev_to": _sig(1 + 9, [_I, _I, _I, _F, _I, _I]),
+    "pdeip_pde_sor4_dev_to": _sig(1 + 8, [_I, _I, _I, _I, _F, _I, _I]),
     "pdeip_oflow_sor_llin4_dev": _sig(1 + 13, [_I, _I, _I, _F, _I, _I]),
     "pdeip_disp_sor_llin4_dev": _sig(1 + 8, [_I, _I, _I, _F, _I, _I]),
     "pdeip_disp_sor_llin_sym4_dev": _sig(1 + 16, [_I, _I, _I, _F, _I, _I, _I]),

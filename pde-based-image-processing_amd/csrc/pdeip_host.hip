@@ -84,9 +84,11 @@ static int oflow_sor_host(const char *who, bool llin, bool fill_residuals, const
     RC(upload(dM, M, nf)); RC(upload(dCu, Cu, nf)); RC(upload(dCv, Cv, nf)); RC(upload(dDu, Du, nf)); RC(upload(dDv, Dv, nf));
     RC(upload(dwW, wW, n)); RC(upload(dwN, wN, n)); RC(upload(dwE, wE, n)); RC(upload(dwS, wS, n));
 
-    if (iter > 0) { // copy the iterate in, relax it in place (Oflow_sor_elin4_2d.c:341-346)
-        HIPCHK(hipMemcpyAsync(do0, llin ? ddU : dUin, n * sizeof(float), hipMemcpyDeviceToDevice, 0));
-        HIPCHK(hipMemcpyAsync(do1, llin ? ddV : dVin, n * sizeof(float), hipMemcpyDeviceToDevice, 0));
+    if (iter > 0) { // copy the iterate in, relax it in place (Oflow_sor_elin4_2d.c:341-346); the point solvers relax input -> output
+        if (solver == PDEIP_SOLVER_ALR) {
+            HIPCHK(hipMemcpyAsync(do0, llin ? ddU : dUin, n * sizeof(float), hipMemcpyDeviceToDevice, 0));
+            HIPCHK(hipMemcpyAsync(do1, llin ? ddV : dVin, n * sizeof(float), hipMemcpyDeviceToDevice, 0));
+        }
         if (solver == PDEIP_SOLVER_ALR && diag)
             RC(pdeip_oflow_alr_llin8_dev(nullptr, dUin, dVin, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, ddiag[0], dwN, ddiag[1], dwE, ddiag[2], dwS, ddiag[3], nrows, ncols, iter, omega, g.mode));
         else if (solver == PDEIP_SOLVER_ALR && llin)
@@ -94,9 +96,9 @@ static int oflow_sor_host(const char *who, bool llin, bool fill_residuals, const
         else if (solver == PDEIP_SOLVER_ALR)
             RC(pdeip_oflow_alr_elin4_dev(nullptr, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode));
         else if (llin)
-            RC(pdeip_oflow_sor_llin4_dev(nullptr, dUin, dVin, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
+            RC(pdeip_oflow_sor_llin4_dev_to(nullptr, dUin, dVin, ddU, ddV, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
         else
-            RC(pdeip_oflow_sor_elin4_dev(nullptr, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
+            RC(pdeip_oflow_sor_elin4_dev_to(nullptr, dUin, dVin, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, dwN, dwE, dwS, nrows, ncols, iter, omega, g.mode, 0));
         RC(download(o0, do0, n));
         RC(download(o1, do1, n));
         RC(pdeip_persist_error());

@@ -8,6 +8,7 @@
 #include "pdeip_pointwise.hpp"
 #include "pdeip_sor_exact.hpp"
 #include "pdeip_sor_rb.hpp"
+#include "pdeip_sor_rbp.hpp"
 
 using namespace pdeip;
 
@@ -38,6 +39,39 @@ int pick_rb2_tj(int nrows, int ncols, int nframes, int ntiles_r)
     return best;
 }
 
+// Strip width of the pipelined kernel (pdeip_sor_rbp.hpp): one workgroup per CU, a launch takes
+// ceil(units / resident workgroups) rounds of nsteps(TJ) = TJ + 5S - 1 steps.
+template <class Mdl, int S>
+int pick_rbp_tj(int ncols, int nframes, int ntiles_r, const void *kernel)
+{
+    using L = RbpLayout<Mdl, S>;
+    const int forced = env_int("PDEIP_RBP_TJ", 0);
+    if (forced > 0) return forced < 2 ? 2 : forced;
+    DeviceState *d = cur_dev();
+    int slots;
+    auto it = d->resident_waves.find(kernel);
+    if (it != d->resident_waves.end()) slots = it->second;
+    else {
+        int blocks = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, L::THREADS, L::LDS_BYTES) != hipSuccess) blocks = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        slots = (blocks > 0 ? blocks : 1) * prop.multiProcessorCount;
+        d->resident_waves[kernel] = slots;
+    }
+    int best = 64;
+    long best_cost = -1;
+    for (int tj = 8; tj <= 1024; tj++) {
+        const long units = (long)ntiles_r * ((ncols + tj - 1) / tj) * nframes;
+        const long cost = ((units + slots - 1) / slots) * L::nsteps(tj);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = tj;
+        }
+    }
+    return best;
+}
+
 // ------------------------------------------------------------------------------------------------
 // sweep drivers (5-point models)
 // ------------------------------------------------------------------------------------------------
@@ -45,14 +79,35 @@ int pick_rb2_tj(int nrows, int ncols, int nframes, int ntiles_r)
 // Runs `iter` sweeps of model Mdl on the iterate buffers P.it_out (in place from the caller's
 // point of view).  P.ro and P.cf must be set, with the RAW planes in the two derived slots
 // (Mdl::D0, Mdl::D1); the derived planes (divisors) are built into workspace here.
+//
+// `dst` (optional): NIT buffers that receive the result while the caller's iterate in P.it_out is only READ -- what a
+// gateway does anyway (copy in, solve on the output: Oflow_sor_elin4_2d.c:341-346).  The red-black launches ping-pong
+// between buffers, so with a separate destination the chain input -> (scratch | dst) ... -> dst needs no copy at all; in
+// place, an odd number of launches ends in the scratch copy and costs one device-to-device copy of the iterate.
 template <class Mdl>
 int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nframes, int iter,
-               float omega, int mode, int col0)
+               float omega, int mode, int col0, float *const *dst = nullptr)
 {
     constexpr int NIT = Mdl::NIT;
     const size_t n = (size_t)nrows * ncols;
     g.last_launches = 0;
-    if (iter <= 0) return PDEIP_OK;
+    if (dst != nullptr) {
+        bool same = true;
+        for (int f = 0; f < NIT; f++) same = same && dst[f] == P.it_out[f];
+        if (same) dst = nullptr;
+    }
+    if (iter <= 0) {
+        if (dst != nullptr)
+            for (int f = 0; f < NIT; f++) HIPCHK(hipMemcpyAsync(dst[f], P.it_out[f], n * nframes * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return PDEIP_OK;
+    }
+    if (dst != nullptr && mode == PDEIP_MODE_EXACT_ORDER) { // the wavefront kernels relax in place: on the destination
+        for (int f = 0; f < NIT; f++) {
+            HIPCHK(hipMemcpyAsync(dst[f], P.it_out[f], n * nframes * sizeof(float), hipMemcpyDeviceToDevice, s));
+            P.it_out[f] = dst[f];
+        }
+        dst = nullptr;
+    }
     float *aux0 = nullptr, *aux1 = nullptr;
     RC(ws_get(WS_AUX0, n * nframes * sizeof(float), &aux0));
     RC(ws_get(WS_AUX1, n * nframes * sizeof(float), &aux1));
@@ -135,12 +190,13 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     float *scratch = nullptr;
     int rc = ws_get(WS_PING, (size_t)NIT * n * nframes * sizeof(float), &scratch);
     if (rc) return rc;
-    float *bufA[NIT], *bufB[NIT];
+    float *bufA[NIT], *bufB[NIT], *bufD[NIT];
     bool vec = (nrows % 4 == 0);
     for (int f = 0; f < NIT; f++) {
         bufA[f] = P.it_out[f];
         bufB[f] = scratch + (size_t)f * n * nframes;
-        vec = vec && aligned16(bufA[f]) && aligned16(bufB[f]);
+        bufD[f] = dst ? dst[f] : nullptr;
+        vec = vec && aligned16(bufA[f]) && aligned16(bufB[f]) && (!dst || aligned16(bufD[f]));
     }
     for (int f = 0; f < Mdl::NCF; f++) vec = vec && aligned16(P.cf[f]);
     vec = vec && aligned16(aux0) && aligned16(aux1);
@@ -153,16 +209,62 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     static const bool fuse_enabled = env_int("PDEIP_RB_FUSE", 1) != 0;
     const bool fuse = fuse_enabled;
     const int TJ1 = pick_rb_tj(nrows, ncols), TJ2 = fuse ? pick_rb2_tj<Mdl>(nrows, ncols, nframes, ntiles_r) : TJ1;
+    // Four sweeps per launch where the rings fit in LDS (pdeip_sor_rbp.hpp): the wave pipeline.  PDEIP_RB_PIPE=0 disables it.
+    constexpr int PS = 4;
+    static const bool pipe_enabled = env_int("PDEIP_RB_PIPE", 1) != 0;
+    // single-field models run one wave per sweep (one wave per SIMD): the pipeline only pays on large frames there
+    const bool pipe = pipe_enabled && fuse && vec && RbpLayout<Mdl, PS>::FITS && (RbpLayout<Mdl, PS>::NW == 2 || n >= (size_t)1 << 21);
+    // launches of this call (the buffer chain below needs the count up front)
+    int total_launches = 0;
+    for (int it = 0; it < iter;) {
+        const int k = (pipe && it + PS <= iter) ? PS : ((fuse && it + 2 <= iter) ? 2 : 1);
+        it += k;
+        total_launches++;
+    }
+    // launch number `flips` (0-based) reads src(flips) and writes out(flips).  In place: caller <-> scratch.  With a
+    // destination: the caller's buffers are only read by launch 0, and the outputs alternate so that the last one is dst.
+    auto buf_out = [&](int launch, int f) -> float * {
+        if (dst) return ((total_launches - 1 - launch) & 1) ? bufB[f] : bufD[f];
+        return (launch & 1) ? bufA[f] : bufB[f];
+    };
+    auto buf_in = [&](int launch, int f) -> const float * { return launch == 0 ? bufA[f] : buf_out(launch - 1, f); };
     SweepTimer timer(s);
     int nlaunch = 0, flips = 0; // flips: how many times the iterate changed buffers
     for (int it = 0; it < iter;) {
+        if (pipe && it + PS <= iter) {
+            using PL = RbpLayout<Mdl, PS>;
+            const bool first = it == 0;
+            const void *kfn = first ? reinterpret_cast<const void *>(&k_sor_rbp<Mdl, PS, true>) : reinterpret_cast<const void *>(&k_sor_rbp<Mdl, PS, false>);
+            RC(ensure_lds(kfn, PL::LDS_BYTES));
+            const int ntiles_p = (nrows + RBP_OWN_ROWS - 1) / RBP_OWN_ROWS;
+            const int TJP = pick_rbp_tj<Mdl, PS>(ncols, nframes, ntiles_p, kfn);
+            const int nunits = ntiles_p * ((ncols + TJP - 1) / TJP);
+            for (int f = 0; f < NIT; f++) {
+                P.it_in[f] = buf_in(flips, f);
+                P.it_out[f] = buf_out(flips, f);
+            }
+            // the derived planes leave the kernel only if a later launch of this call reads them
+            const bool keep = first && it + PS < iter;
+            const dim3 pgrid((unsigned)nunits, (unsigned)nframes), pblock(PL::THREADS);
+            if (first) hipLaunchKernelGGL((k_sor_rbp<Mdl, PS, true>), pgrid, pblock, PL::LDS_BYTES, s, P, keep ? aux0 : nullptr, keep ? aux1 : nullptr, nrows, ncols, TJP, ntiles_p, nunits, omega, col0, n);
+            else hipLaunchKernelGGL((k_sor_rbp<Mdl, PS, false>), pgrid, pblock, PL::LDS_BYTES, s, P, nullptr, nullptr, nrows, ncols, TJP, ntiles_p, nunits, omega, col0, n);
+            if (first) {
+                P.cf[Mdl::D0] = aux0;
+                P.cf[Mdl::D1] = aux1;
+            }
+            it += PS;
+            flips++;
+            nlaunch++;
+            g.last_launches++;
+            continue;
+        }
         const bool two = fuse && it + 2 <= iter;
         const int TJ = two ? TJ2 : TJ1;
         const int nunits = ntiles_r * ((ncols + TJ - 1) / TJ);
         const dim3 grid((unsigned)((nunits + RB_WAVES_PER_BLOCK - 1) / RB_WAVES_PER_BLOCK), (unsigned)nframes);
         for (int f = 0; f < NIT; f++) {
-            P.it_in[f] = (flips & 1) ? bufB[f] : bufA[f];
-            P.it_out[f] = (flips & 1) ? bufA[f] : bufB[f];
+            P.it_in[f] = buf_in(flips, f);
+            P.it_out[f] = buf_out(flips, f);
         }
         const bool first = it == 0; // sweep 0 also builds the divisor planes
         float *d0 = first ? aux0 : nullptr, *d1 = first ? aux1 : nullptr;
@@ -185,7 +287,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         g.last_launches++;
     }
     timer.stop(nlaunch);
-    if (flips & 1) // the last launch wrote the scratch copy
+    if (!dst && (flips & 1)) // in place and the last launch wrote the scratch copy
         for (int f = 0; f < NIT; f++)
             HIPCHK(hipMemcpyAsync(bufA[f], bufB[f], n * nframes * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());
@@ -206,64 +308,87 @@ extern "C" int pdeip_debug_read_stamps(unsigned long long *out)
 // ------------------------------------------------------------------------------------------------
 // device-pointer entry points
 // ------------------------------------------------------------------------------------------------
-extern "C" int pdeip_oflow_sor_elin4_dev(void *stream, float *U, float *V, const float *M, const float *Cu,
-                                         const float *Cv, const float *Du, const float *Dv, const float *wW,
-                                         const float *wN, const float *wE, const float *wS, int nrows,
-                                         int ncols, int iter, float omega, int mode, int col0)
+// Every 5-point solver has two device entry points: `_dev` relaxes the iterate in place, `_dev_to` reads the iterate and writes
+// the relaxed one to separate planes (iter <= 0: a copy) -- the gateway's own shape (copy in, solve on the output) and, for the
+// red-black launches, the one that needs no device-to-device copy of the iterate (run_sweeps).
+extern "C" int pdeip_oflow_sor_elin4_dev_to(void *stream, const float *U, const float *V, float *U_out, float *V_out, const float *M,
+                                            const float *Cu, const float *Cv, const float *Du, const float *Dv, const float *wW,
+                                            const float *wN, const float *wE, const float *wS, int nrows, int ncols, int iter,
+                                            float omega, int mode, int col0)
 {
     const char *who = "pdeip_oflow_sor_elin4_dev";
     RC(check_dims(who, nrows, ncols, 1));
     RC(check_mode(who, mode));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (iter <= 0) return PDEIP_OK;
     SweepPlanes<ModelElin4> P{};
-    P.it_out[0] = U;
-    P.it_out[1] = V;
+    P.it_out[0] = const_cast<float *>(U);
+    P.it_out[1] = const_cast<float *>(V);
     const float *cf[9] = {M, Cu, Cv, Du, Dv, wW, wN, wE, wS}; // Du,Dv: raw planes in the divisor slots
     for (int f = 0; f < 9; f++) P.cf[f] = cf[f];
-    RC(run_sweeps<ModelElin4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
+    float *const dst[2] = {U_out, V_out};
+    RC(run_sweeps<ModelElin4>(s, P, nrows, ncols, 1, iter, omega, mode, col0, dst));
     return PDEIP_OK;
 }
+extern "C" int pdeip_oflow_sor_elin4_dev(void *stream, float *U, float *V, const float *M, const float *Cu,
+                                         const float *Cv, const float *Du, const float *Dv, const float *wW,
+                                         const float *wN, const float *wE, const float *wS, int nrows,
+                                         int ncols, int iter, float omega, int mode, int col0)
+{
+    return pdeip_oflow_sor_elin4_dev_to(stream, U, V, U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, nrows, ncols, iter, omega, mode, col0);
+}
 
+extern "C" int pdeip_oflow_sor_llin4_dev_to(void *stream, const float *U, const float *V, const float *dU, const float *dV,
+                                            float *dU_out, float *dV_out, const float *M, const float *Cu, const float *Cv,
+                                            const float *Du, const float *Dv, const float *wW, const float *wN, const float *wE,
+                                            const float *wS, int nrows, int ncols, int iter, float omega, int mode, int col0)
+{
+    const char *who = "pdeip_oflow_sor_llin4_dev";
+    RC(check_dims(who, nrows, ncols, 1));
+    RC(check_mode(who, mode));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SweepPlanes<ModelLlin4> P{};
+    P.it_out[0] = const_cast<float *>(dU);
+    P.it_out[1] = const_cast<float *>(dV);
+    P.ro[0] = U;
+    P.ro[1] = V;
+    const float *cf[9] = {M, Cu, Cv, Du, Dv, wW, wN, wE, wS}; // Du,Dv: raw planes in the divisor slots
+    for (int f = 0; f < 9; f++) P.cf[f] = cf[f];
+    float *const dst[2] = {dU_out, dV_out};
+    RC(run_sweeps<ModelLlin4>(s, P, nrows, ncols, 1, iter, omega, mode, col0, dst));
+    return PDEIP_OK;
+}
 extern "C" int pdeip_oflow_sor_llin4_dev(void *stream, const float *U, const float *V, float *dU, float *dV,
                                          const float *M, const float *Cu, const float *Cv, const float *Du,
                                          const float *Dv, const float *wW, const float *wN, const float *wE,
                                          const float *wS, int nrows, int ncols, int iter, float omega,
                                          int mode, int col0)
 {
-    const char *who = "pdeip_oflow_sor_llin4_dev";
-    RC(check_dims(who, nrows, ncols, 1));
-    RC(check_mode(who, mode));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (iter <= 0) return PDEIP_OK;
-    SweepPlanes<ModelLlin4> P{};
-    P.it_out[0] = dU;
-    P.it_out[1] = dV;
-    P.ro[0] = U;
-    P.ro[1] = V;
-    const float *cf[9] = {M, Cu, Cv, Du, Dv, wW, wN, wE, wS}; // Du,Dv: raw planes in the divisor slots
-    for (int f = 0; f < 9; f++) P.cf[f] = cf[f];
-    RC(run_sweeps<ModelLlin4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
-    return PDEIP_OK;
+    return pdeip_oflow_sor_llin4_dev_to(stream, U, V, dU, dV, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, nrows, ncols, iter, omega, mode, col0);
 }
 
-extern "C" int pdeip_disp_sor_llin4_dev(void *stream, const float *U, float *dU, const float *Cu,
-                                        const float *Du, const float *wW, const float *wN, const float *wE,
-                                        const float *wS, int nrows, int ncols, int iter, float omega,
-                                        int mode, int col0)
+extern "C" int pdeip_disp_sor_llin4_dev_to(void *stream, const float *U, const float *dU, float *dU_out, const float *Cu,
+                                           const float *Du, const float *wW, const float *wN, const float *wE, const float *wS,
+                                           int nrows, int ncols, int iter, float omega, int mode, int col0)
 {
     const char *who = "pdeip_disp_sor_llin4_dev";
     RC(check_dims(who, nrows, ncols, 1));
     RC(check_mode(who, mode));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (iter <= 0) return PDEIP_OK;
     SweepPlanes<ModelDisp4> P{};
-    P.it_out[0] = dU;
+    P.it_out[0] = const_cast<float *>(dU);
     P.ro[0] = U;
     const float *cf[6] = {Cu, Du, wW, wN, wE, wS}; // Cu,Du: raw planes in the dividend/divisor slots
     for (int f = 0; f < 6; f++) P.cf[f] = cf[f];
-    RC(run_sweeps<ModelDisp4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
+    float *const dst[1] = {dU_out};
+    RC(run_sweeps<ModelDisp4>(s, P, nrows, ncols, 1, iter, omega, mode, col0, dst));
     return PDEIP_OK;
+}
+extern "C" int pdeip_disp_sor_llin4_dev(void *stream, const float *U, float *dU, const float *Cu,
+                                        const float *Du, const float *wW, const float *wN, const float *wE,
+                                        const float *wS, int nrows, int ncols, int iter, float omega,
+                                        int mode, int col0)
+{
+    return pdeip_disp_sor_llin4_dev_to(stream, U, dU, dU, Cu, Du, wW, wN, wE, wS, nrows, ncols, iter, omega, mode, col0);
 }
 
 // Disp_sor_llin_sym4_2d: two disparity fields that do not read each other (disparitySolvers.c:301-548).
@@ -299,20 +424,26 @@ extern "C" int pdeip_disp_sor_llin_sym4_dev(void *stream, const float *U0, float
     return PDEIP_OK;
 }
 
-extern "C" int pdeip_pde_sor4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
-                                  const float *wN, const float *wE, const float *wS, int nrows, int ncols,
-                                  int nframes, int iter, float omega, int mode, int col0)
+extern "C" int pdeip_pde_sor4_dev_to(void *stream, const float *X, float *X_out, const float *TRACE, const float *B, const float *wW,
+                                     const float *wN, const float *wE, const float *wS, int nrows, int ncols, int nframes, int iter,
+                                     float omega, int mode, int col0)
 {
     const char *who = "pdeip_pde_sor4_dev";
     RC(check_dims(who, nrows, ncols, nframes));
     RC(check_mode(who, mode));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (iter <= 0) return PDEIP_OK;
     SweepPlanes<ModelPde4> P{};
-    P.it_out[0] = X;
+    P.it_out[0] = const_cast<float *>(X);
     const float *cf[6] = {B, TRACE, wW, wN, wE, wS}; // B,TRACE: raw planes in the derived slots
     for (int f = 0; f < 6; f++) P.cf[f] = cf[f];
-    RC(run_sweeps<ModelPde4>(s, P, nrows, ncols, nframes, iter, omega, mode, col0));
+    float *const dst[1] = {X_out};
+    RC(run_sweeps<ModelPde4>(s, P, nrows, ncols, nframes, iter, omega, mode, col0, dst));
     return PDEIP_OK;
+}
+extern "C" int pdeip_pde_sor4_dev(void *stream, float *X, const float *TRACE, const float *B, const float *wW,
+                                  const float *wN, const float *wE, const float *wS, int nrows, int ncols,
+                                  int nframes, int iter, float omega, int mode, int col0)
+{
+    return pdeip_pde_sor4_dev_to(stream, X, X, TRACE, B, wW, wN, wE, wS, nrows, ncols, nframes, iter, omega, mode, col0);
 }
 

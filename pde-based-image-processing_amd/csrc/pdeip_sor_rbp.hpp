@@ -1,0 +1,400 @@
+// pdeip_sor_rbp.hpp -- S red-black sweeps per launch as a wave pipeline through LDS (gfx950).
+//
+// Why.  One red-black sweep moves every plane through HBM once (52 B per pixel for the Horn-Schunck model);
+// k_sor_rb<TWO> fuses two sweeps in the registers of one wave and is then bound by its own instruction
+// stream at one wave per SIMD (359 VGPRs), and a third and fourth sweep do not fit a register file.  The
+// solver calls of every driver run iter = 4 sweeps, which share all coefficient planes: read once, a call
+// needs 13 planes of traffic instead of 4 x 13.
+//
+// How.  A workgroup owns a unit of 240 rows x TJ columns and marches along the columns like k_sor_rb, but
+// the S sweeps are S WAVES, one per SIMD, each a plain single-sweep march (red on column x, black on x-1):
+//
+//     loader wave  --LDS-DMA-->  K ring  (coefficient / read-only columns, read by every sweep wave)
+//                  --LDS-DMA-->  O ring  (old iterate columns)  -> wave 0 (sweep 1) -> H ring 0 -> wave 1 -> ... -> wave S-1 -> HBM
+//
+// Wave s trails wave s-1 by three columns: in step t it reads the column its predecessor finished in step
+// t-1, so one workgroup barrier per step is the only synchronisation.  The loader wave issues
+// global_load_lds_dwordx4 (no registers, 1 KiB per instruction: a column of 256 rows is contiguous in the
+// MATLAB layout) P steps ahead and retires them with a counted s_waitcnt vmcnt; nothing else in the kernel
+// reads global memory.  Each sweep wave keeps three-column windows in registers as k_sor_rb does.
+//
+// Exactness.  Per pixel this is Mdl::update() through rb_phase() like every other ordering; the border
+// replicate the reference does between sweeps (rows, then columns: opticalflowSolvers.c:161-179) is reproduced
+// as in rb_march2: rows in the finished column before it is handed on, "column 0 = column 1" substituted where
+// the next sweep reads it.  Bit-identical to S launches of k_sor_rb (tests/test_gpu_parity.py runs through it).
+//
+// Halo.  A half-sweep invalidates one halo row and one halo column per side: 2S columns per side are loaded
+// and 8 rows (two lanes) per side are recomputed, so a wave owns 240 rows; redundancy (TJ + 4S)/TJ x 256/240.
+#pragma once
+#include "pdeip_sor_rb.hpp"
+
+namespace pdeip {
+
+constexpr int RBP_OWN_ROWS = 240; // 60 storing lanes x 4 rows; lanes 0,1 and 62,63 are halo lanes (8 half-sweeps)
+
+template <class Mdl, int S> struct RbpLayout {
+    static constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NCF = Mdl::NCF;
+    static constexpr int NRING = NCF + NRO;            // planes every sweep wave reads: coefficients, then read-only fields
+    static constexpr int P = 3;                        // DMA lead in steps
+    // K-ring columns.  Column group g lands before step g; its last reader is wave S-1 taking it as "column x-1" in step
+    // g + 3(S-1) + 2; its slot is refilled by group g + NK, issued in step g + NK - P: one barrier later at the earliest.
+    static constexpr int NK = P + 3 * (S - 1) + 3;
+    static constexpr int NO = P + 1;                   // O-ring columns
+    static constexpr int COL = 256;                    // floats per plane column (64 lanes x 4 rows)
+    static constexpr int K_FLOATS = NK * NRING * COL;
+    static constexpr int O_FLOATS = NO * NIT * COL;
+    static constexpr int H_FLOATS = (S - 1) * 2 * NIT * COL;
+    static constexpr size_t LDS_BYTES = (size_t)(K_FLOATS + O_FLOATS + H_FLOATS) * sizeof(float);
+    static constexpr int GROUP = NRING + NIT;          // LDS-DMA instructions per column
+    static constexpr int NW = (NIT == 2) ? 2 : 1;      // waves per sweep: the two fields of a coupled model are relaxed by two waves
+    static constexpr int THREADS = 64 * (S * NW + 1);  // sweep waves + the loader wave
+    static constexpr int HALO = 2 * S;                 // columns per side
+    static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && (P - 1) * GROUP <= 63;
+    // wave S-1 finishes column j1-1 in step TJ + 5S - 2 (two warm-up steps, 2S halo columns, three columns of lag per sweep)
+    __host__ __device__ static constexpr int nsteps(int tj) { return tj + 5 * S - 1; }
+};
+
+// one column of one plane: 64 lanes x 16 bytes, contiguous
+__device__ __forceinline__ void rbp_lds_read(float (&d)[4], const float *col, int lane)
+{
+    const float4 t = *reinterpret_cast<const float4 *>(col + 4 * lane);
+    d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+}
+__device__ __forceinline__ void rbp_lds_write(float *col, int lane, const float (&d)[4])
+{
+    *reinterpret_cast<float4 *>(col + 4 * lane) = make_float4(d[0], d[1], d[2], d[3]);
+}
+
+// address-space casts for __builtin_amdgcn_global_load_lds (global source per lane, LDS destination = wave-uniform base + 16 x lane)
+#define RBP_LDS(p) ((__attribute__((address_space(3))) void *)(p))
+#define RBP_GLB(p) ((const __attribute__((address_space(1))) void *)(p))
+
+// LDS traffic only: the loader's DMA stays in flight across it (a __syncthreads() would drain vmcnt)
+__device__ __forceinline__ void rbp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One colour of one column, branch-free, for the fields [F0, F0+NF) of the model: OUT <- CEN with elements {E0, E0+2}
+// relaxed where the row is an interior pixel (ok[], fixed per lane for the whole march).  XC holds the centre values of ALL
+// fields (the coupled models update u from the old v of the same pixel and vice versa); neighbours are needed of the own
+// fields only.  The arithmetic is Mdl::update(), as in every other ordering; what the other fields' half of it would
+// produce is unused here and drops out at compile time.  OUT and CEN are distinct register sets, so the window the result
+// goes into never has to be copied first.
+template <class Mdl, int F0, int NF, int E0>
+__device__ __forceinline__ void rbp_phase(float (&OUT)[NF][4], const float (&C)[NF][4], const float (&W)[NF][4], const float (&E)[NF][4],
+                                          const float (&XC)[Mdl::NIT][4], const float (&rC)[at_least_one<Mdl::NRO>::value][4],
+                                          const float (&rW)[at_least_one<Mdl::NRO>::value][4],
+                                          const float (&rE)[at_least_one<Mdl::NRO>::value][4], const float (&cf)[Mdl::NCF][4],
+                                          const bool (&ok)[4], float omega, float om1)
+{
+    constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NRO1 = at_least_one<NRO>::value;
+    float edge[NF], redge[NRO1]; // the neighbouring lane's adjacent row
+#pragma unroll
+    for (int f = 0; f < NF; f++) edge[f] = (E0 == 0) ? lane_above(C[f][3]) : lane_below(C[f][0]);
+#pragma unroll
+    for (int f = 0; f < NRO1; f++) redge[f] = (NRO == 0) ? 0.0f : ((E0 == 0) ? lane_above(rC[f][3]) : lane_below(rC[f][0]));
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if ((e & 1) != E0) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) OUT[f][e] = C[f][e];
+            continue;
+        }
+        float c[NIT], w[NIT], ea[NIT], n[NIT], s[NIT];
+        float rc[NRO1], rw[NRO1], re[NRO1], rn[NRO1], rs[NRO1], k[Mdl::NCF];
+#pragma unroll
+        for (int f = 0; f < NIT; f++) {
+            c[f] = XC[f][e];
+            w[f] = ea[f] = n[f] = s[f] = 0.0f;
+        }
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            c[F0 + f] = C[f][e];
+            w[F0 + f] = W[f][e];
+            ea[F0 + f] = E[f][e];
+            n[F0 + f] = (e == 0) ? edge[f] : C[f][e == 0 ? 0 : e - 1];
+            s[F0 + f] = (e == 3) ? edge[f] : C[f][e == 3 ? 3 : e + 1];
+        }
+#pragma unroll
+        for (int f = 0; f < NRO1; f++) {
+            rc[f] = rC[f][e];
+            rw[f] = rW[f][e];
+            re[f] = rE[f][e];
+            rn[f] = (e == 0) ? redge[f] : rC[f][e == 0 ? 0 : e - 1];
+            rs[f] = (e == 3) ? redge[f] : rC[f][e == 3 ? 3 : e + 1];
+        }
+#pragma unroll
+        for (int f = 0; f < Mdl::NCF; f++) k[f] = cf[f][e];
+        Mdl::update(c, w, ea, n, s, rc, rw, re, rn, rs, k, omega, om1);
+#pragma unroll
+        for (int f = 0; f < NF; f++) OUT[f][e] = ok[e] ? c[F0 + f] : C[f][e];
+    }
+}
+
+// The march of one sweep wave: sweep s of the launch, fields [F0, F0+NF) of the model.
+template <class Mdl, int S, bool FIRST, int F0, int NF>
+__device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float *dout0, float *dout1, float *Kring, float *Oring, float *Hring,
+                                               int s, int lane, int r, int nrows, int ncols, int j0, int j1, int xbase, int nsteps,
+                                               float omega, int col0, size_t fo)
+{
+    using L = RbpLayout<Mdl, S>;
+    constexpr int NIT = L::NIT, NRO = L::NRO, NRO1 = at_least_one<NRO>::value, NCF = L::NCF, NRING = L::NRING, COL = L::COL;
+    const float om1 = 1.0f - omega;
+    const bool store_lane = (lane >= 2) && (lane <= 61);
+    auto inner = [&](int col) { return col >= 1 && col <= ncols - 2; };
+    // per-lane row predicates, fixed for the whole march: which of the lane's four rows are interior pixels, and whether
+    // the lane holds the top / bottom border row (nrows is a multiple of 4 here, so they are elements 0 and 3)
+    bool ok[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) ok[e] = (r + e >= 1) && (r + e <= nrows - 2);
+    const bool top_lane = (r == 0), bot_lane = (r == nrows - 4);
+
+    // Three-column windows.  The step below is instantiated three times with the roles rotated, so no window ever moves:
+    // O*: the previous sweep's result at x-1, x, x+1, ALL fields (centre values of the other fields feed the coupling term);
+    // R*: own fields after this sweep's red half at x-2, x-1, x.  Coefficients are not windowed: each half-sweep reads its
+    // column from the K ring (LDS has the bandwidth; a nine-wave workgroup caps a wave at 168 VGPRs).
+    float O0[NIT][4], O1[NIT][4], O2[NIT][4], R0[NF][4], R1[NF][4], R2[NF][4];
+    float Q2[NRO1][4], Q1[NRO1][4], Q0[NRO1][4], Qn[NRO1][4]; // read-only fields at x-2, x-1, x, x+1 (moved: four columns, few planes)
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int f = 0; f < NIT; f++) O0[f][e] = O1[f][e] = O2[f][e] = 0.0f;
+#pragma unroll
+        for (int f = 0; f < NF; f++) R0[f][e] = R1[f][e] = R2[f][e] = 0.0f;
+#pragma unroll
+        for (int f = 0; f < NRO1; f++) Q2[f][e] = Q1[f][e] = Q0[f][e] = Qn[f][e] = 0.0f;
+    }
+    // ring positions: K ring slot of column x (group x - xbase - 1 = t - 3s - 1; a wave that is still in front of the first
+    // fetched column reads some slot whose content it never uses), O ring slot of column x+1 (sweep 0), H ring parity
+    int ki = ((-3 * s - 1) % L::NK + L::NK) % L::NK, oi = 0, hp = 1;
+
+    auto step = [&](int t, float (&Om)[NIT][4], float (&Oc)[NIT][4], float (&Op)[NIT][4], float (&Rpp)[NF][4], float (&Rp)[NF][4],
+                    float (&Rc)[NF][4]) __attribute__((always_inline)) {
+        const int x = xbase + t - 3 * s; // this wave's red column; black on x-1
+        // ---- take in column x+1 of the previous sweep's result, and the coefficients of columns x and x-1 ----
+        float *const ks = Kring + (size_t)ki * NRING * COL;                                   // column x
+        const float *const kps = Kring + (size_t)(ki == 0 ? L::NK - 1 : ki - 1) * NRING * COL; // column x-1
+        float Kc[NCF][4], Kp[NCF][4];
+        {
+            const float *src = (s == 0) ? Oring + (size_t)oi * NIT * COL : Hring + (size_t)((s - 1) * 2 + hp) * NIT * COL;
+#pragma unroll
+            for (int f = 0; f < NIT; f++) rbp_lds_read(Op[f], src + f * COL, lane);
+#pragma unroll
+            for (int f = 0; f < NCF; f++) rbp_lds_read(Kc[f], ks + f * COL, lane);
+#pragma unroll
+            for (int f = 0; f < NRO1; f++)
+                if (NRO > 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        Q2[f][e] = Q1[f][e];
+                        Q1[f][e] = Q0[f][e];
+                        Q0[f][e] = Qn[f][e];
+                    }
+                    // read-only fields ride one column ahead of the coefficients (the red half reads them at x+1)
+                    rbp_lds_read(Qn[f], Kring + (size_t)(ki + 1 == L::NK ? 0 : ki + 1) * NRING * COL + (NCF + (NRO > 0 ? f : 0)) * COL, lane);
+                }
+#pragma unroll
+            for (int f = 0; f < NCF; f++) rbp_lds_read(Kp[f], kps + f * COL, lane);
+        }
+        const int p = (x + col0) & 1;
+
+        if (FIRST && s == 0) {
+            // Sweep 1 of a call builds the divisor planes as it goes (opticalflowSolvers.c:111-127): column x was just read
+            // raw; derive it, put the derived planes back into its K-ring slot (this wave reads them again as column x-1 in the
+            // next step, the later sweeps three steps from now) and store them if launches follow that need them.  A wave
+            // that owns one field of a coupled model derives that field's divisor.
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float k[NCF];
+#pragma unroll
+                for (int f = 0; f < NCF; f++) k[f] = Kc[f][e];
+                Mdl::derive(k);
+                Kc[Mdl::D0][e] = k[Mdl::D0];
+                Kc[Mdl::D1][e] = k[Mdl::D1];
+            }
+            const bool d0_mine = (NF == NIT) || F0 == 0, d1_mine = (NF == NIT) || F0 == 1;
+            if (d0_mine) rbp_lds_write(ks + Mdl::D0 * COL, lane, Kc[Mdl::D0]);
+            if (d1_mine) rbp_lds_write(ks + Mdl::D1 * COL, lane, Kc[Mdl::D1]);
+            if (dout0 != nullptr && store_lane && x >= j0 && x < j1) {
+                if (d0_mine) rb_store4<true>(Kc[Mdl::D0], dout0 + fo, x, r, nrows);
+                if (d1_mine) rb_store4<true>(Kc[Mdl::D1], dout1 + fo, x, r, nrows);
+            }
+        }
+
+#define PDEIP_RBP_PHASE(OUT, CEN, WEST, EAST, XCEN, QC, QW, QE, KK)                                               \
+    do {                                                                                                          \
+        if (p == 0) rbp_phase<Mdl, F0, NF, 0>(OUT, CEN, WEST, EAST, XCEN, QC, QW, QE, KK, ok, omega, om1);        \
+        else        rbp_phase<Mdl, F0, NF, 1>(OUT, CEN, WEST, EAST, XCEN, QC, QW, QE, KK, ok, omega, om1);        \
+    } while (0)
+        // the own fields of the O windows
+        float OmF[NF][4], OcF[NF][4], OpF[NF][4];
+#pragma unroll
+        for (int f = 0; f < NF; f++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                OmF[f][e] = Om[F0 + f][e];
+                OcF[f][e] = Oc[F0 + f][e];
+                OpF[f][e] = Op[F0 + f][e];
+            }
+
+        // ---- red half-sweep on column x: Rc <- Oc with the red pixels relaxed ----
+        if (inner(x)) {
+            // sweeps after the first see a border column as the replicate of its inner neighbour after the previous sweep
+            // (:172-179), i.e. as this column itself; the first sweep of a launch reads the stored border
+            const bool wb = (s > 0) && !inner(x - 1), eb = (s > 0) && !inner(x + 1);
+            if (wb || eb) {
+                float Wv[NF][4], Ev[NF][4];
+#pragma unroll
+                for (int f = 0; f < NF; f++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        Wv[f][e] = wb ? OcF[f][e] : OmF[f][e];
+                        Ev[f][e] = eb ? OcF[f][e] : OpF[f][e];
+                    }
+                PDEIP_RBP_PHASE(Rc, OcF, Wv, Ev, Oc, Q0, Q1, Qn, Kc);
+            } else {
+                PDEIP_RBP_PHASE(Rc, OcF, OmF, OpF, Oc, Q0, Q1, Qn, Kc);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < NF; f++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) Rc[f][e] = OcF[f][e];
+        }
+
+        // ---- black half-sweep on column x-1: F <- Rp with the black pixels relaxed; then hand it on ----
+        // (the other fields' centre values at the black pixels are still the previous sweep's: the red half did not touch them)
+        const int xb = x - 1;
+        float F[NF][4];
+        if (inner(xb)) {
+            // a border column kept its replicate through this sweep's red half: the previous sweep's result of column xb (= Om)
+            const bool wb = (s > 0) && !inner(xb - 1), eb = (s > 0) && !inner(xb + 1);
+            if (wb || eb) {
+                float Wv[NF][4], Ev[NF][4];
+#pragma unroll
+                for (int f = 0; f < NF; f++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        Wv[f][e] = wb ? OmF[f][e] : Rpp[f][e];
+                        Ev[f][e] = eb ? OmF[f][e] : Rc[f][e];
+                    }
+                PDEIP_RBP_PHASE(F, Rp, Wv, Ev, Om, Q1, Q2, Q0, Kp);
+            } else {
+                PDEIP_RBP_PHASE(F, Rp, Rpp, Rc, Om, Q1, Q2, Q0, Kp);
+            }
+            // rows first (:161-170): border row 0 <- row 1, border row nrows-1 <- row nrows-2
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                F[f][0] = top_lane ? F[f][1] : F[f][0];
+                F[f][3] = bot_lane ? F[f][2] : F[f][3];
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < NF; f++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) F[f][e] = Rp[f][e];
+        }
+#undef PDEIP_RBP_PHASE
+        if (s < S - 1) {
+            float *dst = Hring + (size_t)(s * 2 + (hp ^ 1)) * NIT * COL;
+#pragma unroll
+            for (int f = 0; f < NF; f++) rbp_lds_write(dst + (F0 + f) * COL, lane, F[f]);
+        } else if (store_lane && xb >= j0 && xb < j1 && inner(xb)) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                float *out = P.it_out[F0 + f] + fo;
+                rb_store4<true>(F[f], out, xb, r, nrows);
+                if (xb == 1) rb_store4<true>(F[f], out, 0, r, nrows); // then columns (:172-179)
+                if (xb == ncols - 2) rb_store4<true>(F[f], out, ncols - 1, r, nrows);
+            }
+        }
+        ki = (ki + 1 == L::NK) ? 0 : ki + 1;
+        oi = (oi + 1 == L::NO) ? 0 : oi + 1;
+        hp ^= 1;
+        rbp_barrier();
+    };
+
+    rbp_barrier(); // group 0 is in LDS
+    for (int t = 0; t < nsteps; t += 3) {
+        step(t, O0, O1, O2, R0, R1, R2);
+        if (t + 1 < nsteps) step(t + 1, O1, O2, O0, R1, R2, R0);
+        if (t + 2 < nsteps) step(t + 2, O2, O0, O1, R2, R0, R1);
+    }
+}
+
+template <class Mdl, int S, bool FIRST>
+__global__ void __launch_bounds__((RbpLayout<Mdl, S>::THREADS))
+k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, int TJ, int ntiles_r, int nunits, float omega,
+          int col0, size_t frame_stride)
+{
+    using L = RbpLayout<Mdl, S>;
+    constexpr int NIT = L::NIT, NRO = L::NRO, NCF = L::NCF, NRING = L::NRING, COL = L::COL, NW = L::NW;
+    extern __shared__ __attribute__((aligned(16))) float rbp_lds[];
+    float *const Kring = rbp_lds;
+    float *const Oring = Kring + L::K_FLOATS;
+    float *const Hring = Oring + L::O_FLOATS;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 .. S*NW-1: sweep waves; S*NW: loader
+    int unit = blockIdx.x;
+    { // XCD-aware order: contiguous unit ranges per XCD (neighbouring strips share halo columns through one L2)
+        const int nb = gridDim.x, per = nb >> 3;
+        if (unit < (per << 3)) unit = (unit & 7) * per + (unit >> 3);
+    }
+    if (unit >= nunits) return;
+    const size_t fo = (size_t)blockIdx.y * frame_stride;
+    const int nstrips = nunits / ntiles_r;
+    const int a = unit / nstrips, b = unit % nstrips;
+    const int r = a * RBP_OWN_ROWS - 8 + 4 * lane;
+    const int j0 = b * TJ, j1 = (j0 + TJ < ncols) ? j0 + TJ : ncols;
+    const int nsteps = L::nsteps(TJ);
+    // red column of sweep 0 in step t: x0(t) = xbase + t; sweep s: x0(t) - 3s.  Two warm-up steps fill the windows.
+    const int xbase = j0 - L::HALO + 1 - 2;
+
+    if (wave == S * NW) {
+        // =========================================== loader wave =============================================
+        // group g = column xbase + 1 + g, consumed by sweep 0 in step g
+        const int rr = r < 0 ? 0 : (r > nrows - 4 ? nrows - 4 : r);
+        int kslot = 0, oslot = 0;
+        auto issue = [&](int g) __attribute__((always_inline)) {
+            const int y = xbase + 1 + g;
+            const int cc = y < 0 ? 0 : (y > ncols - 1 ? ncols - 1 : y);
+            const size_t off = fo + (size_t)cc * nrows + rr;
+            float *kdst = Kring + (size_t)kslot * NRING * COL;
+#pragma unroll
+            for (int f = 0; f < NCF; f++)
+                __builtin_amdgcn_global_load_lds(RBP_GLB(P.cf[f] + off), RBP_LDS(kdst + f * COL), 16, 0, 0);
+#pragma unroll
+            for (int f = 0; f < NRO; f++)
+                __builtin_amdgcn_global_load_lds(RBP_GLB(P.ro[f] + off), RBP_LDS(kdst + (NCF + f) * COL), 16, 0, 0);
+            float *odst = Oring + (size_t)oslot * NIT * COL;
+#pragma unroll
+            for (int f = 0; f < NIT; f++)
+                __builtin_amdgcn_global_load_lds(RBP_GLB(P.it_in[f] + off), RBP_LDS(odst + f * COL), 16, 0, 0);
+            kslot = (kslot + 1 == L::NK) ? 0 : kslot + 1;
+            oslot = (oslot + 1 == L::NO) ? 0 : oslot + 1;
+        };
+        for (int g = 0; g < L::P; g++) issue(g);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L::P - 1) * L::GROUP) : "memory"); // group 0 has landed
+        rbp_barrier();
+        for (int t = 0; t < nsteps; t++) {
+            issue(t + L::P);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L::P - 1) * L::GROUP) : "memory"); // group t+1 has landed
+            rbp_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may land in LDS after the workgroup has gone
+        return;
+    }
+
+    // ============================================ sweep waves ===============================================
+    // Coupled two-field models run two waves per sweep, one per field (u is updated from the OLD v of the same pixel and vice
+    // versa -- opticalflowSolvers.c:129-149 -- so the two halves of a half-sweep are independent); the workgroup then has two
+    // waves per SIMD, which is what keeps the VALUs busy while a wave waits for LDS or the barrier.
+    if constexpr (NW == 2) {
+        const int s = wave >> 1;
+        if ((wave & 1) == 0) rbp_sweep_wave<Mdl, S, FIRST, 0, 1>(P, dout0, dout1, Kring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
+        else rbp_sweep_wave<Mdl, S, FIRST, 1, 1>(P, dout0, dout1, Kring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
+    } else {
+        rbp_sweep_wave<Mdl, S, FIRST, 0, NIT>(P, dout0, dout1, Kring, Oring, Hring, wave, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
+    }
+}
+
+} // namespace pdeip

@@ -52,12 +52,18 @@ def sync_check():
     capi.call("pdeip_persist_error")
 
 
-def oflow_sor_elin4(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER, col0=0):
-    """In place on U, V (GS_SOR_elin4_2d, opticalflowSolvers.c:41)."""
+def oflow_sor_elin4(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER, col0=0, out=None):
+    """In place on U, V (GS_SOR_elin4_2d, opticalflowSolvers.c:41); with out=(U2, V2): U, V are only read and the relaxed
+    iterate goes to U2, V2 (no device-to-device copy in the red-black mode; callers alternate between two sets)."""
     _chk(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS)
     nrows, ncols, _ = _dims(U)
-    capi.call("pdeip_oflow_sor_elin4_dev", _stream(), *_p(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS), nrows, ncols,
-              int(iter), float(omega), int(mode), int(col0))
+    if out is None:
+        capi.call("pdeip_oflow_sor_elin4_dev", _stream(), *_p(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS), nrows, ncols,
+                  int(iter), float(omega), int(mode), int(col0))
+    else:
+        _chk(*out)
+        capi.call("pdeip_oflow_sor_elin4_dev_to", _stream(), *_p(U, V, out[0], out[1], M, Cu, Cv, Du, Dv, wW, wN, wE, wS), nrows,
+                  ncols, int(iter), float(omega), int(mode), int(col0))
 
 
 def oflow_sor_llin4(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, iter, omega, mode=capi.MODE_EXACT_ORDER, col0=0):

@@ -21,6 +21,7 @@ COLOUR = 1  # red-black / four-colour order        (product: PDEIP_MODE_RED_BLAC
 _P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _SIGS = {
     "orc_oflow_sor_elin4": [_P] * 11 + [_I, _I, _I, _F, _I],
+    "orc_oflow_sor_elin4_rb_omp": [_P] * 11 + [_I, _I, _I, _F, _I],
     "orc_oflow_sor_llin4": [_P] * 13 + [_I, _I, _I, _F, _I],
     "orc_oflow_res_elin4": [_P] * 13 + [_I, _I, _I],
     "orc_oflow_lhs_elin4": [_P] * 11 + [_I, _I, _I],
@@ -61,7 +62,7 @@ def lib():
         for name, sig in _SIGS.items():
             fn = getattr(_lib, name)
             fn.argtypes = sig
-            fn.restype = None
+            fn.restype = ctypes.c_int if name.endswith("_omp") else None
     return _lib
 
 
@@ -86,6 +87,14 @@ def oflow_sor_elin4(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, omega, order=LE
     ins = [F(a) for a in (M, Cu, Cv, Du, Dv, wW, wN, wE, wS)]
     lib().orc_oflow_sor_elin4(_p(U), _p(V), *[_p(a) for a in ins], U.shape[0], U.shape[1], int(it), float(omega), order)
     return U, V
+
+
+def oflow_sor_elin4_rb_omp(U, V, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, omega, nthreads=0):
+    """Red-black order on `nthreads` host threads (0 = OpenMP default); returns (U, V, threads used)."""
+    U, V = F(U), F(V)
+    ins = [F(a) for a in (M, Cu, Cv, Du, Dv, wW, wN, wE, wS)]
+    used = lib().orc_oflow_sor_elin4_rb_omp(_p(U), _p(V), *[_p(a) for a in ins], U.shape[0], U.shape[1], int(it), float(omega), int(nthreads))
+    return U, V, used
 
 
 def oflow_sor_llin4(U, V, dU, dV, M, Cu, Cv, Du, Dv, wW, wN, wE, wS, it, omega, order=LEX):

@@ -2,9 +2,13 @@
 generator, the CPU tests, the GPU parity tests, smoke() and bench.py).
 
 Shapes follow MATLAB: [nrows, ncols] or [nrows, ncols, nframes], float32, column-major.
-Coefficients are drawn so that the linear systems are diagonally dominant / positive definite
-(as the drivers' are), which keeps 20 sweeps at omega=1.9 finite; `nan_frac` laces the data
-terms with NaN the way out-of-range warps do in the drivers.
+The four (eight) weight planes of the parity problems are drawn INDEPENDENTLY on purpose: a kernel that
+reads the wrong weight plane or the right plane at a neighbour's position cannot hide behind a symmetry.
+The price: wE(i,j) != wW(i,j+1), the operator is not symmetric and SOR at omega = 1.9 does not converge on
+these planes -- a few tens of sweeps stay finite, which is all a bit-for-bit comparison needs.  Problems
+that must CONVERGE (known-answer tests, bench.py) pass symmetric=True: wE[:, :-1] = wW[:, 1:],
+wS[:-1, :] = wN[1:, :], which is what the drivers' OPdiffWeights / DdiffWeights produce.  `nan_frac`
+laces the data terms with NaN the way out-of-range warps do in the drivers.
 """
 import numpy as np
 
@@ -21,6 +25,14 @@ def _weights(rng, shape, n=4):
     return [_plane(rng, shape, 0.5, 5.0) for _ in range(n)]
 
 
+def symmetrize(wW, wN, wE, wS):
+    """Make (wW, wN, wE, wS) the weights of a symmetric operator: the east weight of a pixel is the west weight of
+    its east neighbour, the south weight the north weight of its south neighbour (in place on wE, wS)."""
+    wE[:, :-1] = wW[:, 1:]
+    wS[:-1, :] = wN[1:, :]
+    return wW, wN, wE, wS
+
+
 def _lace(rng, arrays, frac):
     """Put NaN at the same random pixels of every array in `arrays` (in place)."""
     if frac <= 0:
@@ -30,10 +42,10 @@ def _lace(rng, arrays, frac):
         a[mask] = np.nan
 
 
-def oflow_coeffs(rng, nrows, ncols, nframes=1, nan_frac=0.0, nan_mode="all"):
-    """M, Cu, Cv, Du, Dv with the structure of a motion tensor: Du=a^2, Dv=b^2, M=0.9ab."""
+def oflow_coeffs(rng, nrows, ncols, nframes=1, nan_frac=0.0, nan_mode="all", amp=1.5):
+    """M, Cu, Cv, Du, Dv with the structure of a motion tensor: Du=a^2, Dv=b^2, M=0.9ab; |a|,|b| <= amp (image gradients)."""
     shape = (nrows, ncols) if nframes == 1 else (nrows, ncols, nframes)
-    a, b = rng.uniform(-1.5, 1.5, size=shape), rng.uniform(-1.5, 1.5, size=shape)
+    a, b = rng.uniform(-amp, amp, size=shape), rng.uniform(-amp, amp, size=shape)
     c = rng.uniform(-1.0, 1.0, size=shape)
     M, Du, Dv = _f(0.9 * a * b), _f(a * a + 0.05), _f(b * b + 0.05)
     Cu, Cv = _f(-a * c), _f(-b * c)
@@ -48,11 +60,13 @@ def oflow_coeffs(rng, nrows, ncols, nframes=1, nan_frac=0.0, nan_mode="all"):
     return M, Cu, Cv, Du, Dv
 
 
-def elin4(seed, nrows, ncols, nframes=1, nan_frac=0.0, nan_mode="all"):
+def elin4(seed, nrows, ncols, nframes=1, nan_frac=0.0, nan_mode="all", symmetric=False, amp=1.5):
     rng = np.random.default_rng(seed)
     U, V = _plane(rng, (nrows, ncols), -1, 1), _plane(rng, (nrows, ncols), -1, 1)
-    M, Cu, Cv, Du, Dv = oflow_coeffs(rng, nrows, ncols, nframes, nan_frac, nan_mode)
+    M, Cu, Cv, Du, Dv = oflow_coeffs(rng, nrows, ncols, nframes, nan_frac, nan_mode, amp)
     wW, wN, wE, wS = _weights(rng, (nrows, ncols))
+    if symmetric:
+        symmetrize(wW, wN, wE, wS)
     return dict(U=U, V=V, M=M, Cu=Cu, Cv=Cv, Du=Du, Dv=Dv, wW=wW, wN=wN, wE=wE, wS=wS)
 
 

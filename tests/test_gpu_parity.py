@@ -168,3 +168,53 @@ def test_solver_errors(pdeip):
     q = pb.pde4(92, 16, 16)
     with pytest.raises(pdeip.mex_api.MexError, match="no such solver"):
         pdeip.mex_api.PDEsolver4(*q.values(), np.float32(1), np.float32(1.9), np.float32(3))
+
+
+@pytest.mark.parametrize("shape", [(64, 80), (97, 131), (480, 300)])
+@pytest.mark.parametrize("it", [0, 1, 2, 4, 5, 8, 9])
+def test_out_of_place_elin4(pdeip, oracle, shape, it):
+    """pdeip_oflow_sor_elin4_dev_to: the iterate is only read, the result lands in the second plane set -- both orderings,
+    every launch-count parity of the red-black chain (1 / 2 / 4 sweeps per launch), vs the oracle and vs the in-place call."""
+    dev, capi = pdeip.device, pdeip.capi
+    p = pb.elin4(901, *shape, nan_frac=0.01)
+    coef = [dev.to_device(p[k]) for k in ("M", "Cu", "Cv", "Du", "Dv", "wW", "wN", "wE", "wS")]
+    for mode, order in ((capi.MODE_RED_BLACK, oracle.COLOUR), (capi.MODE_EXACT_ORDER, oracle.LEX)):
+        U, V = dev.to_device(p["U"]), dev.to_device(p["V"])
+        U2, V2 = U.clone().fill_(7.0), V.clone().fill_(7.0)
+        dev.oflow_sor_elin4(U, V, *coef, it, 1.9, mode, out=(U2, V2))
+        want = oracle.oflow_sor_elin4(*p.values(), it, 1.9, order) if it > 0 else (p["U"], p["V"])
+        assert pb.bit_equal(dev.to_matlab(U), p["U"]) and pb.bit_equal(dev.to_matlab(V), p["V"]), "the input planes were written"
+        assert pb.bit_equal(dev.to_matlab(U2), want[0]), pb.describe_mismatch(dev.to_matlab(U2), want[0])
+        assert pb.bit_equal(dev.to_matlab(V2), want[1])
+        if it > 0:
+            dev.oflow_sor_elin4(U, V, *coef, it, 1.9, mode)
+            assert pb.bit_equal(dev.to_matlab(U), want[0]) and pb.bit_equal(dev.to_matlab(V), want[1])
+
+
+def test_out_of_place_other_models(pdeip, oracle):
+    """The llin4 / disp4 / pde4 out-of-place entry points through the C-ABI (device pointers), red-black, iter = 4 and 6."""
+    import torch
+
+    dev, capi = pdeip.device, pdeip.capi
+    st = lambda: torch.cuda.current_stream().cuda_stream
+    for it in (4, 6):
+        q = pb.llin4(902, 120, 96, nan_frac=0.02)
+        d = {k: dev.to_device(v) for k, v in q.items()}
+        o0, o1 = torch.empty_like(d["dU"]), torch.empty_like(d["dV"])
+        capi.call("pdeip_oflow_sor_llin4_dev_to", st(), *[d[k].data_ptr() for k in ("U", "V", "dU", "dV")], o0.data_ptr(), o1.data_ptr(),
+                  *[d[k].data_ptr() for k in ("M", "Cu", "Cv", "Du", "Dv", "wW", "wN", "wE", "wS")], 120, 96, it, 1.9, 1, 0)
+        want = oracle.oflow_sor_llin4(*q.values(), it, 1.9, oracle.COLOUR)
+        assert pb.bit_equal(dev.to_matlab(o0), want[0]) and pb.bit_equal(dev.to_matlab(o1), want[1])
+        assert pb.bit_equal(dev.to_matlab(d["dU"]), q["dU"])
+        e = pb.disp4(903, 120, 96, nan_frac=0.02)
+        d = {k: dev.to_device(v) for k, v in e.items()}
+        o = torch.empty_like(d["dU"])
+        capi.call("pdeip_disp_sor_llin4_dev_to", st(), d["U"].data_ptr(), d["dU"].data_ptr(), o.data_ptr(),
+                  *[d[k].data_ptr() for k in ("Cu", "Du", "wW", "wN", "wE", "wS")], 120, 96, it, 1.9, 1, 0)
+        assert pb.bit_equal(dev.to_matlab(o), oracle.disp_sor_llin4(*e.values(), it, 1.9, oracle.COLOUR))
+        f = pb.pde4(904, 120, 96, nframes=2, nan_frac=0.02)
+        d = {k: dev.to_device(v) for k, v in f.items()}
+        o = torch.empty_like(d["X"])
+        capi.call("pdeip_pde_sor4_dev_to", st(), d["X"].data_ptr(), o.data_ptr(), *[d[k].data_ptr() for k in ("TRACE", "B", "wW", "wN", "wE", "wS")],
+                  120, 96, 2, it, 1.75, 1, 0)
+        assert pb.bit_equal(dev.to_matlab(o), oracle.pde_sor4(*f.values(), it, 1.75, oracle.COLOUR))
