@@ -66,6 +66,9 @@ __device__ __forceinline__ void rbp_lds_write(float *col, int lane, const float 
 }
 
 // address-space casts for __builtin_amdgcn_global_load_lds (global source per lane, LDS destination = wave-uniform base + 16 x lane)
+#ifndef RBP_AUX_COEF
+#define RBP_AUX_COEF 0 /* default cache policy; nt (2) measured the same: the kernel is bound by instruction issue, not by the DMA */
+#endif
 #define RBP_LDS(p) ((__attribute__((address_space(3))) void *)(p))
 #define RBP_GLB(p) ((const __attribute__((address_space(1))) void *)(p))
 
@@ -235,12 +238,30 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
                 OpF[f][e] = Op[F0 + f][e];
             }
 
-        // ---- red half-sweep on column x: Rc <- Oc with the red pixels relaxed ----
-        if (inner(x)) {
-            // sweeps after the first see a border column as the replicate of its inner neighbour after the previous sweep
-            // (:172-179), i.e. as this column itself; the first sweep of a launch reads the stored border
-            const bool wb = (s > 0) && !inner(x - 1), eb = (s > 0) && !inner(x + 1);
-            if (wb || eb) {
+        const int xb = x - 1;
+        float F[NF][4];
+        if (x >= 3 && x <= ncols - 3) {
+            // ---- the common case: neither half-sweep touches or reads a border column; one parity branch for both ----
+            // red on column x: Rc <- Oc with the red pixels relaxed; black on column x-1: F <- Rp with the black pixels relaxed
+            // (the other fields' centre values at the black pixels are still the previous sweep's: the red half left them alone)
+            if (p == 0) {
+                rbp_phase<Mdl, F0, NF, 0>(Rc, OcF, OmF, OpF, Oc, Q0, Q1, Qn, Kc, ok, omega, om1);
+                rbp_phase<Mdl, F0, NF, 0>(F, Rp, Rpp, Rc, Om, Q1, Q2, Q0, Kp, ok, omega, om1);
+            } else {
+                rbp_phase<Mdl, F0, NF, 1>(Rc, OcF, OmF, OpF, Oc, Q0, Q1, Qn, Kc, ok, omega, om1);
+                rbp_phase<Mdl, F0, NF, 1>(F, Rp, Rpp, Rc, Om, Q1, Q2, Q0, Kp, ok, omega, om1);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; f++) { // rows first (:161-170): border row 0 <- row 1, border row nrows-1 <- row nrows-2
+                F[f][0] = top_lane ? F[f][1] : F[f][0];
+                F[f][3] = bot_lane ? F[f][2] : F[f][3];
+            }
+        } else {
+            // ---- columns at the image border (and the clamped columns outside it) ----
+            if (inner(x)) {
+                // sweeps after the first see a border column as the replicate of its inner neighbour after the previous sweep
+                // (:172-179), i.e. as this column itself; the first sweep of a launch reads the stored border
+                const bool wb = (s > 0) && !inner(x - 1), eb = (s > 0) && !inner(x + 1);
                 float Wv[NF][4], Ev[NF][4];
 #pragma unroll
                 for (int f = 0; f < NF; f++)
@@ -251,23 +272,14 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
                     }
                 PDEIP_RBP_PHASE(Rc, OcF, Wv, Ev, Oc, Q0, Q1, Qn, Kc);
             } else {
-                PDEIP_RBP_PHASE(Rc, OcF, OmF, OpF, Oc, Q0, Q1, Qn, Kc);
+#pragma unroll
+                for (int f = 0; f < NF; f++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) Rc[f][e] = OcF[f][e];
             }
-        } else {
-#pragma unroll
-            for (int f = 0; f < NF; f++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) Rc[f][e] = OcF[f][e];
-        }
-
-        // ---- black half-sweep on column x-1: F <- Rp with the black pixels relaxed; then hand it on ----
-        // (the other fields' centre values at the black pixels are still the previous sweep's: the red half did not touch them)
-        const int xb = x - 1;
-        float F[NF][4];
-        if (inner(xb)) {
-            // a border column kept its replicate through this sweep's red half: the previous sweep's result of column xb (= Om)
-            const bool wb = (s > 0) && !inner(xb - 1), eb = (s > 0) && !inner(xb + 1);
-            if (wb || eb) {
+            if (inner(xb)) {
+                // a border column kept its replicate through this sweep's red half: the previous sweep's result of column xb (= Om)
+                const bool wb = (s > 0) && !inner(xb - 1), eb = (s > 0) && !inner(xb + 1);
                 float Wv[NF][4], Ev[NF][4];
 #pragma unroll
                 for (int f = 0; f < NF; f++)
@@ -277,20 +289,17 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
                         Ev[f][e] = eb ? OmF[f][e] : Rc[f][e];
                     }
                 PDEIP_RBP_PHASE(F, Rp, Wv, Ev, Om, Q1, Q2, Q0, Kp);
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+                    F[f][0] = top_lane ? F[f][1] : F[f][0];
+                    F[f][3] = bot_lane ? F[f][2] : F[f][3];
+                }
             } else {
-                PDEIP_RBP_PHASE(F, Rp, Rpp, Rc, Om, Q1, Q2, Q0, Kp);
+#pragma unroll
+                for (int f = 0; f < NF; f++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) F[f][e] = Rp[f][e];
             }
-            // rows first (:161-170): border row 0 <- row 1, border row nrows-1 <- row nrows-2
-#pragma unroll
-            for (int f = 0; f < NF; f++) {
-                F[f][0] = top_lane ? F[f][1] : F[f][0];
-                F[f][3] = bot_lane ? F[f][2] : F[f][3];
-            }
-        } else {
-#pragma unroll
-            for (int f = 0; f < NF; f++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) F[f][e] = Rp[f][e];
         }
 #undef PDEIP_RBP_PHASE
         if (s < S - 1) {
@@ -361,7 +370,7 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
             float *kdst = Kring + (size_t)kslot * NRING * COL;
 #pragma unroll
             for (int f = 0; f < NCF; f++)
-                __builtin_amdgcn_global_load_lds(RBP_GLB(P.cf[f] + off), RBP_LDS(kdst + f * COL), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(RBP_GLB(P.cf[f] + off), RBP_LDS(kdst + f * COL), 16, 0, RBP_AUX_COEF);
 #pragma unroll
             for (int f = 0; f < NRO; f++)
                 __builtin_amdgcn_global_load_lds(RBP_GLB(P.ro[f] + off), RBP_LDS(kdst + (NCF + f) * COL), 16, 0, 0);

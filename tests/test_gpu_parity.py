@@ -175,7 +175,9 @@ def test_solver_errors(pdeip):
 def test_out_of_place_elin4(pdeip, oracle, shape, it):
     """pdeip_oflow_sor_elin4_dev_to: the iterate is only read, the result lands in the second plane set -- both orderings,
     every launch-count parity of the red-black chain (1 / 2 / 4 sweeps per launch), vs the oracle and vs the in-place call."""
-    dev, capi = pdeip.device, pdeip.capi
+    import importlib
+
+    dev, capi = importlib.import_module("pde-based-image-processing_amd.device"), pdeip.capi
     p = pb.elin4(901, *shape, nan_frac=0.01)
     coef = [dev.to_device(p[k]) for k in ("M", "Cu", "Cv", "Du", "Dv", "wW", "wN", "wE", "wS")]
     for mode, order in ((capi.MODE_RED_BLACK, oracle.COLOUR), (capi.MODE_EXACT_ORDER, oracle.LEX)):
@@ -195,7 +197,9 @@ def test_out_of_place_other_models(pdeip, oracle):
     """The llin4 / disp4 / pde4 out-of-place entry points through the C-ABI (device pointers), red-black, iter = 4 and 6."""
     import torch
 
-    dev, capi = pdeip.device, pdeip.capi
+    import importlib
+
+    dev, capi = importlib.import_module("pde-based-image-processing_amd.device"), pdeip.capi
     st = lambda: torch.cuda.current_stream().cuda_stream
     for it in (4, 6):
         q = pb.llin4(902, 120, 96, nan_frac=0.02)
