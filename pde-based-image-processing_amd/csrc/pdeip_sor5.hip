@@ -159,7 +159,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_exact_persist<Mdl>), plds));
             dst->persist_used = true;
             SweepTimer timer(s);
-            hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(B * iter * nframes)), dim3(128), plds, s, P, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
+            hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(B * iter * nframes)), dim3(exp_threads<Mdl>()), plds, s, P, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
             timer.stop(1);
             g.last_launches++;
             const int nb = 2 * ncols + 2 * (nrows - 2);

@@ -444,8 +444,11 @@ __device__ __forceinline__ void persist_wait3(const unsigned *my_ptr, unsigned m
 
 typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
 
+// compute wave(s), loader wave, storer wave; the coupled two-field models relax with two compute waves, one per field
+template <class Mdl> constexpr int exp_threads() { return Mdl::NIT == 2 ? 256 : 192; }
+
 template <class Mdl>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__((exp_threads<Mdl>()))
 k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, int B, int T, int NC, int nframes,
                     float omega, size_t frame_stride)
 {
@@ -458,7 +461,14 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
     unsigned *s_ticket = reinterpret_cast<unsigned *>(smem + 2 * L::BUF + 2 * L::OUTB);
 
     const int lane = threadIdx.x & 63;
-    const bool mover = (threadIdx.x >> 6) == 1;
+    // Roles.  The walker's pace is set by whichever wave is slowest per chunk.  A wave that both polls the neighbours'
+    // counters (a write-through round trip of ~1 us) and drains its own write-through stores before publishing (another one)
+    // is slower than the wave that relaxes, so the two round trips belong to two waves with their own vmcnt queues: the
+    // LOADER polls, fetches and stashes; the STORER writes the relaxed chunk back and publishes the counter.  The coupled
+    // models update u from the OLD v of the same pixel and vice versa (opticalflowSolvers.c:129-149), so their two fields are
+    // relaxed by two COMPUTE waves that never exchange anything: half the instructions per step each.
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 compute (field 0 / all), 1 loader, 2 storer, 3 compute (field 1)
+    const bool mover = role == 1;
     if (threadIdx.x == 0) *s_ticket = atomicAdd(ctl.ticket, 1u);
     __syncthreads();
     const unsigned tk = *s_ticket;
@@ -545,6 +555,58 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
                         make_float4(epre[f].v[0], epre[f].v[1], epre[f].v[2], epre[f].v[3]);
             }
         };
+        // chunk c is fetched two barriers before it is relaxed and stashed one barrier before.  Per interval: issue the
+        // dependency poll of the chunk two ahead (one load, three counters), stash the chunk that has landed while the poll is
+        // in flight, then look at the poll and issue the loads.
+        auto poll_issue = [&]() __attribute__((always_inline)) -> unsigned {
+            return my_ptr != nullptr ? __hip_atomic_load(my_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        };
+        auto poll_finish = [&](int c, unsigned seen) __attribute__((always_inline)) {
+            const int need = lane == 0 ? c + 5 : (lane == 1 ? c + 2 : c - 2);
+            const unsigned un = (unsigned)(need < 0 ? 0 : (need < NC ? need : NC));
+            if (__all(my_ptr == nullptr || seen >= un)) return;
+            persist_wait3(my_ptr, un, ctl.abort_flag); // not there yet: the bounded spin
+        };
+        wait_deps(0);
+        fetch(0, preA, epreA);
+        stash(preA, epreA, 0);
+        if (NC > 1) {
+            wait_deps(1);
+            if constexpr (TWO_SETS) fetch(1, preB, epreB);
+            else fetch(1, preA, epreA);
+        }
+        lds_barrier(); // chunk 0 is in buffer 0
+        for (int c = 0; c < NC; c += 2) {
+            // ---- while chunk c (buffer 0) is relaxed ----
+            {
+                const bool pf = c + 2 < NC;
+                const unsigned seen = pf ? poll_issue() : 0u;
+                if (c + 1 < NC) {
+                    if constexpr (TWO_SETS) stash(preB, epreB, 1);
+                    else stash(preA, epreA, 1);
+                }
+                if (pf) { poll_finish(c + 2, seen); fetch(c + 2, preA, epreA); }
+            }
+            lds_barrier();
+            if (c + 1 >= NC) break;
+            // ---- while chunk c+1 (buffer 1) is relaxed ----
+            {
+                const bool pf = c + 3 < NC;
+                const unsigned seen = pf ? poll_issue() : 0u;
+                if (c + 2 < NC) stash(preA, epreA, 0);
+                if (pf) {
+                    poll_finish(c + 3, seen);
+                    if constexpr (TWO_SETS) fetch(c + 3, preB, epreB);
+                    else fetch(c + 3, preA, epreA);
+                }
+            }
+            lds_barrier();
+        }
+        return;
+    }
+
+    if (role == 2) {
+        // ================================ storer wave =========================================
         // relaxed chunk c: LDS -> global, write-through (sc1)
         auto store_out = [&](int c) __attribute__((always_inline)) {
             const float *outb = outb_base + (c & 1) * L::OUTB;
@@ -572,63 +634,22 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
                     }
                 }
         };
-        // publish progress = c+1 once every store of this wave has left (recipe R1: drain, then the flag).
-        // `younger_loads` = vector loads issued AFTER those stores (the prefetch of a later chunk): vmcnt
-        // retires in order, so waiting until only that many operations remain drains the stores without
-        // waiting for the prefetch.  (vmcnt encodes 0..63.)
-        constexpr int FETCH_LOADS = NP * 4 + NF * 4;
-        auto publish = [&](int c, bool younger_loads) __attribute__((always_inline)) {
-            if (younger_loads && FETCH_LOADS <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FETCH_LOADS <= 63 ? FETCH_LOADS : 0) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // publish progress = c+1 once every store of this wave has left (recipe R1: drain, then the flag); this wave issues
+        // nothing but those stores, so the drain is a plain vmcnt(0)
+        auto publish = [&](int c) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(prog_mine, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        // chunk c is fetched two barriers before it is relaxed, stashed one barrier before, written back one after.
-        // Per step: stash the chunk that landed, issue the write-back stores, wait for the dependencies of the
-        // chunk two ahead and issue its loads, then publish behind vmcnt(#loads).
-        wait_deps(0);
-        fetch(0, preA, epreA);
-        stash(preA, epreA, 0);
-        if (NC > 1) {
-            wait_deps(1);
-            if constexpr (TWO_SETS) fetch(1, preB, epreB);
-            else fetch(1, preA, epreA);
-        }
         lds_barrier(); // chunk 0 is in buffer 0
-        for (int c = 0; c < NC; c += 2) {
-            // ---- while chunk c (buffer 0) is relaxed ----
-            if constexpr (TWO_SETS) {
-                if (c + 1 < NC) stash(preB, epreB, 1);
-                if (c >= 1) store_out(c - 1);
-                const bool pf = c + 2 < NC;
-                if (pf) { wait_deps(c + 2); fetch(c + 2, preA, epreA); }
-                if (c >= 1) publish(c - 1, pf);
-            } else {
-                if (c + 1 < NC) stash(preA, epreA, 1);
-                if (c >= 1) store_out(c - 1);
-                const bool pf = c + 2 < NC;
-                if (pf) { wait_deps(c + 2); fetch(c + 2, preA, epreA); }
-                if (c >= 1) publish(c - 1, pf);
-            }
-            lds_barrier();
-            if (c + 1 >= NC) break;
-            // ---- while chunk c+1 (buffer 1) is relaxed ----
-            if constexpr (TWO_SETS) {
-                if (c + 2 < NC) stash(preA, epreA, 0);
-                store_out(c);
-                const bool pf = c + 3 < NC;
-                if (pf) { wait_deps(c + 3); fetch(c + 3, preB, epreB); }
-                publish(c, pf);
-            } else {
-                if (c + 2 < NC) stash(preA, epreA, 0);
-                store_out(c);
-                const bool pf = c + 3 < NC;
-                if (pf) { wait_deps(c + 3); fetch(c + 3, preA, epreA); }
-                publish(c, pf);
+        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: write chunk k-1 back
+            if (k >= 1) {
+                store_out(k - 1);
+                publish(k - 1);
             }
             lds_barrier();
         }
         store_out(NC - 1);
-        publish(NC - 1, false);
+        publish(NC - 1);
         return;
     }
 
@@ -640,16 +661,22 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
     const bool first_sweep = (t == 0);
     const int i0 = 1 - lane; // row of this lane at step 0 of chunk 0
 
+    auto compute_wave = [&](auto f0_tag, auto nfw_tag) __attribute__((always_inline)) {
+    // this wave relaxes the fields [F0, F0 + NFW); of the other fields it only follows the centre value (the coupling term)
+    constexpr int F0 = decltype(f0_tag)::value, NFW = decltype(nfw_tag)::value;
+    auto mine = [](int f) { return f >= F0 && f < F0 + NFW; };
     lds_barrier(); // the mover has passed the dependency waits of chunks 0 and 1
     // state at step 0 (rows <= 1): sc1 loads, after the waits above
     float prev[NIT], cen[NIT], north0[NIT], west0[NIT], topb[NIT], rcen[NRO1], rnorth[NRO1];
 #pragma unroll
     for (int f = 0; f < NIT; f++) {
         cen[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc, crow(i0)), 0, 16));
-        north0[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc, crow(i0 - 1)), 0, 16));
-        west0[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc - 1, crow(i0)), 0, 16));
-        topb[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc, 0), 0, 16));
-        prev[f] = 0.0f;
+        north0[f] = west0[f] = topb[f] = prev[f] = 0.0f;
+        if (mine(f)) {
+            north0[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc, crow(i0 - 1)), 0, 16));
+            west0[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc - 1, crow(i0)), 0, 16));
+            topb[f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(jc, 0), 0, 16));
+        }
     }
 #pragma unroll
     for (int f = 0; f < NRO1; f++) {
@@ -685,16 +712,20 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
 #pragma unroll
                 for (int f = 0; f < NIT; f++) {
                     const float sraw = el(s4[f]);
-                    const float eraw = dpp_from_upper_lane(sraw, el(e4[f]));
-                    float wnew = dpp_from_lower_lane(prev[f], el(e4[f]));
-                    if (q == 0 && lane != 0) wnew = west0[f];
-                    float nv = (q == 0) ? north0[f] : prev[f];
-                    if (!INTERIOR && i == 1) nv = first_sweep ? topb[f] : cen[f];
                     c[f] = cen[f];
-                    n[f] = nv;
-                    s[f] = (!INTERIOR && i + 1 == nrows - 1 && !first_sweep) ? cen[f] : sraw;
-                    e[f] = (!INTERIOR && j + 1 == ncols - 1 && !first_sweep) ? cen[f] : eraw;
-                    w[f] = (!INTERIOR && j - 1 == 0 && !first_sweep) ? cen[f] : wnew;
+                    if (mine(f)) {
+                        const float eraw = dpp_from_upper_lane(sraw, el(e4[f]));
+                        float wnew = dpp_from_lower_lane(prev[f], el(e4[f]));
+                        if (q == 0 && lane != 0) wnew = west0[f];
+                        float nv = (q == 0) ? north0[f] : prev[f];
+                        if (!INTERIOR && i == 1) nv = first_sweep ? topb[f] : cen[f];
+                        n[f] = nv;
+                        s[f] = (!INTERIOR && i + 1 == nrows - 1 && !first_sweep) ? cen[f] : sraw;
+                        e[f] = (!INTERIOR && j + 1 == ncols - 1 && !first_sweep) ? cen[f] : eraw;
+                        w[f] = (!INTERIOR && j - 1 == 0 && !first_sweep) ? cen[f] : wnew;
+                    } else {
+                        n[f] = s[f] = e[f] = w[f] = 0.0f; // the other field's neighbours feed nothing this wave keeps
+                    }
                     cen[f] = sraw;
                 }
 #pragma unroll
@@ -711,7 +742,7 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
                 for (int f = 0; f < NCF; f++) kk[f] = el(ck[f]);
                 Mdl::update(c, w, e, n, s, rcen, rwest, reast, rnorth, rsouth, kk, omega, om1);
 #pragma unroll
-                for (int f = 0; f < NIT; f++) {
+                for (int f = F0; f < F0 + NFW; f++) {
                     if (active) prev[f] = c[f];
                     const float r = c[f];
                     if (x == 0) res[f].x = r; else if (x == 1) res[f].y = r; else if (x == 2) res[f].z = r; else res[f].w = r;
@@ -723,7 +754,7 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
                 }
             }
 #pragma unroll
-            for (int f = 0; f < NIT; f++) *reinterpret_cast<float4 *>(&outb[(f * 64 + lane) * EX_STR + 4 * mq]) = res[f];
+            for (int f = F0; f < F0 + NFW; f++) *reinterpret_cast<float4 *>(&outb[(f * 64 + lane) * EX_STR + 4 * mq]) = res[f];
         }
         };
         {
@@ -733,6 +764,12 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
             else relax_chunk(std::false_type{});
         }
         lds_barrier();
+    }    };
+    if constexpr (NIT == 2) {
+        if (role == 0) compute_wave(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        else compute_wave(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    } else {
+        compute_wave(std::integral_constant<int, 0>{}, std::integral_constant<int, NIT>{});
     }
 }
 
