@@ -118,4 +118,20 @@ void read_env_once();
 // ---- host staging (pdeip_host.hip) ---------------------------------------------------------------------
 inline size_t pad4(size_t n) { return (n + 3) & ~(size_t)3; }
 
+// ---- one solver call across the device group (pdeip_multi.hip) --------------------------------------------
+// Planes are HOST pointers in the order of the corresponding *_dev_to entry point.
+struct MultiCall {
+    int kind;                     // 0 elin4, 1 llin4, 2 disp4, 3 pde4, 4 pde8
+    int n_it, n_ro, n_cf, frames; // iterate planes, read-only neighbour planes, coefficient planes; frames per plane
+    const float *it_in[2];
+    float *it_out[2];
+    const float *ro[2];
+    const float *cf[11];
+    int nrows, ncols, iter;
+    float omega;
+};
+// Runs a red-black point-SOR call as column slabs over the devices of pdeip_set_devices().  *handled = 0: not split (one
+// device, or the slabs would be narrower than their halo): the caller takes the single-device path.
+int multi_sor(const MultiCall &mc, int *handled);
+
 } // namespace pdeip

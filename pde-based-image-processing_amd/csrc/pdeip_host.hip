@@ -64,6 +64,22 @@ static int oflow_sor_host(const char *who, bool llin, bool fill_residuals, const
     RC(use_device());
     const size_t n = (size_t)nrows * ncols, nf = n * (size_t)F;
 
+    // several devices (pdeip_set_devices / PDEIP_DEVICES): a red-black point-SOR call is cut into column slabs
+    if (g.mode == PDEIP_MODE_RED_BLACK && solver == PDEIP_SOLVER_SOR && iter > 0 && RU == nullptr && g.ngroup > 0) {
+        MultiCall mc{};
+        mc.kind = llin ? 1 : 0;
+        mc.n_it = 2; mc.n_ro = llin ? 2 : 0; mc.n_cf = 9; mc.frames = 1;
+        mc.it_in[0] = llin ? dU : U; mc.it_in[1] = llin ? dV : V;
+        mc.it_out[0] = o0; mc.it_out[1] = o1;
+        mc.ro[0] = U; mc.ro[1] = V;
+        const float *cfh[9] = {M, Cu, Cv, Du, Dv, wW, wN, wE, wS}; // the solver reads frame 0 of the coefficient planes
+        for (int k = 0; k < 9; k++) mc.cf[k] = cfh[k];
+        mc.nrows = nrows; mc.ncols = ncols; mc.iter = iter; mc.omega = omega;
+        int handled = 0;
+        RC(multi_sor(mc, &handled));
+        if (handled) return PDEIP_OK;
+    }
+
     Arena ar;
     RC(ar.init(pad4(n) * 16 + pad4(nf) * 7));
     float *dUin = ar.take(n), *dVin = ar.take(n), *ddU = ar.take(n), *ddV = ar.take(n);
@@ -220,6 +236,18 @@ extern "C" int pdeip_disp_sor_llin4(const float *U, const float *dU, const float
         memset(dU_out, 0, n * sizeof(float));
         return PDEIP_OK;
     }
+    if (g.mode == PDEIP_MODE_RED_BLACK && solver == PDEIP_SOLVER_SOR) {
+        MultiCall mc{};
+        mc.kind = 2;
+        mc.n_it = 1; mc.n_ro = 1; mc.n_cf = 6; mc.frames = 1;
+        mc.it_in[0] = dU; mc.it_out[0] = dU_out; mc.ro[0] = U;
+        const float *cfh[6] = {Cu, Du, wW, wN, wE, wS};
+        for (int k = 0; k < 6; k++) mc.cf[k] = cfh[k];
+        mc.nrows = nrows; mc.ncols = ncols; mc.iter = iter; mc.omega = omega;
+        int handled = 0;
+        RC(multi_sor(mc, &handled));
+        if (handled) return PDEIP_OK;
+    }
     Arena ar;
     RC(ar.init(pad4(n) * 8));
     float *dUin = ar.take(n), *ddU = ar.take(n), *dCu = ar.take(n), *dDu = ar.take(n);
@@ -289,6 +317,18 @@ extern "C" int pdeip_pde_sor4(const float *X, const float *TRACE, const float *B
         memcpy(X_out, X, nf * sizeof(float));
         return PDEIP_OK;
     }
+    if (g.mode == PDEIP_MODE_RED_BLACK && solver == PDEIP_SOLVER_SOR) {
+        MultiCall mc{};
+        mc.kind = 3;
+        mc.n_it = 1; mc.n_ro = 0; mc.n_cf = 6; mc.frames = nframes;
+        mc.it_in[0] = X; mc.it_out[0] = X_out;
+        const float *cfh[6] = {TRACE, B, wW, wN, wE, wS};
+        for (int k = 0; k < 6; k++) mc.cf[k] = cfh[k];
+        mc.nrows = nrows; mc.ncols = ncols; mc.iter = iter; mc.omega = omega;
+        int handled = 0;
+        RC(multi_sor(mc, &handled));
+        if (handled) return PDEIP_OK;
+    }
     Arena ar;
     RC(ar.init(pad4(nf) * 7));
     float *dX = ar.take(nf), *dT = ar.take(nf), *dB = ar.take(nf);
@@ -319,6 +359,18 @@ extern "C" int pdeip_pde_sor8(const float *X, const float *TRACE, const float *B
     if (iter <= 0 && solver != PDEIP_SOLVER_ALR) { // GS_ALR_SOR_8_2d runs its one iteration regardless (pdeSolvers.c:362)
         memcpy(X_out, X, nf * sizeof(float));
         return PDEIP_OK;
+    }
+    if (g.mode == PDEIP_MODE_RED_BLACK && solver == PDEIP_SOLVER_SOR && iter > 0) {
+        MultiCall mc{};
+        mc.kind = 4;
+        mc.n_it = 1; mc.n_ro = 0; mc.n_cf = 10; mc.frames = nframes;
+        mc.it_in[0] = X; mc.it_out[0] = X_out;
+        const float *cfh[10] = {TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW};
+        for (int k = 0; k < 10; k++) mc.cf[k] = cfh[k];
+        mc.nrows = nrows; mc.ncols = ncols; mc.iter = iter; mc.omega = omega;
+        int handled = 0;
+        RC(multi_sor(mc, &handled));
+        if (handled) return PDEIP_OK;
     }
     Arena ar;
     RC(ar.init(pad4(nf) * 11));
