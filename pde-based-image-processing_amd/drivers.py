@@ -69,6 +69,7 @@ def _flow_llin(level_cls, Iin, channels, fstTerm, sndTerm, defaults, mode, param
         if scl > 0:
             cols, rows = P0[scl - 1].shape[-2:]
             U, V = _up(U, 1.0 / p["scl_factor"], rows, cols), _up(V, 1.0 / p["scl_factor"], rows, cols)
+    dev.sync_check()  # results leave the device: a timed-out dependency wait of the exact-order kernel must not pass silently
     return dev.to_matlab(U), dev.to_matlab(V)
 
 
@@ -104,12 +105,14 @@ def FlowEminHS_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
             dev.median3(U * inv, None, mU)
             dev.median3(V * inv, None, mV)
             U, V = dev.pyr_resize(mU, rows, cols, "bicubic"), dev.pyr_resize(mV, rows, cols, "bicubic")
+    dev.sync_check()  # results leave the device: a timed-out dependency wait of the exact-order kernel must not pass silently
     return dev.to_matlab(U), dev.to_matlab(V)
 
 
 def FlowEminNDFASFMG_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
     I0, I1 = _frames(Iin, channels)
     gU, gV = fas.FasFmgFlow(param, mode=mode).run(dev.to_device(I0), dev.to_device(I1))
+    dev.sync_check()
     return dev.to_matlab(gU), dev.to_matlab(gV)
 
 
@@ -128,6 +131,7 @@ def DispEminND_llin_2D(Il, Ir, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXA
         if scl > 0:
             cols, rows = P0[scl - 1].shape[-2:]
             U = _up(U, 1.0 / p["scl_factor"], rows, cols)
+    dev.sync_check()
     return dev.to_matlab(U)
 
 
@@ -148,6 +152,7 @@ def DispEminND_llin_sym_2D(Il, Ir, mode=capi.MODE_EXACT_ORDER, **param):
         if scl > 0:
             cols, rows = P0[scl - 1].shape[-2:]
             U0, U1 = _up(U0, 1.0 / p["scl_factor"], rows, cols), _up(U1, 1.0 / p["scl_factor"], rows, cols)
+    dev.sync_check()
     return np.stack([dev.to_matlab(U0), dev.to_matlab(U1)], axis=2)
 
 
@@ -171,6 +176,7 @@ def _tv(I_in, level_cls, p, G, smooth_last):
         if scl > 0:
             c, r = Iin[scl - 1].shape[-2:]
             Iout = dev.pyr_resize(Iout, r, c)
+    dev.sync_check()
     return dev.to_matlab(Iout)
 
 
