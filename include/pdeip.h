@@ -345,6 +345,12 @@ int pdeip_disp_assemble_gradmag_dev(void *stream, const float *It1, const float 
  * u_double: U is still the double array of the coarsest scale's first firstLoop; du_double: first inner iteration (dU = zeros). */
 int pdeip_flow_apriori_dev(void *stream, const double *Us, const float *U, const float *dU, double gammaS, double alpha,
                            double as_diff, int u_double, int du_double, int nrows, int ncols, float *CGd, float *DGd);
+/* The disparity driver's variant (DispEminND_llin_2D.m:246-248, :277-284, :291-292; param.Us, gammaS): ASCu = Us - U, ASDu = 1,
+ * gS = gammaS/alpha * exp(-(Us - U - dU)^2 / as_diff^2) with as_diff = 1.75*(1/scl_factor)^-(scl-1); the slices are added to
+ * CGd / DGd by a plain sum (NaN propagates).  exp() is the library's own fixed double algorithm (csrc/pdeip_flow.hpp det_exp),
+ * shared with the numpy statement of the driver, so results are reproducible bit for bit; not MATLAB's exp to the last ulp. */
+int pdeip_disp_apriori_dev(void *stream, const double *Us, const float *U, const float *dU, double gammaS, double alpha,
+                           double as_diff, int u_double, int du_double, int nrows, int ncols, float *CGd, float *DGd);
 /* rgb2grad (FlowEminND_llin_2D_v10.m:368-381; fstTerm 'grad'): out [.. x 2*nframes], frames 2f-1 / 2f (1-based) = the [1 0 -1]
  * differences of input frame f along x / y, replicate borders */
 int pdeip_rgb2grad_dev(void *stream, const float *in, int nrows, int ncols, int nframes, float *out);

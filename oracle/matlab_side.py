@@ -87,6 +87,43 @@ def apriori_slices(Us, U, dU, gammaS, alpha, as_diff, u_double, du_double):
     return (asc * gS).astype(F32), gS
 
 
+# exp() for the disparity driver's influence function.  libm's / MATLAB's exp are not reproducible bit for bit between a
+# host and a device, so the statement and the kernel (csrc/pdeip_flow.hpp det_exp) share ONE algorithm in IEEE double
+# arithmetic without FMA: x = k ln2 + r with |r| <= ln2/2 (two-part ln2), the Taylor polynomial of degree 13 by Horner
+# (one multiply, then one add per step), 2^k by ldexp.  Relative error < 3e-16 on [-700, 0]; "parity unpinned" w.r.t.
+# MATLAB's own exp like every other MATLAB-side stage.
+_EXP_C = [1.0 / f for f in (1, 1, 2, 6, 24, 120, 720, 5040, 40320, 362880, 3628800, 39916800, 479001600, 6227020800)]
+_LN2_HI, _LN2_LO, _INV_LN2 = 6.93147180369123816490e-01, 1.90821492927058770002e-10, 1.44269504088896338700e+00
+
+
+def det_exp(x):
+    x = np.maximum(np.asarray(x, dtype=np.float64), -700.0)
+    k = np.floor(x * _INV_LN2 + 0.5)
+    r = (x - k * _LN2_HI) - k * _LN2_LO
+    p = np.full_like(r, _EXP_C[13])
+    for c in _EXP_C[12::-1]:
+        p = p * r + c
+    return np.ldexp(p, np.where(np.isnan(k), 0.0, k).astype(np.int64))  # NaN in, NaN out (p is NaN there)
+
+
+def disp_apriori_slices(Us, U, dU, gammaS, alpha, as_diff, u_double, du_double):
+    """[ASCu.*gS, ASDu.*gS] of DispEminND_llin_2D.m:246-248, :277-284 as the single slices cat() makes of them:
+    ASCu = USap - U, ASDu = 1, gS = gammaS/alpha * exp(-(USap - U - dU).^2 / ASdiff^2).  Typing as in apriori_slices."""
+    Us = Us.astype(np.float64)
+    asd2 = as_diff * as_diff
+    k = gammaS / alpha
+    if u_double and du_double:
+        asc = Us - U.astype(np.float64)
+        t = asc - dU.astype(np.float64)
+        gS = k * det_exp(-(t * t) / asd2)
+        return (asc * gS).astype(F32), gS.astype(F32)
+    asc = (Us - U.astype(np.float64)).astype(F32) if u_double else (Us.astype(F32) - U.astype(F32)).astype(F32)
+    t = (asc - dU.astype(F32)).astype(F32)
+    arg = (-(t * t).astype(F32) / F32(asd2)).astype(F32)
+    gS = (F32(k) * det_exp(arg.astype(np.float64)).astype(F32)).astype(F32)   # single exp := the double algorithm, rounded once
+    return (asc * gS).astype(F32), gS
+
+
 def nan_append(acc, v):
     """One more slice of a nansum"""
     return np.where(np.isnan(v), acc, (acc + v).astype(F32))
@@ -190,11 +227,13 @@ def disp_assemble(term1, term2, dU, alpha):
     return outs
 
 
-def disp_level(orc, I1t0, I1t1, U, param, I2t0=None, I2t1=None):
-    """One pyramid level of DispEminND_llin_2D.m (:202-316, without the pyramid's imresize)."""
+def disp_level(orc, I1t0, I1t1, U, param, I2t0=None, I2t1=None, Us=None, as_diff=None, u_double=False):
+    """One pyramid level of DispEminND_llin_2D.m (:202-316, without the pyramid's imresize).  Us: the spatial a-priori field of
+    the scale (param.Us, float64; gammaS in param), as_diff = 1.75*(1/scl_factor)^-(scl-1), u_double: U is still MATLAB's double
+    array (coarsest scale, before its first median)."""
     U = U.astype(F32)
     Z = np.zeros_like(U)
-    for _ in range(param["firstLoop"]):
+    for first in range(param["firstLoop"]):
         X, Y = flow_coords(U, Z)
         w1 = orc.BilinInterp_2d(I1t1, X, Y)
         d = orc.FstDerivatives5(I1t0, w1)
@@ -208,8 +247,11 @@ def disp_level(orc, I1t0, I1t1, U, param, I2t0=None, I2t1=None):
                 d2 = orc.FstDerivatives5(I2t0, w2)
                 t2 = (d2[0], d2[1], param["b2"])
         dU = np.zeros_like(U)
-        for _ in range(param["secondLoop"]):
+        for k in range(param["secondLoop"]):
             CuGd, DuGd = disp_assemble(t1, t2, dU, param["alpha"])
+            if Us is not None:   # plain sum(): one more slice, NaN propagates (:291-292)
+                c, d = disp_apriori_slices(Us, U, dU, param["gammaS"], param["alpha"], as_diff, u_double and first == 0, k == 0)
+                CuGd, DuGd = (CuGd + c).astype(F32), (DuGd + d).astype(F32)
             wW, wN, wE, wS = orc.DdiffWeights((U + dU).astype(F32), 0.00001)
             dU = orc.Disp_sor_llin4_2d(U, dU, CuGd, DuGd, wW, wN, wE, wS, param["iter"], param["omega"], solver=param["solver"],
                                        order=param["order"])

@@ -190,6 +190,21 @@ int orc_oflow_sor_elin4_rb_omp(float *U, float *V, const float *M, const float *
     return used;
 }
 
+/* Copies a [ncols][nrows] plane with the thread-to-column assignment of orc_oflow_sor_elin4_rb_omp, so that a destination
+ * whose pages have not been touched yet ends up spread over the NUMA nodes the way the sweep will read it (first touch).
+ * Only used to prepare the buffers of the all-core CPU comparator. */
+void orc_plane_copy_omp(float *dst, const float *src, int nrows, int ncols, int nthreads)
+{
+    int j;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#else
+    (void)nthreads;
+#endif
+    for (j = 0; j < ncols; j++) memcpy(dst + (size_t)j * nrows, src + (size_t)j * nrows, (size_t)nrows * sizeof(float));
+}
+
 /* Neighbourhood term of the late-linearization solvers (opticalflowSolvers.c:563-580):
  * ((dW+W-c)*wW + (dE+E-c)*wE) + ((dN+N-c)*wN + (dS+S-c)*wS). */
 static float llin_neigh(const float *U, const float *dU, size_t pos, int nrows, const float *wW,

@@ -48,6 +48,8 @@ int orc_oflow_sor_elin4_rb_omp(float *U, float *V, const float *M, const float *
                                const float *Dv, const float *wW, const float *wN, const float *wE, const float *wS,
                                int nrows, int ncols, int iter, float omega, int nthreads);
 
+void orc_plane_copy_omp(float *dst, const float *src, int nrows, int ncols, int nthreads);
+
 /* opticalflowSolvers.c:504-680 (GS_SOR_llin4_2d) == :1487-1667 (GS_SOR_llin8_2d); dU,dV in place. */
 void orc_oflow_sor_llin4(const float *U, const float *V, float *dU, float *dV, const float *M,
                          const float *Cu, const float *Cv, const float *Du, const float *Dv,

@@ -90,6 +90,7 @@ SIGNATURES = {
     "pdeip_sym_flow_terms_dev": [_P, _P, _P, _I, _I, _P, _P, _P, _P],
     "pdeip_sym_assemble_dev": [_P] * 7 + [_I] + [_P] * 5 + [_F, _F, _F, ctypes.c_double, ctypes.c_double, _I, _I, _I, _P, _P],
     "pdeip_flow_apriori_dev": [_P, _P, _P, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _I, _I, _I, _P, _P],
+    "pdeip_disp_apriori_dev": [_P, _P, _P, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _I, _I, _I, _P, _P],
     "pdeip_pyr_resize_dev": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pdeip_pyr_smooth_dev": [_P, _P, _I, _I, _I, _P, _I, _P],
     "pdeip_flow_opdiffweights_dev": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],

@@ -118,6 +118,50 @@ __global__ void k_flow_apriori(float *CGd, float *DGd, const double *Us, const f
     DGd[pos] = d;
 }
 
+// exp() of the disparity driver's influence function: the algorithm of oracle/matlab_side.py det_exp, operation for operation
+// (IEEE double, no FMA: this file is compiled -ffp-contract=off), so host statement and kernel agree bit for bit.
+__device__ __forceinline__ double det_exp(double x)
+{
+    constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10, INV_LN2 = 1.44269504088896338700e+00;
+    constexpr double C[14] = {1.0 / 1, 1.0 / 1, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                              1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+    x = x < -700.0 ? -700.0 : x; // NaN stays NaN (the comparison is false)
+    const double k = floor(x * INV_LN2 + 0.5);
+    const double r = (x - k * LN2_HI) - k * LN2_LO;
+    double p = C[13];
+#pragma unroll
+    for (int i = 12; i >= 0; --i) p = p * r + C[i];
+    return ldexp(p, (int)k);
+}
+
+// Spatial a-priori slice of the DISPARITY assembly (DispEminND_llin_2D.m:246-248, :277-284, :291-292):
+//   ASCu = USap - U;  ASDu = 1;  gS = gammaS/alpha * exp(-(USap - U - dU).^2 / ASdiff^2)
+// appended to CuGd / DuGd by the driver's plain sum() (a NaN propagates).  Typing as in k_flow_apriori; the single-precision
+// exp is defined as the double algorithm above rounded once.
+__global__ void k_disp_apriori(float *CGd, float *DGd, const double *Us, const float *U, const float *dU, double gammaS, double alpha,
+                               double asd2, int u_double, int du_double, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    const double k = gammaS / alpha;
+    float cS, dS;
+    if (u_double && du_double) {
+        const double asc = Us[pos] - (double)U[pos];
+        const double t = asc - (double)dU[pos];
+        const double gS = k * det_exp(-(t * t) / asd2);
+        cS = (float)(asc * gS);
+        dS = (float)gS;
+    } else {
+        const float asc = u_double ? (float)(Us[pos] - (double)U[pos]) : (float)Us[pos] - U[pos];
+        const float t = asc - dU[pos];
+        const float arg = -(t * t) / (float)asd2;
+        const float gS = (float)k * (float)det_exp((double)arg);
+        cS = asc * gS;
+        dS = gS;
+    }
+    CGd[pos] = CGd[pos] + cS;
+    DGd[pos] = DGd[pos] + dS;
+}
+
 // Disparity twin of the assembly (matlab/disparity/DispEminND_llin_2D.m:258-293): one unknown, and a plain
 // sum() over the channels -- a NaN (out-of-range warp) propagates into CuGd/DuGd, where the solver's
 // isnan(Cu) test picks it up (disparitySolvers.c:66).

@@ -188,6 +188,17 @@ extern "C" int pdeip_flow_apriori_dev(void *stream, const double *Us, const floa
     return PDEIP_OK;
 }
 
+extern "C" int pdeip_disp_apriori_dev(void *stream, const double *Us, const float *U, const float *dU, double gammaS, double alpha,
+                                      double as_diff, int u_double, int du_double, int nrows, int ncols, float *CGd, float *DGd)
+{
+    RC(check_dims("pdeip_disp_apriori_dev", nrows, ncols, 1));
+    if (!Us || !U || !dU || !CGd || !DGd) return set_err(PDEIP_ERR_ARG, "pdeip_disp_apriori_dev: null plane");
+    hipLaunchKernelGGL(k_disp_apriori, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), CGd, DGd, Us, U, dU, gammaS,
+                       alpha, as_diff * as_diff, u_double, du_double, nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_rgb2grad_dev(void *stream, const float *in, int nrows, int ncols, int nframes, float *out)
 {
     RC(check_dims("pdeip_rgb2grad_dev", nrows, ncols, nframes));

@@ -424,6 +424,15 @@ def flow_apriori(Us, U, dU, gammaS, alpha, as_diff, u_double, du_double, CGd, DG
               int(bool(u_double)), int(bool(du_double)), nrows, ncols, CGd.data_ptr(), DGd.data_ptr())
 
 
+def disp_apriori(Us, U, dU, gammaS, alpha, as_diff, u_double, du_double, CGd, DGd):
+    """Adds the disparity driver's spatial a-priori slice (DispEminND_llin_2D.m:277-292, exp influence function) to CGd / DGd."""
+    _chk(U, dU, CGd, DGd)
+    _chk64(Us)
+    nrows, ncols, _ = _dims(U)
+    capi.call("pdeip_disp_apriori_dev", _stream(), Us.data_ptr(), U.data_ptr(), dU.data_ptr(), float(gammaS), float(alpha), float(as_diff),
+              int(bool(u_double)), int(bool(du_double)), nrows, ncols, CGd.data_ptr(), DGd.data_ptr())
+
+
 # ---- the drivers' image pyramid on the device (csrc/pdeip_pyr.hpp; definitions in pyramid.py) -------------
 
 def pyr_resize(I, nrows_out, ncols_out, method="bilinear"):

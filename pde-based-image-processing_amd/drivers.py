@@ -119,15 +119,32 @@ def FlowEminNDFASFMG_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **pa
 DISP_DEFAULTS = dict(alpha=0.042, gammaS=0.005, omega=1.9, firstLoop=4, secondLoop=6, iter=4, b1=1.48, b2=0.29, scl_factor=0.75, solver=2)   # DispEminND_llin_2D.m:51-63
 
 
-def DispEminND_llin_2D(Il, Ir, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, **param):
+def DispEminND_llin_2D(Il, Ir, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, Us=None, **param):
+    """Us: param.Us of the reference, a spatial a-priori disparity map at full resolution (double; NaN = no constraint there,
+    zeroed as DispEminND_llin_2D.m:170 does).  It is scaled down with the pyramid (:172-176), starts the coarsest scale (:178;
+    there MATLAB's U is that double array itself -- here its float32 rounding, a 1e-8 relative difference in the first
+    firstLoop of the coarsest scale) and enters every assembly through the exp influence function (:277-292)."""
     p = dict(DISP_DEFAULTS, **param)
     p["sndTerm"] = sndTerm.lower()
     P0, P1 = pyramid.build_dev(dev.to_device(_c3(Il) / np.float32(255)), dev.to_device(_c3(Ir) / np.float32(255)), p["scl_factor"], 10)
     level = fl.DispLlinLevel(p, mode=mode)
     U = _zeros_like_plane(P0[-1])
+    USap = None
+    if Us is not None:
+        us = np.array(Us, dtype=np.float64)
+        us[np.isnan(us)] = 0.0
+        USap = [us]
+        for scl in range(1, len(P0)):
+            cols, rows = P0[scl].shape[-2:]
+            USap.append(pyramid.resize(USap[-1] * p["scl_factor"], rows, cols, "bilinear", out_dtype=np.float64))
+        U = dev.to_device(USap[-1].astype(np.float32))
     for scl in range(len(P0) - 1, -1, -1):
         (a0, a1), (b0, b1) = _terms(P0[scl], P1[scl], fstTerm, sndTerm)
-        U = level.run(a0, a1, U, b0, b1)
+        if USap is None:
+            U = level.run(a0, a1, U, b0, b1)
+        else:
+            us64 = torch.from_numpy(np.ascontiguousarray(USap[scl].T)).to(U.device)
+            U = level.run(a0, a1, U, b0, b1, Us=us64, as_diff=1.75 * p["scl_factor"] ** scl, u_double=(scl == len(P0) - 1))
         if scl > 0:
             cols, rows = P0[scl - 1].shape[-2:]
             U = _up(U, 1.0 / p["scl_factor"], rows, cols)

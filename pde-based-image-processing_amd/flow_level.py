@@ -133,7 +133,9 @@ class DispLlinLevel:
     def __init__(self, param, mode=capi.MODE_EXACT_ORDER):
         self.p, self.mode = dict(param), mode
 
-    def run(self, I1t0, I1t1, U, I2t0=None, I2t1=None):
+    def run(self, I1t0, I1t1, U, I2t0=None, I2t1=None, Us=None, as_diff=None, u_double=False):
+        """Us: optional spatial a-priori disparity of this scale (float64, param.Us with gammaS in param; DispEminND_llin_2D.m:
+        246-248, :277-292), as_diff = 1.75*(1/scl_factor)^-(scl-1), u_double: U is still MATLAB's double array (coarsest scale)."""
         p = self.p
         new = lambda like: torch.empty_like(like)
         X, Y, zero = new(U), new(U), torch.zeros_like(U)
@@ -144,7 +146,7 @@ class DispLlinLevel:
         wts = [new(U) for _ in range(4)]  # wW, wN, wE, wS
         U, Un = U.clone(), new(U)
         solve = dev.disp_sor_llin4 if int(p["solver"]) == 1 else dev.disp_alr_llin4
-        for _ in range(int(p["firstLoop"])):
+        for first in range(int(p["firstLoop"])):
             dev.flow_coords(U, zero, X, Y)                           # single(X+U), single(Y)
             dev.warp_bilinear(I1t1, X, Y, w1)
             dev.fst_derivatives5(I1t0, w1, *d1)
@@ -158,8 +160,10 @@ class DispLlinLevel:
                     dev.fst_derivatives5(I2t0, w2, *d2)
                     t2 = (d2[0], d2[1], p["b2"])
             dU = torch.zeros_like(U)
-            for _ in range(int(p["secondLoop"])):
+            for k in range(int(p["secondLoop"])):
                 dev.disp_assemble(t1, t2, dU, p["alpha"], CuGd, DuGd)
+                if Us is not None:
+                    dev.disp_apriori(Us, U, dU, p["gammaS"], p["alpha"], as_diff, u_double and first == 0, k == 0, CuGd, DuGd)
                 dev.add(U, dU, S)
                 dev.diffweights6(S, 0.00001, *wts)
                 solve(U, dU, CuGd, DuGd, *wts, int(p["iter"]), float(p["omega"]), self.mode)

@@ -85,9 +85,9 @@ def _resize_matrix(n_in, n_out, method="bilinear"):
     return M
 
 
-def resize(I, out_rows, out_cols, method="bilinear"):
+def resize(I, out_rows, out_cols, method="bilinear", out_dtype=np.float32):
     """imresize(I, [out_rows out_cols], method); method 'bilinear' or 'bicubic' (imresize's default).  Rows first, then
-    columns, taps summed left to right in double, rounded to single once."""
+    columns, taps summed left to right in double, rounded to single once (out_dtype=np.float64: a double array stays double)."""
     I3 = (I if I.ndim == 3 else I[:, :, None]).astype(np.float64)
     ri, rw = _resize_taps(I3.shape[0], out_rows, method)
     ci, cw = _resize_taps(I3.shape[1], out_cols, method)
@@ -97,7 +97,7 @@ def resize(I, out_rows, out_cols, method="bilinear"):
     out = cw[:, 0][None, :, None] * T1[:, ci[:, 0]]
     for k in range(1, ci.shape[1]):
         out = out + cw[:, k][None, :, None] * T1[:, ci[:, k]]
-    return out.astype(np.float32).reshape((out_rows, out_cols) + I.shape[2:])
+    return out.astype(out_dtype).reshape((out_rows, out_cols) + I.shape[2:])
 
 
 def build(I0, I1, scl_factor=0.75, min_size=20, G=None):

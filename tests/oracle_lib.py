@@ -22,6 +22,7 @@ _P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _SIGS = {
     "orc_oflow_sor_elin4": [_P] * 11 + [_I, _I, _I, _F, _I],
     "orc_oflow_sor_elin4_rb_omp": [_P] * 11 + [_I, _I, _I, _F, _I],
+    "orc_plane_copy_omp": [_P, _P, _I, _I, _I],
     "orc_oflow_sor_llin4": [_P] * 13 + [_I, _I, _I, _F, _I],
     "orc_oflow_res_elin4": [_P] * 13 + [_I, _I, _I],
     "orc_oflow_lhs_elin4": [_P] * 11 + [_I, _I, _I],

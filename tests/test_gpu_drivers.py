@@ -108,3 +108,19 @@ def test_tv_drivers_denoise(pdeip):
         assert rms(out) < 0.6 * rms(noisy), (fn.__name__, rms(out), rms(noisy))
     out = D.TVdenoise8(np.stack([noisy, noisy[::-1]], axis=2), mode=pdeip.MODE_RED_BLACK, solver=1)
     assert out.shape == (90, 120, 2) and rms(out[:, :, 0]) < 0.7 * rms(noisy)
+
+
+def test_disparity_driver_with_spatial_apriori(pdeip):
+    """param.Us of DispEminND_llin_2D: a (wrong) a-priori disparity pulls the result towards it where gammaS is large, a
+    correct one leaves the recovered shift alone; NaN entries mean "no constraint"."""
+    D = drv()
+    left, right = _stereo_pair()
+    base = D.DispEminND_llin_2D(left, right, "rgb", "none")
+    Us = np.full(left.shape[:2], -3.0)
+    Us[:5, :] = np.nan
+    good = D.DispEminND_llin_2D(left, right, "rgb", "none", Us=Us)
+    assert good.shape == base.shape and np.isfinite(good).all()
+    assert abs(float(np.median(good[10:-10, 20:-20])) + 3.0) < 0.3
+    pulled = D.DispEminND_llin_2D(left, right, "rgb", "none", Us=np.full(left.shape[:2], -2.0), gammaS=5.0)
+    m = float(np.median(pulled[10:-10, 20:-20]))
+    assert -3.0 < m < -1.9 and abs(m + 2.0) < abs(float(np.median(base[10:-10, 20:-20])) + 2.0), m

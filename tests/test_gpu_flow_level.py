@@ -439,3 +439,46 @@ def test_resident_levels_with_spatial_apriori(pdeip, oracle, solver, mode, order
     gU, gV = fl.FlowAdLevel(param, mode=mode).run(d0, d1, dev.to_device(U0), dev.to_device(V0), d0, Us=t64(Us), Vs=t64(Vs), as_diff=1.5,
                                                   u_double=u_double)
     same(dev.to_matlab(gU), wU, "anisotropic a-priori level U"); same(dev.to_matlab(gV), wV, "anisotropic a-priori level V")
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (6, 90)])
+def test_disparity_apriori_slice(pdeip, shape):
+    """k_disp_apriori vs the numpy statement: the exp influence function through the shared deterministic exp, four typing regimes."""
+    import torch
+    ms, dev = matlab_side(), sub("device")
+    rng = np.random.default_rng(shape[0] + 1)
+    f = lambda lo, hi: np.asfortranarray(rng.uniform(lo, hi, size=shape).astype(np.float32))
+    U, dU, C0, D0 = f(-6, 6), f(-.5, .5), f(-1, 1), f(0, 2)
+    C0[1, 2] = np.nan
+    Us = np.asfortranarray(rng.uniform(-6, 6, size=shape))
+    dUs = torch.from_numpy(np.ascontiguousarray(Us.T)).cuda()
+    for u_double in (False, True):
+        for du_double in (False, True):
+            dUx = np.zeros(shape, np.float32) if du_double else dU
+            gC, gD = dev.to_device(C0), dev.to_device(D0)
+            dev.disp_apriori(dUs, dev.to_device(U), dev.to_device(dUx), 0.005, 0.15, 1.75, u_double, du_double, gC, gD)
+            c, d = ms.disp_apriori_slices(Us, U, dUx, 0.005, 0.15, 1.75, u_double, du_double)
+            wC, wD = (C0 + c).astype(np.float32), (D0 + d).astype(np.float32)
+            got = dev.to_matlab(gC)
+            assert np.array_equal(np.isnan(got), np.isnan(wC))
+            same(got, wC, "disparity a-priori Cu (u_double=%s du_double=%s)" % (u_double, du_double))
+            same(dev.to_matlab(gD), wD, "disparity a-priori Du (u_double=%s du_double=%s)" % (u_double, du_double))
+            assert float(np.nanmax(d)) > 0 and float(np.nanmin(d)) < 0.9 * float(np.nanmax(d))  # the exponential really varies
+
+
+@pytest.mark.parametrize("solver,mode,order,u_double", [(2, 0, 0, True), (1, 1, 1, False)])
+def test_disparity_level_with_spatial_apriori(pdeip, oracle, solver, mode, order, u_double):
+    import torch
+    ms, dev, fl = matlab_side(), sub("device"), sub("flow_level")
+    I0, I1 = frames(91, 40, 52, 2)
+    rng = np.random.default_rng(13)
+    Us = np.asfortranarray(rng.uniform(-1, 1, size=(40, 52)))
+    U0 = np.asfortranarray(Us.astype(np.float32)) if not u_double else np.asfortranarray(np.round(Us * 4) / 4).astype(np.float32)
+    param = dict(firstLoop=2, secondLoop=2, iter=3, omega=1.9 if solver == 2 else 1.0, solver=solver, alpha=0.15, b1=0.25, b2=0.72, gammaS=0.005,
+                 order=order)
+    want = ms.disp_level(oracle, I0, I1, U0, param, Us=Us, as_diff=1.75, u_double=u_double)
+    t64 = torch.from_numpy(np.ascontiguousarray(Us.T)).cuda()
+    got = fl.DispLlinLevel(param, mode=mode).run(dev.to_device(I0), dev.to_device(I1), dev.to_device(U0), Us=t64, as_diff=1.75, u_double=u_double)
+    same(dev.to_matlab(got), want, "disparity level with a-priori")
+    plain = ms.disp_level(oracle, I0, I1, U0, param)
+    assert not np.array_equal(plain, want)  # the term acts

@@ -241,3 +241,11 @@ def test_pyramid_masks_and_smoothing():
     assert np.allclose(py.smooth(flat, py.gaussian(7, 2.0)), 0.7, atol=1e-6)
     P0, P1 = py.build(np.random.default_rng(0).random((40, 50)).astype(np.float32), np.zeros((40, 50), np.float32), 0.75, 10, py.gaussian(3, 1.0))
     assert [p.shape for p in P0] == [(40, 50), (30, 38), (23, 29), (18, 22), (14, 17), (11, 13), (9, 10)]
+
+
+def test_deterministic_exp_is_exp():
+    """The influence function's exp (shared by the numpy statement and the kernel) is exp to ~2 ulp of double on its domain."""
+    x = np.concatenate([-np.logspace(-12, 2.8, 4000), [0.0, -1e-300, -699.9, -5000.0]])
+    got, want = ms.det_exp(x), np.exp(np.maximum(x, -700.0))
+    assert np.all(np.abs(got - want) <= 4e-16 * want)
+    assert ms.det_exp(0.0) == 1.0 and np.isnan(ms.det_exp(np.nan))
