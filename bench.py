@@ -227,13 +227,17 @@ def main():
             dev.oflow_sor_elin4(a[0], a[1], *coef, ITER, OMEGA, capi.MODE_RED_BLACK, out=b)
             cur[0] ^= 1
     else:
-        def step_rb():
-            solver.solve([U, V], coef, ITER, OMEGA)
+        state = [[U, V]]
+
+        def step_rb():  # the slab form of the same thing: the solver returns the plane set that holds the iterate now
+            state[0] = solver.solve_pingpong(state[0], coef, ITER, OMEGA)
 
     dt, ms, nl = timed(step_rb, args.steps, args.warmup)
     value = args.steps * ITER / dt
     if world == 1:
         U, V = sets[cur[0]]
+    else:
+        U, V = state[0]
     if not (bool(torch.isfinite(U).all()) and bool(torch.isfinite(V).all())):
         raise SystemExit("bench.py: the iterate is not finite after the timed loop (the workload must converge)")
     # per launch: this rank's pixels (owned + halo columns are all relaxed by the launch; count owned only)

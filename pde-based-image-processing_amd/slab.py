@@ -120,9 +120,12 @@ class SlabDomain:
         return None
 
 
-def _hip_elin4(it, coef, n_sweeps, omega, col0):
+def _hip_elin4(it, coef, n_sweeps, omega, col0, out=None):
     from . import capi, device
-    device.oflow_sor_elin4(it[0], it[1], *coef, n_sweeps, omega, mode=capi.MODE_RED_BLACK, col0=col0)
+    device.oflow_sor_elin4(it[0], it[1], *coef, n_sweeps, omega, mode=capi.MODE_RED_BLACK, col0=col0, out=out)
+
+
+_hip_elin4.out_of_place = True  # relaxes `it` into `out` when given: no device-to-device copy after an odd number of launches
 
 
 def _hip_llin4(it, coef, n_sweeps, omega, col0):
@@ -160,6 +163,7 @@ class SlabSolver:
         self.dom, self.k = domain, sweeps_per_exchange
         self.sweep_fn = sweep_fn if sweep_fn is not None else HIP_SWEEPS[kind]
         self.since = None  # sweeps relaxed since the halo was last refreshed; None: unknown, exchange first
+        self._alt = None   # second plane set of the out-of-place form (solve_pingpong)
 
     def invalidate(self):
         """The iterate planes were changed from outside (or are different tensors): refresh the halo before the next sweep."""
@@ -178,3 +182,28 @@ class SlabSolver:
             self.sweep_fn(iterate, coef, k, omega, self.dom.col0)
             self.since += k
             done += k
+
+    def solve_pingpong(self, iterate, coef, iters, omega):
+        """solve() for sweep functions that can write their result to a second plane set (`out_of_place`): every run of sweeps
+        relaxes the current planes into the other set, so no launch sequence ends with a device-to-device copy.  Returns the
+        planes that hold the iterate now -- the caller carries them into the next call (the halo budget goes with them)."""
+        if not getattr(self.sweep_fn, "out_of_place", False):
+            self.solve(iterate, coef, iters, omega)
+            return iterate
+        if self._alt is None or any(a.shape != b.shape for a, b in zip(self._alt, iterate)) or any(a is b for a in self._alt for b in iterate):
+            self._alt = [torch.empty_like(t) for t in iterate]
+        cur, other = list(iterate), self._alt
+        done = 0
+        while done < iters:
+            room = 0 if self.since is None else self.k - self.since
+            if room <= 0:
+                self.dom.exchange(cur)
+                self.since, room = 0, self.k
+            k = min(room, iters - done)
+            self.sweep_fn(cur, coef, k, omega, self.dom.col0, out=other)
+            cur, other = other, cur
+            self.since += k
+            done += k
+        self._alt = other
+        return cur
+
