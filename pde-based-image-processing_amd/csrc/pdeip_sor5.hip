@@ -9,6 +9,7 @@
 #include "pdeip_sor_exact.hpp"
 #include "pdeip_sor_rb.hpp"
 #include "pdeip_sor_rbp.hpp"
+#include "pdeip_sor_small.hpp"
 
 using namespace pdeip;
 
@@ -186,6 +187,23 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         return PDEIP_OK;
     }
 
+    // a frame that fits one workgroup's LDS: every sweep of the call in one launch (pdeip_sor_small.hpp); PDEIP_RB_SMALL=0 disables
+    const bool small_enabled = env_int("PDEIP_RB_SMALL", 1) != 0; // read per call: the tests switch it
+    if (small_enabled && SmallLayout<Mdl>::fits(nrows, ncols)) {
+        const size_t lds = SmallLayout<Mdl>::lds_bytes(nrows, ncols);
+        RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_small<Mdl>), lds));
+        for (int f = 0; f < NIT; f++) {
+            P.it_in[f] = P.it_out[f];
+            if (dst) P.it_out[f] = dst[f];
+        }
+        SweepTimer timer(s);
+        hipLaunchKernelGGL(k_sor_small<Mdl>, dim3((unsigned)nframes), dim3(SMALL_THREADS), lds, s, P, nrows, ncols, iter, omega, col0, n);
+        timer.stop(1);
+        g.last_launches++;
+        HIPCHK(hipGetLastError());
+        return PDEIP_OK;
+    }
+
     // red-black: ping-pong between the caller's buffers and a scratch copy
     float *scratch = nullptr;
     int rc = ws_get(WS_PING, (size_t)NIT * n * nframes * sizeof(float), &scratch);
@@ -211,7 +229,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     const int TJ1 = pick_rb_tj(nrows, ncols), TJ2 = fuse ? pick_rb2_tj<Mdl>(nrows, ncols, nframes, ntiles_r) : TJ1;
     // Four sweeps per launch where the rings fit in LDS (pdeip_sor_rbp.hpp): the wave pipeline.  PDEIP_RB_PIPE=0 disables it.
     constexpr int PS = 4;
-    static const bool pipe_enabled = env_int("PDEIP_RB_PIPE", 1) != 0;
+    const bool pipe_enabled = env_int("PDEIP_RB_PIPE", 1) != 0; // read per call: the tests switch it
     // single-field models run one wave per sweep (one wave per SIMD): the pipeline only pays on large frames there
     const bool pipe = pipe_enabled && fuse && vec && RbpLayout<Mdl, PS>::FITS && (RbpLayout<Mdl, PS>::NW == 2 || n >= (size_t)1 << 21);
     // launches of this call (the buffer chain below needs the count up front)

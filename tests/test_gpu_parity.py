@@ -222,3 +222,40 @@ def test_out_of_place_other_models(pdeip, oracle):
         capi.call("pdeip_pde_sor4_dev_to", st(), d["X"].data_ptr(), o.data_ptr(), *[d[k].data_ptr() for k in ("TRACE", "B", "wW", "wN", "wE", "wS")],
                   120, 96, 2, it, 1.75, 1, 0)
         assert pb.bit_equal(dev.to_matlab(o), oracle.pde_sor4(*f.values(), it, 1.75, oracle.COLOUR))
+
+
+@pytest.mark.parametrize("small,pipe", [("1", "1"), ("0", "1"), ("0", "0")])
+@pytest.mark.parametrize("shape", [(24, 40), (33, 29), (68, 120), (64, 96), (100, 48), (17, 30), (9, 15), (3, 3), (4, 5)])
+def test_red_black_kernel_families_agree(pdeip, oracle, shape, small, pipe):
+    """The three red-black kernel families -- one workgroup per small frame (k_sor_small), the four-sweep wave pipeline
+    (k_sor_rbp) and the one/two-sweep marches (k_sor_rb) -- are selected by frame size; switched by hand they must all give
+    the oracle's colour-ordered result on the same frames, every 5-point model, iter 1..9, NaN-laced data."""
+    import os
+
+    api = pdeip.mex_api
+    old = {k: os.environ.get(k) for k in ("PDEIP_RB_SMALL", "PDEIP_RB_PIPE")}
+    os.environ["PDEIP_RB_SMALL"], os.environ["PDEIP_RB_PIPE"] = small, pipe
+    api.set_mode(1)
+    try:
+        f = np.float32
+        for it in (1, 4, 9):
+            p = pb.elin4(961, *shape, nan_frac=0.02)
+            for g, w in zip(api.Oflow_sor_elin4_2d(*p.values(), f(it), f(1.9), f(1)), oracle.Oflow_sor_elin4_2d(*p.values(), it, 1.9, order=oracle.COLOUR)):
+                assert pb.bit_equal(g, w), "elin4 %s it=%d small=%s pipe=%s: %s" % (shape, it, small, pipe, pb.describe_mismatch(g, w))
+            q = pb.llin4(962, *shape, nan_frac=0.02)
+            for g, w in zip(api.Oflow_sor_llin4_2d(*q.values(), f(it), f(1.9), f(1)), oracle.Oflow_sor_llin4_2d(*q.values(), it, 1.9, order=oracle.COLOUR)):
+                assert pb.bit_equal(g, w), "llin4 %s it=%d" % (shape, it)
+            d = pb.disp4(963, *shape, nan_frac=0.02)
+            assert pb.bit_equal(api.Disp_sor_llin4_2d(*d.values(), f(it), f(1.9), f(1)), oracle.Disp_sor_llin4_2d(*d.values(), it, 1.9, order=oracle.COLOUR))
+            e = pb.pde4(964, *shape, nframes=3, nan_frac=0.02)
+            assert pb.bit_equal(api.PDEsolver4(*e.values(), f(it), f(1.75), f(1)), oracle.PDEsolver4(*e.values(), it, 1.75, order=oracle.COLOUR))
+            y = pb.dispsym4(965, *shape, nan_frac=0.02)
+            for g, w in zip(api.Disp_sor_llin_sym4_2d(*y.values(), f(it), f(1.9), f(1)), oracle.Disp_sor_llin_sym4_2d(*y.values(), it, 1.9, order=oracle.COLOUR)):
+                assert pb.bit_equal(g, w)
+    finally:
+        api.set_mode(0)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
