@@ -35,21 +35,40 @@ constexpr int RBP_OWN_ROWS = 240; // 60 storing lanes x 4 rows; lanes 0,1 and 62
 template <class Mdl, int S> struct RbpLayout {
     static constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NCF = Mdl::NCF;
     static constexpr int NRING = NCF + NRO;            // planes every sweep wave reads: coefficients, then read-only fields
-    static constexpr int P = 3;                        // DMA lead in steps
-    // K-ring columns.  Column group g lands before step g; its last reader is wave S-1 taking it as "column x-1" in step
-    // g + 3(S-1) + 2; its slot is refilled by group g + NK, issued in step g + NK - P: one barrier later at the earliest.
-    static constexpr int NK = P + 3 * (S - 1) + 3;
-    static constexpr int NO = P + 1;                   // O-ring columns
     static constexpr int COL = 256;                    // floats per plane column (64 lanes x 4 rows)
+    static constexpr int GROUP = NRING + NIT;          // LDS-DMA instructions per column
+    // K-ring columns for a DMA lead of p steps.  Column group g lands before step g; wave s reads it (as "column x") in step
+    // g + 3s + 1 and keeps it in registers for the step after; its slot is refilled by group g + NK, issued in step
+    // g + NK - p, which has to come after wave S-1's read.
+    static constexpr int nk_for(int p) { return p + 3 * (S - 1) + 2; }
+    static constexpr size_t lds_for(int p)
+    {
+        return (size_t)(nk_for(p) * NRING * COL + (p + 1) * NIT * COL + (S - 1) * 2 * NIT * COL) * sizeof(float);
+    }
+    // DMA lead in steps: what is in flight per CU (lead x GROUP KiB) has to cover an HBM round trip at the rate the
+    // kernel consumes it, so take the longest lead the 160 KiB of LDS and the 6-bit vmcnt counter allow (at most 8)
+    static constexpr int pick_lead()
+    {
+        int best = 0;
+        for (int p = 1; p <= 8; p++)
+            if (lds_for(p) <= (size_t)160 * 1024 && (p - 1) * GROUP <= 63) best = p;
+        return best;
+    }
+#ifdef RBP_LEAD
+    static constexpr int P = RBP_LEAD;
+#else
+    static constexpr int P = pick_lead();
+#endif
+    static constexpr int NK = nk_for(P);
+    static constexpr int NO = P + 1;                   // O-ring columns
     static constexpr int K_FLOATS = NK * NRING * COL;
     static constexpr int O_FLOATS = NO * NIT * COL;
     static constexpr int H_FLOATS = (S - 1) * 2 * NIT * COL;
     static constexpr size_t LDS_BYTES = (size_t)(K_FLOATS + O_FLOATS + H_FLOATS) * sizeof(float);
-    static constexpr int GROUP = NRING + NIT;          // LDS-DMA instructions per column
     static constexpr int NW = (NIT == 2) ? 2 : 1;      // waves per sweep: the two fields of a coupled model are relaxed by two waves
     static constexpr int THREADS = 64 * (S * NW + 1);  // sweep waves + the loader wave
     static constexpr int HALO = 2 * S;                 // columns per side
-    static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && (P - 1) * GROUP <= 63;
+    static constexpr bool FITS = P >= 3 && LDS_BYTES <= 160 * 1024 && (P - 1) * GROUP <= 63;
     // wave S-1 finishes column j1-1 in step TJ + 5S - 2 (two warm-up steps, 2S halo columns, three columns of lag per sweep)
     __host__ __device__ static constexpr int nsteps(int tj) { return tj + 5 * S - 1; }
 };
@@ -152,10 +171,14 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
 
     // Three-column windows.  The step below is instantiated three times with the roles rotated, so no window ever moves:
     // O*: the previous sweep's result at x-1, x, x+1, ALL fields (centre values of the other fields feed the coupling term);
-    // R*: own fields after this sweep's red half at x-2, x-1, x.  Coefficients are not windowed: each half-sweep reads its
-    // column from the K ring (LDS has the bandwidth; a nine-wave workgroup caps a wave at 168 VGPRs).
+    // R*: own fields after this sweep's red half at x-2, x-1, x.
     float O0[NIT][4], O1[NIT][4], O2[NIT][4], R0[NF][4], R1[NF][4], R2[NF][4];
     float Q2[NRO1][4], Q1[NRO1][4], Q0[NRO1][4], Qn[NRO1][4]; // read-only fields at x-2, x-1, x, x+1 (moved: four columns, few planes)
+    float KA[NCF][4], KB[NCF][4]; // coefficients of columns x-1 and x, roles alternating: each column is read from the K ring once
+#pragma unroll
+    for (int f = 0; f < NCF; f++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) KA[f][e] = KB[f][e] = 0.0f;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
 #pragma unroll
@@ -170,12 +193,10 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
     int ki = ((-3 * s - 1) % L::NK + L::NK) % L::NK, oi = 0, hp = 1;
 
     auto step = [&](int t, float (&Om)[NIT][4], float (&Oc)[NIT][4], float (&Op)[NIT][4], float (&Rpp)[NF][4], float (&Rp)[NF][4],
-                    float (&Rc)[NF][4]) __attribute__((always_inline)) {
+                    float (&Rc)[NF][4], const float (&Kp)[NCF][4], float (&Kc)[NCF][4]) __attribute__((always_inline)) {
         const int x = xbase + t - 3 * s; // this wave's red column; black on x-1
         // ---- take in column x+1 of the previous sweep's result, and the coefficients of columns x and x-1 ----
-        float *const ks = Kring + (size_t)ki * NRING * COL;                                   // column x
-        const float *const kps = Kring + (size_t)(ki == 0 ? L::NK - 1 : ki - 1) * NRING * COL; // column x-1
-        float Kc[NCF][4], Kp[NCF][4];
+        float *const ks = Kring + (size_t)ki * NRING * COL; // column x; column x-1 (Kp) is the Kc of the previous step, kept in registers
         {
             const float *src = (s == 0) ? Oring + (size_t)oi * NIT * COL : Hring + (size_t)((s - 1) * 2 + hp) * NIT * COL;
 #pragma unroll
@@ -194,8 +215,6 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
                     // read-only fields ride one column ahead of the coefficients (the red half reads them at x+1)
                     rbp_lds_read(Qn[f], Kring + (size_t)(ki + 1 == L::NK ? 0 : ki + 1) * NRING * COL + (NCF + (NRO > 0 ? f : 0)) * COL, lane);
                 }
-#pragma unroll
-            for (int f = 0; f < NCF; f++) rbp_lds_read(Kp[f], kps + f * COL, lane);
         }
         const int p = (x + col0) & 1;
 
@@ -322,10 +341,14 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
     };
 
     rbp_barrier(); // group 0 is in LDS
-    for (int t = 0; t < nsteps; t += 3) {
-        step(t, O0, O1, O2, R0, R1, R2);
-        if (t + 1 < nsteps) step(t + 1, O1, O2, O0, R1, R2, R0);
-        if (t + 2 < nsteps) step(t + 2, O2, O0, O1, R2, R0, R1);
+    // the O/R windows rotate with period 3, the coefficient pair (column x-1, column x) with period 2: six steps per trip
+    for (int t = 0; t < nsteps; t += 6) {
+        step(t, O0, O1, O2, R0, R1, R2, KA, KB);
+        if (t + 1 < nsteps) step(t + 1, O1, O2, O0, R1, R2, R0, KB, KA);
+        if (t + 2 < nsteps) step(t + 2, O2, O0, O1, R2, R0, R1, KA, KB);
+        if (t + 3 < nsteps) step(t + 3, O0, O1, O2, R0, R1, R2, KB, KA);
+        if (t + 4 < nsteps) step(t + 4, O1, O2, O0, R1, R2, R0, KA, KB);
+        if (t + 5 < nsteps) step(t + 5, O2, O0, O1, R2, R0, R1, KB, KA);
     }
 }
 
