@@ -83,6 +83,10 @@ int pdeip_get_devices(int *ids, int capacity);
 int pdeip_release(void);
 /* Number of kernel launches the last *_dev solver call enqueued (diagnostic). */
 int pdeip_last_launch_count(void);
+/* Changes whenever the library frees or regrows a cached workspace buffer (a larger frame, pdeip_release, pdeip_set_device).
+ * A caller that captured *_dev calls into a HIP graph must re-capture when the value differs from the one at capture time:
+ * the graph's kernel arguments point into those buffers. */
+int pdeip_workspace_generation(void);
 /* Waits for the device and reports PDEIP_ERR_DEVICE if a bounded dependency wait of the persistent
  * exact-order kernel (PDEIP_EXACT_PERSIST=1) timed out during the preceding calls. */
 int pdeip_persist_error(void);

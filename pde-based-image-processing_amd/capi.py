@@ -112,6 +112,7 @@ SIGNATURES = {
     "pdeip_get_devices": [ctypes.POINTER(ctypes.c_int), _I],
     "pdeip_release": [],
     "pdeip_last_launch_count": [],
+    "pdeip_workspace_generation": [],
     "pdeip_persist_error": [],
     "pdeip_profile_enable": [_I],
     "pdeip_profile_read": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],

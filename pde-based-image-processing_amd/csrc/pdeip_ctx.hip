@@ -58,13 +58,16 @@ int ws_get(int slot, size_t bytes, float **out)
         HIPCHK(hipDeviceSynchronize());
         if (slot == WS_CTL) latch_abort(d);
         if (slot == WS_ORDER) d->order_B = d->order_T = 0; // the cached schedule table goes with its buffer
-        if (d->ws[slot]) HIPCHK(hipFree(d->ws[slot]));
+        if (d->ws[slot]) {
+            HIPCHK(hipFree(d->ws[slot]));
+            g.ws_generation++;
+        }
         d->ws[slot] = nullptr;
         d->ws_bytes[slot] = 0;
         hipError_t e = hipMalloc(&d->ws[slot], bytes);
         if (e != hipSuccess) return set_err(PDEIP_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         d->ws_bytes[slot] = bytes;
-        if (slot == WS_CTL) HIPCHK(hipMemset(d->ws[slot], 0, bytes)); // the abort word starts clear
+        if (slot == WS_CTL || slot == WS_SMALL) HIPCHK(hipMemset(d->ws[slot], 0, bytes)); // the abort word / load counter start clear
     }
     *out = static_cast<float *>(d->ws[slot]);
     return PDEIP_OK;
@@ -207,6 +210,7 @@ static void release_device(DeviceState *d)
     if (d->device < 0) return;
     if (hipSetDevice(d->device) != hipSuccess) return;
     latch_abort(d);
+    g.ws_generation++;
     for (int s = 0; s < WS_NSLOT; s++) {
         if (d->ws[s]) (void)hipFree(d->ws[s]);
         d->ws[s] = nullptr;
@@ -272,6 +276,7 @@ extern "C" int pdeip_release(void)
     return PDEIP_OK;
 }
 extern "C" int pdeip_last_launch_count(void) { return g.last_launches; }
+extern "C" int pdeip_workspace_generation(void) { return g.ws_generation; }
 extern "C" int pdeip_persist_error(void)
 { // waits for the device(s), then reports whether a bounded spin of the persistent kernel timed out
     bool bad = false;

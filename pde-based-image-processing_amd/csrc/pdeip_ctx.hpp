@@ -49,6 +49,7 @@ struct DeviceState {
 struct Context {
     int mode = PDEIP_MODE_EXACT_ORDER;
     int last_launches = 0;
+    int ws_generation = 0; // bumped whenever a workspace buffer is freed or regrown: captured HIP graphs hold its pointers
     char err[512] = "";
     int rb_tj = 0;        // columns per red-black unit (0 = default)
     bool env_read = false; // PDEIP_MODE / PDEIP_DEVICE / PDEIP_DEVICES consulted

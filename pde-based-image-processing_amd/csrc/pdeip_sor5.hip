@@ -187,21 +187,49 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         return PDEIP_OK;
     }
 
-    // a frame that fits one workgroup's LDS: every sweep of the call in one launch (pdeip_sor_small.hpp); PDEIP_RB_SMALL=0 disables
+    // small frames: the iterate resident in LDS, one launch per (up to) four sweeps (pdeip_sor_small.hpp); PDEIP_RB_SMALL=0 disables
     const bool small_enabled = env_int("PDEIP_RB_SMALL", 1) != 0; // read per call: the tests switch it
-    if (small_enabled && SmallLayout<Mdl>::fits(nrows, ncols)) {
-        const size_t lds = SmallLayout<Mdl>::lds_bytes(nrows, ncols);
-        RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_small<Mdl>), lds));
-        for (int f = 0; f < NIT; f++) {
-            P.it_in[f] = P.it_out[f];
-            if (dst) P.it_out[f] = dst[f];
+    if (small_enabled) {
+        using SL = SmallLayout<Mdl>;
+        const int qpref = env_int("PDEIP_SMALL_Q", 1); // 1 measured fastest at every scale (tools/time_small.py): short workgroups beat little redundancy
+        SmallPlan sp = SL::plan(nrows, ncols, iter, qpref < 1 ? 1 : qpref);
+        int per_launch = iter;
+        if (!sp.ok && iter > SMALL_MAX_SWEEPS) {
+            sp = SL::plan(nrows, ncols, SMALL_MAX_SWEEPS, qpref < 1 ? 1 : qpref);
+            per_launch = SMALL_MAX_SWEEPS;
         }
-        SweepTimer timer(s);
-        hipLaunchKernelGGL(k_sor_small<Mdl>, dim3((unsigned)nframes), dim3(SMALL_THREADS), lds, s, P, nrows, ncols, iter, omega, col0, n);
-        timer.stop(1);
-        g.last_launches++;
-        HIPCHK(hipGetLastError());
-        return PDEIP_OK;
+        // a cut frame relaxed in place needs every workgroup resident at once (the load counter below)
+        if (sp.ok && sp.nslabs > 1 && (long)sp.nslabs * nframes > 224) sp.ok = false;
+        if (sp.ok) {
+            RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_small<Mdl>), sp.lds));
+            unsigned *counter = nullptr, *abort_word = nullptr;
+            if (sp.nslabs > 1) {
+                float *p = nullptr;
+                RC(ws_get(WS_SMALL, 64, &p));
+                counter = reinterpret_cast<unsigned *>(p);
+                RC(ws_get(WS_CTL, 16, &p));
+                abort_word = reinterpret_cast<unsigned *>(p);
+            }
+            DeviceState *d = cur_dev();
+            for (int f = 0; f < NIT; f++) {
+                P.it_in[f] = P.it_out[f];
+                if (dst) P.it_out[f] = dst[f];
+            }
+            SweepTimer timer(s);
+            int nl = 0;
+            for (int it = 0; it < iter; it += per_launch, nl++) {
+                const int k = iter - it < per_launch ? iter - it : per_launch;
+                const bool gated = sp.nslabs > 1 && P.it_in[0] == P.it_out[0];
+                if (gated) d->persist_used = true; // a timed-out wait raises the sticky abort word
+                hipLaunchKernelGGL(k_sor_small<Mdl>, dim3((unsigned)sp.nslabs, (unsigned)nframes), dim3(SMALL_THREADS), sp.lds, s, P, nrows, ncols, k,
+                                   omega, col0, n, sp.W, gated ? counter : nullptr, abort_word);
+                for (int f = 0; f < NIT; f++) P.it_in[f] = P.it_out[f]; // later launches of the call: in place on the result
+            }
+            timer.stop(nl);
+            g.last_launches += nl;
+            HIPCHK(hipGetLastError());
+            return PDEIP_OK;
+        }
     }
 
     // red-black: ping-pong between the caller's buffers and a scratch copy

@@ -17,7 +17,17 @@ def to_device(a, device="cuda"):
     """numpy [nrows, ncols(, F)] (any order) -> torch [(F,) ncols, nrows] on `device`, same bytes as MATLAB."""
     a = np.asarray(a, dtype=np.float32)
     t = a.transpose(2, 1, 0) if a.ndim == 3 else a.T
-    return torch.from_numpy(np.ascontiguousarray(t)).to(device)
+    if t.flags.c_contiguous:   # column-major input (what MATLAB holds): its bytes are the device layout already
+        return torch.from_numpy(t).to(device)
+    # row-major numpy input: upload the bytes as they are and change the layout on the device (a strided host copy of a
+    # 1080p colour pair takes longer than the whole resident run)
+    d = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return (d.permute(2, 1, 0) if a.ndim == 3 else d.T).contiguous()
+
+
+def div_scalar(t, s):
+    """t ./ s in float32 with a true division (a Python-scalar divisor would be turned into a multiplication by 1/s)."""
+    return t / torch.tensor(s, dtype=torch.float32, device=t.device)
 
 
 def to_matlab(t):

@@ -14,13 +14,15 @@ capi.MODE_RED_BLACK the parallel one).
     TVdenoise8 / TVdenoise4     matlab/denoising/TVdenoise{8,4}.m                 total-variation denoising
 
 Not carried over: the spatial a-priori inputs at driver level (the levels take them: Us=, Vs=) and `scales` limits.
+`graph=True` (the llin flow drivers and the FAS driver, parallel orderings): the run's launches are captured into a HIP graph
+on the first call for a frame size and replayed afterwards (graphs.py) -- same kernels and bits, no per-launch host work.
 """
 import math
 
 import numpy as np
 import torch
 
-from . import capi, device as dev, fas, flow_level as fl, pyramid
+from . import capi, device as dev, fas, flow_level as fl, graphs, pyramid
 
 
 def _up(t, inv, nrows, ncols, method="bilinear"):
@@ -33,14 +35,15 @@ def _zeros_like_plane(t):
 
 
 def _frames(Iin, channels):
+    """cat(3, frame0, frame1) -> the two frames on the device, [C, ncols, nrows] each (one upload, sliced there)."""
     I = np.asarray(Iin, dtype=np.float32)
-    I = I if I.ndim == 3 else I[:, :, None]
-    return np.asfortranarray(I[:, :, :channels]), np.asfortranarray(I[:, :, channels:2 * channels])
+    d = dev.to_device(I if I.ndim == 3 else I[:, :, None])
+    return d[:channels].contiguous(), d[channels:2 * channels].contiguous()
 
 
 def _c3(I):
     I = np.asarray(I, dtype=np.float32)
-    return np.asfortranarray(I if I.ndim == 3 else I[:, :, None])
+    return dev.to_device(I if I.ndim == 3 else I[:, :, None])
 
 
 def _terms(d0, d1, fst, snd):
@@ -53,22 +56,39 @@ def _terms(d0, d1, fst, snd):
     return I1, I2
 
 
+_GRAPHS = {}   # (driver, frame shape, parameters) -> graphs.GraphedRun of its device part
+
+
 def _flow_llin(level_cls, Iin, channels, fstTerm, sndTerm, defaults, mode, param):
+    param = dict(param)
+    graph = bool(param.pop("graph", False)) and mode != capi.MODE_EXACT_ORDER   # the exact-order schedule tables are uploaded per shape
     p = dict(defaults, **param)
     p["sndTerm"] = sndTerm.lower()
     I0, I1 = _frames(Iin, channels)
-    P0, P1 = pyramid.build_dev(dev.to_device(I0 / np.float32(255)), dev.to_device(I1 / np.float32(255)), p["scl_factor"], 20)
-    level = level_cls(p, mode=mode)
-    U = _zeros_like_plane(P0[-1])
-    V = torch.zeros_like(U)
-    for scl in range(len(P0) - 1, -1, -1):
-        d0, d1 = P0[scl], P1[scl]
-        (a0, a1), (b0, b1) = _terms(d0, d1, fstTerm, sndTerm)
-        args = (a0, a1, U, V) + ((d0,) if level_cls is fl.FlowAdLevel else ()) + (b0, b1)
-        U, V = level.run(*args)
-        if scl > 0:
-            cols, rows = P0[scl - 1].shape[-2:]
-            U, V = _up(U, 1.0 / p["scl_factor"], rows, cols), _up(V, 1.0 / p["scl_factor"], rows, cols)
+
+    def device_part(f0, f1):
+        P0, P1 = pyramid.build_dev(f0, f1, p["scl_factor"], 20)
+        level = level_cls(p, mode=mode)
+        U = _zeros_like_plane(P0[-1])
+        V = torch.zeros_like(U)
+        for scl in range(len(P0) - 1, -1, -1):
+            d0, d1 = P0[scl], P1[scl]
+            (a0, a1), (b0, b1) = _terms(d0, d1, fstTerm, sndTerm)
+            args = (a0, a1, U, V) + ((d0,) if level_cls is fl.FlowAdLevel else ()) + (b0, b1)
+            U, V = level.run(*args)
+            if scl > 0:
+                cols, rows = P0[scl - 1].shape[-2:]
+                U, V = _up(U, 1.0 / p["scl_factor"], rows, cols), _up(V, 1.0 / p["scl_factor"], rows, cols)
+        return U, V
+
+    f0, f1 = dev.div_scalar(I0, 255.0), dev.div_scalar(I1, 255.0)
+    if graph:   # the few thousand launches of the run replayed as one HIP graph (graphs.py); same kernels, same results
+        key = (level_cls.__name__, tuple(I0.shape), fstTerm.lower(), sndTerm.lower(), int(mode), tuple(sorted((k, repr(v)) for k, v in p.items())))
+        if key not in _GRAPHS:
+            _GRAPHS[key] = graphs.GraphedRun(device_part)
+        U, V = _GRAPHS[key](f0, f1)
+    else:
+        U, V = device_part(f0, f1)
     dev.sync_check()  # results leave the device: a timed-out dependency wait of the exact-order kernel must not pass silently
     return dev.to_matlab(U), dev.to_matlab(V)
 
@@ -92,7 +112,7 @@ HS_DEFAULTS = dict(alpha=0.2, omega=1.9, iter=20, b1=0.25, b2=0.75, scl_factor=0
 def FlowEminHS_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
     p = dict(HS_DEFAULTS, **param)
     I0, I1 = _frames(Iin, channels)
-    P0, P1 = pyramid.build_dev(dev.to_device(I0 / np.float32(255)), dev.to_device(I1 / np.float32(255)), p["scl_factor"], 20)
+    P0, P1 = pyramid.build_dev(dev.div_scalar(I0, 255.0), dev.div_scalar(I1, 255.0), p["scl_factor"], 20)
     level = fl.FlowHsLevel(p, mode=mode)
     U = _zeros_like_plane(P0[-1])
     V = torch.zeros_like(U)
@@ -111,7 +131,14 @@ def FlowEminHS_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
 
 def FlowEminNDFASFMG_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
     I0, I1 = _frames(Iin, channels)
-    gU, gV = fas.FasFmgFlow(param, mode=mode).run(dev.to_device(I0), dev.to_device(I1))
+    param = dict(param)
+    if param.pop("graph", False):
+        key = ("FasFmgFlow", tuple(I0.shape), int(mode), tuple(sorted((k, repr(v)) for k, v in param.items())))
+        if key not in _GRAPHS:
+            _GRAPHS[key] = fas.FasFmgFlow(param, mode=mode)
+        gU, gV = _GRAPHS[key].run_graph(I0, I1)
+    else:
+        gU, gV = fas.FasFmgFlow(param, mode=mode).run(I0, I1)
     dev.sync_check()
     return dev.to_matlab(gU), dev.to_matlab(gV)
 
@@ -126,7 +153,7 @@ def DispEminND_llin_2D(Il, Ir, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXA
     firstLoop of the coarsest scale) and enters every assembly through the exp influence function (:277-292)."""
     p = dict(DISP_DEFAULTS, **param)
     p["sndTerm"] = sndTerm.lower()
-    P0, P1 = pyramid.build_dev(dev.to_device(_c3(Il) / np.float32(255)), dev.to_device(_c3(Ir) / np.float32(255)), p["scl_factor"], 10)
+    P0, P1 = pyramid.build_dev(dev.div_scalar(_c3(Il), 255.0), dev.div_scalar(_c3(Ir), 255.0), p["scl_factor"], 10)
     level = fl.DispLlinLevel(p, mode=mode)
     U = _zeros_like_plane(P0[-1])
     USap = None
@@ -159,7 +186,7 @@ def DispEminND_llin_sym_2D(Il, Ir, mode=capi.MODE_EXACT_ORDER, **param):
     """-> U [nrows, ncols, 2] (left-to-right and right-to-left disparity)."""
     p = dict(SYM_DEFAULTS, **param)
     # no /255 in this driver (:81-82); its coarsest scale stays unsmoothed (:94-98)
-    P0, P1 = pyramid.build_dev(dev.to_device(_c3(Il)), dev.to_device(_c3(Ir)), p["scl_factor"], 10, pyramid.gaussian(3, 1.0), smooth_last=False)
+    P0, P1 = pyramid.build_dev(_c3(Il), _c3(Ir), p["scl_factor"], 10, pyramid.gaussian(3, 1.0), smooth_last=False)
     level = fl.DispSymLevel(p, mode=mode)
     U0 = _zeros_like_plane(P0[-1])
     U1 = torch.zeros_like(U0)

@@ -16,7 +16,7 @@ Planes are torch float32 CUDA tensors [C, ncols, nrows] / [ncols, nrows] (device
 import numpy as np
 import torch
 
-from . import capi, device as dev
+from . import capi, device as dev, graphs
 
 IDT, IDX, IDY, IDXX, IDYY, IDXY, IDXT, IDYT, M, CU, CV, DU, DV = range(13)   # plane order of fas_prepare
 
@@ -37,6 +37,7 @@ class FasFmgFlow:
         self.p = dict(DEFAULTS, **(param or {}))
         self.mode = mode
         self.planes = []
+        self._graphs = {}
 
     # ---- set-up (:104-153) -------------------------------------------------------------------------
     def prepare(self, I0, I1):
@@ -102,6 +103,16 @@ class FasFmgFlow:
             dev.fas_prolong_add(V, Vc, Vres, 1.0 / s)
         self.smooth(U, V, pl, Cu, Cv)
         return U, V
+
+    def run_graph(self, I0, I1):
+        """run() replayed as a HIP graph (captured on the first call per frame shape; graphs.py).  The returned planes are the
+        graph's output buffers: valid until the next call.  Exact order falls back to run() (schedule tables are uploaded)."""
+        if self.mode == capi.MODE_EXACT_ORDER:
+            return self.run(I0, I1)
+        key = (tuple(I0.shape), tuple(I1.shape))
+        if key not in self._graphs:
+            self._graphs[key] = graphs.GraphedRun(self.run)
+        return self._graphs[key](I0, I1)
 
     # ---- the driver's outer loop (:161-183) --------------------------------------------------------
     def run(self, I0, I1):

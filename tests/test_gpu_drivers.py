@@ -124,3 +124,23 @@ def test_disparity_driver_with_spatial_apriori(pdeip):
     pulled = D.DispEminND_llin_2D(left, right, "rgb", "none", Us=np.full(left.shape[:2], -2.0), gammaS=5.0)
     m = float(np.median(pulled[10:-10, 20:-20]))
     assert -3.0 < m < -1.9 and abs(m + 2.0) < abs(float(np.median(base[10:-10, 20:-20])) + 2.0), m
+
+
+def test_graph_replay_gives_the_eager_bits(pdeip):
+    """graph=True replays the run's launches from a captured HIP graph (graphs.py): the same bits as the eager run, on the
+    first call (warm-up + capture + replay) and on later calls with new frames of the same size; row-major and column-major
+    numpy inputs take different upload paths (device.to_device) to the same device bytes."""
+    I, _, _ = _yosemite255()
+    D = drv()
+    kw = dict(mode=pdeip.MODE_RED_BLACK, solver=1, omega=1.5)
+    for frames in (I, np.asfortranarray(I[::-1].copy()), I[:, ::-1].copy()):
+        want = D.FlowEminND_llin_2D_v10(frames, 1, "grad", "gradmag", **kw)
+        got = D.FlowEminND_llin_2D_v10(frames, 1, "grad", "gradmag", graph=True, **kw)
+        assert pb.bit_equal(got[0], want[0]) and pb.bit_equal(got[1], want[1]), pb.describe_mismatch(got[0], want[0])
+        want = D.FlowEminNDFASFMG_elin_2D_v10(frames, 1, solver=1, omega=1.0, **{"mode": pdeip.MODE_RED_BLACK})
+        got = D.FlowEminNDFASFMG_elin_2D_v10(frames, 1, solver=1, omega=1.0, graph=True, **{"mode": pdeip.MODE_RED_BLACK})
+        assert pb.bit_equal(got[0], want[0]) and pb.bit_equal(got[1], want[1])
+    # exact order: graph=True is accepted and runs eagerly
+    a = D.FlowEminND_llin_2D_v10(I, 1, "rgb", "none", solver=1, graph=True)
+    b = D.FlowEminND_llin_2D_v10(I, 1, "rgb", "none", solver=1)
+    assert pb.bit_equal(a[0], b[0])

@@ -225,7 +225,7 @@ def test_out_of_place_other_models(pdeip, oracle):
 
 
 @pytest.mark.parametrize("small,pipe", [("1", "1"), ("0", "1"), ("0", "0")])
-@pytest.mark.parametrize("shape", [(24, 40), (33, 29), (68, 120), (64, 96), (100, 48), (17, 30), (9, 15), (3, 3), (4, 5)])
+@pytest.mark.parametrize("shape", [(24, 40), (33, 29), (68, 120), (64, 96), (100, 48), (17, 30), (9, 15), (3, 3), (4, 5), (135, 240), (270, 100)])
 def test_red_black_kernel_families_agree(pdeip, oracle, shape, small, pipe):
     """The three red-black kernel families -- one workgroup per small frame (k_sor_small), the four-sweep wave pipeline
     (k_sor_rbp) and the one/two-sweep marches (k_sor_rb) -- are selected by frame size; switched by hand they must all give
@@ -259,3 +259,45 @@ def test_red_black_kernel_families_agree(pdeip, oracle, shape, small, pipe):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("qpref", ["1", "2", "4"])
+@pytest.mark.parametrize("shape", [(68, 120), (135, 240), (270, 96), (45, 500), (31, 33), (200, 301)])
+def test_small_frame_slabs_in_place(pdeip, oracle, shape, qpref):
+    """k_sor_small cuts a frame into column slabs with a halo of two columns per sweep; relaxed IN PLACE the workgroups gate
+    their stores on a load counter.  Device-pointer entry points, every 5-point model, iter 1 / 4 / 9 (9 = three launches of
+    4+4+1 sweeps when the frame is cut), the slab width steered through PDEIP_SMALL_Q, vs the oracle's colour order."""
+    import importlib
+    import os
+
+    dev, capi = importlib.import_module("pde-based-image-processing_amd.device"), pdeip.capi
+    old = os.environ.get("PDEIP_SMALL_Q")
+    os.environ["PDEIP_SMALL_Q"] = qpref
+    try:
+        for it in (1, 4, 9):
+            p = pb.elin4(971, *shape, nan_frac=0.02)
+            d = {k: dev.to_device(v) for k, v in p.items()}
+            dev.oflow_sor_elin4(*[d[k] for k in ("U", "V", "M", "Cu", "Cv", "Du", "Dv", "wW", "wN", "wE", "wS")], it, 1.9, capi.MODE_RED_BLACK)
+            want = oracle.oflow_sor_elin4(*p.values(), it, 1.9, oracle.COLOUR)
+            assert pb.bit_equal(dev.to_matlab(d["U"]), want[0]), "elin4 %s it=%d q=%s: %s" % (shape, it, qpref, pb.describe_mismatch(dev.to_matlab(d["U"]), want[0]))
+            assert pb.bit_equal(dev.to_matlab(d["V"]), want[1])
+            q = pb.llin4(972, *shape, nan_frac=0.02)
+            d = {k: dev.to_device(v) for k, v in q.items()}
+            dev.oflow_sor_llin4(*[d[k] for k in ("U", "V", "dU", "dV", "M", "Cu", "Cv", "Du", "Dv", "wW", "wN", "wE", "wS")], it, 1.9, capi.MODE_RED_BLACK)
+            want = oracle.oflow_sor_llin4(*q.values(), it, 1.9, oracle.COLOUR)
+            assert pb.bit_equal(dev.to_matlab(d["dU"]), want[0]), "llin4 %s it=%d q=%s: %s" % (shape, it, qpref, pb.describe_mismatch(dev.to_matlab(d["dU"]), want[0]))
+            assert pb.bit_equal(dev.to_matlab(d["dV"]), want[1])
+            e = pb.disp4(973, *shape, nan_frac=0.02)
+            d = {k: dev.to_device(v) for k, v in e.items()}
+            dev.disp_sor_llin4(*[d[k] for k in ("U", "dU", "Cu", "Du", "wW", "wN", "wE", "wS")], it, 1.9, capi.MODE_RED_BLACK)
+            assert pb.bit_equal(dev.to_matlab(d["dU"]), oracle.disp_sor_llin4(*e.values(), it, 1.9, oracle.COLOUR)), "disp4 %s it=%d" % (shape, it)
+            f = pb.pde4(974, *shape, nframes=3, nan_frac=0.02)
+            d = {k: dev.to_device(v) for k, v in f.items()}
+            dev.pde_sor4(*[d[k] for k in ("X", "TRACE", "B", "wW", "wN", "wE", "wS")], it, 1.75, capi.MODE_RED_BLACK)
+            assert pb.bit_equal(dev.to_matlab(d["X"]), oracle.pde_sor4(*f.values(), it, 1.75, oracle.COLOUR)), "pde4 %s it=%d" % (shape, it)
+        assert capi.load().pdeip_persist_error() == 0, capi.last_error()
+    finally:
+        if old is None:
+            os.environ.pop("PDEIP_SMALL_Q", None)
+        else:
+            os.environ["PDEIP_SMALL_Q"] = old

@@ -1,0 +1,32 @@
+"""Where the wall time of FlowEminND_llin_2D_v10 at 1080p goes: host-side frame preparation, upload, the resident run (eager / graph), download."""
+import importlib, sys, time
+sys.path.insert(0, "."); import numpy as np, torch
+drivers = importlib.import_module("pde-based-image-processing_amd.drivers"); capi = importlib.import_module("pde-based-image-processing_amd").capi
+dev = importlib.import_module("pde-based-image-processing_amd.device"); graphs = importlib.import_module("pde-based-image-processing_amd.graphs")
+fl = importlib.import_module("pde-based-image-processing_amd.flow_level"); pyramid = importlib.import_module("pde-based-image-processing_amd.pyramid")
+jj, ii = np.meshgrid(np.arange(1920), np.arange(1080))
+tex = lambda di, dj, c: (np.sin(0.021 * (ii + di) + c) * np.cos(0.017 * (jj + dj) - c) + 0.3 * np.sin(0.11 * (ii + di) + 0.07 * (jj + dj))).astype(np.float32)
+I0 = np.stack([tex(0, 0, c) for c in range(3)], axis=2); I1 = np.stack([tex(0.7, -0.4, c) for c in range(3)], axis=2)
+Iseq = np.concatenate([(I0 + 1.3) * 98.0, (I1 + 1.3) * 98.0], axis=2).astype(np.float32)
+def T(fn, n=3):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): r = fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3, r
+t, (A, B) = T(lambda: drivers._frames(Iseq, 3)); print("frames split (numpy): %.2f ms" % t)
+t, (f0, f1) = T(lambda: (dev.to_device(A / np.float32(255)), dev.to_device(B / np.float32(255)))); print("scale + upload: %.2f ms" % t)
+p = dict(drivers.ND_DEFAULTS, solver=1, omega=1.5, sndTerm="gradmag")
+def device_part(f0, f1):
+    P0, P1 = pyramid.build_dev(f0, f1, p["scl_factor"], 20)
+    level = fl.FlowLlinLevel(p, mode=1)
+    U = drivers._zeros_like_plane(P0[-1]); V = torch.zeros_like(U)
+    for scl in range(len(P0) - 1, -1, -1):
+        (a0, a1), (b0, b1) = drivers._terms(P0[scl], P1[scl], "grad", "gradmag")
+        U, V = level.run(a0, a1, U, V, b0, b1)
+        if scl > 0:
+            cols, rows = P0[scl - 1].shape[-2:]
+            U, V = drivers._up(U, 1.0 / p["scl_factor"], rows, cols), drivers._up(V, 1.0 / p["scl_factor"], rows, cols)
+    return U, V
+t, (U, V) = T(lambda: device_part(f0, f1)); print("resident run, eager: %.2f ms" % t)
+gr = graphs.GraphedRun(device_part)
+t, (U, V) = T(lambda: gr(f0, f1)); print("resident run, graph replay: %.2f ms" % t)
+t, _ = T(lambda: (dev.to_matlab(U), dev.to_matlab(V))); print("download: %.2f ms" % t)

@@ -1,0 +1,24 @@
+"""Red-black solver call (iter = 4, in place) per pyramid scale: us per call for each model, A/B over env knobs."""
+import importlib, sys, time
+import torch
+sys.path.insert(0, ".")
+dev = importlib.import_module("pde-based-image-processing_amd.device")
+shapes = [(540, 960), (270, 480), (135, 240), (68, 120), (34, 60), (17, 30), (456, 810), (342, 608), (257, 456), (193, 342), (145, 257), (109, 193), (82, 145), (61, 108)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+for nr, nc in shapes:
+    g = torch.Generator(device="cuda").manual_seed(1)
+    P = lambda lo, hi: torch.empty((nc, nr), device="cuda").uniform_(lo, hi, generator=g)
+    U, V, dU, dV = P(-1, 1), P(-1, 1), P(-0.1, 0.1), P(-0.1, 0.1)
+    coef = [P(-0.5, 0.5) for _ in range(3)] + [P(0.1, 1), P(0.1, 1)] + [P(0.5, 5) for _ in range(4)]
+    calls = {"elin4": lambda: dev.oflow_sor_elin4(U, V, *coef, 4, 1.0, 1), "llin4": lambda: dev.oflow_sor_llin4(U, V, dU, dV, *coef, 4, 1.0, 1),
+             "disp4": lambda: dev.disp_sor_llin4(U, dU, coef[1], coef[3], *coef[5:], 4, 1.0, 1)}
+    row = []
+    for name, fn in calls.items():
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50): fn()
+        torch.cuda.synchronize()
+        row.append("%s %6.1f" % (name, (time.perf_counter() - t0) / 50 * 1e6))
+    print("%9s  %s" % ("%dx%d" % (nr, nc), "  ".join(row)), flush=True)
