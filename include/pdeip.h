@@ -368,6 +368,10 @@ int pdeip_hs_assemble_dev(void *stream, const float *It0, const float *It1, int 
 int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const float *V, const float *dU, const float *dV, int nrows,
                                  int ncols, float *wW, float *wN, float *wS, float *wE);
 /* dU, dV may both be NULL: OPdiffWeights(U, V) of the early-linearisation drivers (FlowEminNDFASFMG_elin_2D_v10.m:392). */
+/* Diagnostic: the weights' single(1 ./ sqrt(x)) takes a short sequence that is proven against the exact one (double sqrt,
+ * double divide, one rounding) value by value; this runs n arguments (random ones and ones aimed at rounding boundaries)
+ * through both and returns how many differ (0 expected), or -1 on a device error. */
+int pdeip_selftest_inv_sqrt(int n, unsigned seed);
 
 /* ---- the drivers' image pyramid.  IPT semantics have nothing to be checked against here: pyramid.py states our definition
  * (tap lists at MATLAB's pixel-centre convention, antialiased when shrinking, replicate borders, double accumulation) and

@@ -94,6 +94,7 @@ SIGNATURES = {
     "pdeip_pyr_resize_dev": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "pdeip_pyr_smooth_dev": [_P, _P, _I, _I, _I, _P, _I, _P],
     "pdeip_flow_opdiffweights_dev": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "pdeip_selftest_inv_sqrt": [_I, ctypes.c_uint],
     "pdeip_tv_assemble_dev": [_P, _P, _P, _I, _I, _I, _F] + [_P] * 10,
     "pdeip_median3_dev": [_P, _P, _P, _I, _I, _P],
     "pdeip_oflow_res_elin4_dev": _sig(1 + 13, [_I, _I, _I]),

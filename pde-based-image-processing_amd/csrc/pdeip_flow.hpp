@@ -219,10 +219,34 @@ __global__ void k_add2(float *out, const float *A, const float *B, int nrows, in
     out[pos] = A[pos] + B[pos];
 }
 
+// single(1 ./ sqrt(x)) of a double x, i.e. the correctly rounded double square root, the correctly rounded double quotient,
+// then one rounding to single -- without the two long IEEE sequences in the common case.  v_rsq_f64 plus two Newton steps
+// is within 2 ulp (double) of 1/sqrt(x), and so is the exact sequence's quotient, so both round to the same single unless a
+// single rounding boundary (a double whose low 29 mantissa bits are 0x10000000) lies within a few ulp of the estimate; those
+// values (and non-finite, huge or tiny x, where single goes subnormal) take the exact sequence.  Same bits, always.
+__device__ __forceinline__ float single_inv_sqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-(x * y), y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    e = __builtin_fma(-(x * y), y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    const unsigned lo = (unsigned)__double2loint(y) & 0x1fffffffu;
+    const bool safe = (lo - 0x10000000u + 16u > 32u) && (x > 1e-30) && (x < 1e60); // false for NaN
+    if (safe) return (float)y;
+    return (float)(1.0 / sqrt(x));
+}
+
 // OPdiffWeights (:389-433) on (U+dU, V+dV): 6-point discretisation, evaluated in double like the MATLAB
 // function (it casts its inputs), circshift wrap-around at the frame edges included, cast to single on
 // the way into the solver call.  ver = imfilter(.,[0.25 0 -0.25]','replicate') = 0.25*(north) - 0.25*(south),
 // hor likewise with west/east.
+// The weight between two pixels is one number: wW(i,j) and wE(i,j-1) are the same expression (the difference enters
+// squared, the two cross terms are summed in the other order -- both exact symmetries in IEEE arithmetic -- and the
+// circshift pairs the same pixels across the frame edge), likewise wN(i,j) and wS(i-1,j).  A thread therefore evaluates the
+// east and the south weight of its pixel and also stores them as the west weight of its east neighbour and the north weight
+// of its south neighbour: half the double-precision work of evaluating four directions per pixel, every plane entry
+// written exactly once.
 __global__ void k_flow_opdiffweights(float *wW, float *wN, float *wS, float *wE, const float *U, const float *V,
                                      const float *dU, const float *dV, int nrows, int ncols)
 {
@@ -235,28 +259,30 @@ __global__ void k_flow_opdiffweights(float *wW, float *wN, float *wS, float *wE,
         return (double)s;
     };
     auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
-    auto ver = [&](int f, int ii, int jj) { return 0.25 * F(f, clampi(ii - 1, nrows - 1), jj) - 0.25 * F(f, clampi(ii + 1, nrows - 1), jj); };
-    auto hor = [&](int f, int ii, int jj) { return 0.25 * F(f, ii, clampi(jj - 1, ncols - 1)) - 0.25 * F(f, ii, clampi(jj + 1, ncols - 1)); };
-    const int jw = j == 0 ? ncols - 1 : j - 1, je = j == ncols - 1 ? 0 : j + 1; // circshift wraps
-    const int in_ = i == 0 ? nrows - 1 : i - 1, is = i == nrows - 1 ? 0 : i + 1;
-    double w[4]; // W, E, N, S
+    const int je = j == ncols - 1 ? 0 : j + 1, is = i == nrows - 1 ? 0 : i + 1; // circshift wraps
+    const int iu = clampi(i - 1, nrows - 1), id = clampi(i + 1, nrows - 1);     // 'replicate' rows / columns of the cross stencils
+    const int jl = clampi(j - 1, ncols - 1), jr = clampi(j + 1, ncols - 1);
+    double accE = 0.0, accS = 0.0;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const int ii = d == 2 ? in_ : (d == 3 ? is : i), jj = d == 0 ? jw : (d == 1 ? je : j);
-        double acc = 0.0;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) { // (U_d - U)^2 + (Uver + Uver_d)^2 + (V_d - V)^2 + (Vver + Vver_d)^2, left to right
-            const double diff = F(f, ii, jj) - F(f, i, j);
-            const double cross = d < 2 ? ver(f, i, j) + ver(f, ii, jj) : hor(f, i, j) + hor(f, ii, jj);
-            acc = f == 0 ? diff * diff : acc + diff * diff;
-            acc = acc + cross * cross;
-        }
-        w[d] = 1.0 / sqrt(acc + 0.00001);
+    for (int f = 0; f < 2; ++f) { // (U_d - U)^2 + (Uver + Uver_d)^2 + (V_d - V)^2 + (Vver + Vver_d)^2, left to right
+        const double c = F(f, i, j), n = F(f, iu, j), s = F(f, id, j), w = F(f, i, jl), e = F(f, i, jr);
+        const double ver_c = 0.25 * n - 0.25 * s, hor_c = 0.25 * w - 0.25 * e;
+        // east neighbour (i, je): its vertical stencil; south neighbour (is, j): its horizontal stencil
+        const double ce = F(f, i, je), cs = F(f, is, j);
+        const double ver_e = 0.25 * F(f, iu, je) - 0.25 * F(f, id, je);
+        const double hor_s = 0.25 * F(f, is, jl) - 0.25 * F(f, is, jr);
+        const double dE = ce - c, dS = cs - c;
+        const double xE = ver_c + ver_e, xS = hor_c + hor_s;
+        accE = f == 0 ? dE * dE : accE + dE * dE;
+        accE = accE + xE * xE;
+        accS = f == 0 ? dS * dS : accS + dS * dS;
+        accS = accS + xS * xS;
     }
-    wW[pos] = (float)w[0];
-    wE[pos] = (float)w[1];
-    wN[pos] = (float)w[2];
-    wS[pos] = (float)w[3];
+    const float we = single_inv_sqrt(accE + 0.00001), ws = single_inv_sqrt(accS + 0.00001);
+    wE[pos] = we;
+    wW[(size_t)je * nrows + i] = we;
+    wS[pos] = ws;
+    wN[(size_t)j * nrows + is] = ws;
 }
 
 // medfilt2(A + B, [3 3], 'symmetric') (:352-353): exact selection of the 5th of 9, symmetric padding

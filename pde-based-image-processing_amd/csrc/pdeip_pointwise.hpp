@@ -308,32 +308,86 @@ __device__ __forceinline__ float v5_of_h5(const float *in, const float *op1, con
     return sum5(t);
 }
 
-static __global__ void k_fst_derivatives5(float *Idt, float *Idx, float *Idy, const float *It0, const float *It1,
-                                   int nrows, int ncols, size_t frame_stride)
-{
-    PDEIP_PIXEL_INDEX();
-    const size_t fo = (size_t)blockIdx.z * frame_stride;
-    const float *a = It0 + fo, *b = It1 + fo;
-    Idt[fo + pos] = a[pos] * 0.50f + b[pos] * -0.50f;                         // TemporalConvWO2 (:44-60)
-    Idx[fo + pos] = h5_of_v5(b, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);      // :376-378
-    Idy[fo + pos] = v5_of_h5(b, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);      // :380-382
-}
+// Tiled form.  A workgroup of 64 x 4 threads owns 64 rows x 4 columns of one frame: it stages the (64+4) x (4+4) input
+// neighbourhood of both frames in LDS (replicate ends = clamped coordinates, as the reference's loops read them), evaluates
+// every first-stage temporary the tile needs ONCE -- V5(smooth) of both frames on 64 x 8, H5(smooth) of both frames and
+// H5(d1) of the second on 68 x 4 -- and then the second-stage taps from LDS.  Per output pixel that is about 70 multiply-adds
+// and 4 global loads instead of 7 x 25 of each; products and left-to-right sums are the reference's, so the bits are too.
+constexpr int D5_TR = 64, D5_TC = 4, D5_IR = D5_TR + 4, D5_IC = D5_TC + 4;
 
-static __global__ void k_snd_derivatives5(float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy,
-                                   const float *It0, const float *It1, int nrows, int ncols, size_t frame_stride)
+template <bool SND>
+__global__ void __launch_bounds__(D5_TR *D5_TC)
+k_derivatives5_tiled(float *o0, float *o1, float *o2, float *o3, float *o4, const float *It0, const float *It1, int nrows, int ncols,
+                     size_t frame_stride)
 {
-    PDEIP_PIXEL_INDEX();
+    __shared__ float inA[D5_IC][D5_IR], inB[D5_IC][D5_IR];                  // [tile column][tile row]: rows contiguous
+    __shared__ float VA[D5_IC][D5_TR], VB[D5_IC][D5_TR];                    // V5(smooth) at own rows, columns j-2..j+2
+    __shared__ float HA[D5_TC][D5_IR], HB[D5_TC][D5_IR], HD[D5_TC][D5_IR];  // H5(smooth) a, b; H5(d1) b at rows i-2..i+2, own columns
+    const int tr = threadIdx.x, tc = threadIdx.y, tid = tc * D5_TR + tr;
+    const int i0 = blockIdx.x * D5_TR, j0 = blockIdx.y * D5_TC;
     const size_t fo = (size_t)blockIdx.z * frame_stride;
     const float *a = It0 + fo, *b = It1 + fo;
-    float t1 = h5_of_v5(a, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);           // :459-463
-    float t2 = h5_of_v5(b, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);
-    Idxt[fo + pos] = t1 * 0.50f + t2 * -0.50f;
-    t1 = v5_of_h5(a, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);                 // :465-469
-    t2 = v5_of_h5(b, SIM_SMOOTH, SIM_D1, i, j, nrows, ncols);
-    Idyt[fo + pos] = t1 * 0.50f + t2 * -0.50f;
-    Idxx[fo + pos] = h5_of_v5(b, SIM_SMOOTH, SIM_D2, i, j, nrows, ncols);     // :472-473
-    Idyy[fo + pos] = v5_of_h5(b, SIM_SMOOTH, SIM_D2, i, j, nrows, ncols);     // :476-477
-    Idxy[fo + pos] = v5_of_h5(b, SIM_D1, SIM_D1, i, j, nrows, ncols);         // :480-481
+    for (int e = tid; e < D5_IC * D5_IR; e += D5_TR * D5_TC) {
+        const int c = e / D5_IR, r = e - c * D5_IR;
+        const size_t g = (size_t)clampi(j0 - 2 + c, 0, ncols - 1) * nrows + clampi(i0 - 2 + r, 0, nrows - 1);
+        if (SND) inA[c][r] = a[g];
+        inB[c][r] = b[g];
+    }
+    __syncthreads();
+    for (int e = tid; e < D5_IC * D5_TR; e += D5_TR * D5_TC) { // vertical temporaries: own rows, every staged column
+        const int c = e / D5_TR, r = e - c * D5_TR;
+        float t[5];
+        if (SND) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) t[k] = inA[c][r + k] * SIM_SMOOTH[k];
+            VA[c][r] = sum5(t);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) t[k] = inB[c][r + k] * SIM_SMOOTH[k];
+        VB[c][r] = sum5(t);
+    }
+    for (int e = tid; e < D5_TC * D5_IR; e += D5_TR * D5_TC) { // horizontal temporaries: every staged row, own columns
+        const int c = e / D5_IR, r = e - c * D5_IR;
+        float t[5];
+        if (SND) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) t[k] = inA[c + k][r] * SIM_SMOOTH[k];
+            HA[c][r] = sum5(t);
+#pragma unroll
+            for (int k = 0; k < 5; k++) t[k] = inB[c + k][r] * SIM_D1[k];
+            HD[c][r] = sum5(t);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) t[k] = inB[c + k][r] * SIM_SMOOTH[k];
+        HB[c][r] = sum5(t);
+    }
+    __syncthreads();
+    const int i = i0 + tr, j = j0 + tc;
+    if (i >= nrows || j >= ncols) return;
+    const size_t pos = fo + (size_t)j * nrows + i;
+    auto h5 = [&](const float (&V)[D5_IC][D5_TR], const float *op) { // H5(op) of a vertical temporary at (i, j)
+        float t[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) t[k] = V[tc + k][tr] * op[k];
+        return sum5(t);
+    };
+    auto v5 = [&](const float (&H)[D5_TC][D5_IR], const float *op) { // V5(op) of a horizontal temporary at (i, j)
+        float t[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) t[k] = H[tc][tr + k] * op[k];
+        return sum5(t);
+    };
+    if (SND) {
+        o0[pos] = h5(VA, SIM_D1) * 0.50f + h5(VB, SIM_D1) * -0.50f; // Idxt (:459-463)
+        o1[pos] = v5(HA, SIM_D1) * 0.50f + v5(HB, SIM_D1) * -0.50f; // Idyt (:465-469)
+        o2[pos] = h5(VB, SIM_D2);                                   // Idxx (:472-473)
+        o3[pos] = v5(HB, SIM_D2);                                   // Idyy (:476-477)
+        o4[pos] = v5(HD, SIM_D1);                                   // Idxy (:480-481)
+    } else {
+        o0[pos] = It0[pos] * 0.50f + inB[tc + 2][tr + 2] * -0.50f; // Idt: TemporalConvWO2 (:44-60)
+        o1[pos] = h5(VB, SIM_D1);                                   // Idx (:376-378)
+        o2[pos] = v5(HB, SIM_D1);                                   // Idy (:380-382)
+    }
 }
 
 } // namespace pdeip

@@ -92,8 +92,8 @@ extern "C" int pdeip_fst_derivatives5_dev(void *stream, const float *It0, const 
                                           int nframes, float *Idt, float *Idx, float *Idy)
 {
     RC(check_deriv_dims("pdeip_fst_derivatives5_dev", nrows, ncols, nframes));
-    hipLaunchKernelGGL(k_fst_derivatives5, pixel_grid(nrows, ncols, nframes), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       Idt, Idx, Idy, It0, It1, nrows, ncols, (size_t)nrows * ncols);
+    hipLaunchKernelGGL(k_derivatives5_tiled<false>, dim3((nrows + D5_TR - 1) / D5_TR, (ncols + D5_TC - 1) / D5_TC, nframes), dim3(D5_TR, D5_TC), 0,
+                       static_cast<hipStream_t>(stream), Idt, Idx, Idy, nullptr, nullptr, It0, It1, nrows, ncols, (size_t)nrows * ncols);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }
@@ -102,8 +102,8 @@ extern "C" int pdeip_snd_derivatives5_dev(void *stream, const float *It0, const 
                                           int nframes, float *Idxt, float *Idyt, float *Idxx, float *Idyy, float *Idxy)
 {
     RC(check_deriv_dims("pdeip_snd_derivatives5_dev", nrows, ncols, nframes));
-    hipLaunchKernelGGL(k_snd_derivatives5, pixel_grid(nrows, ncols, nframes), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       Idxt, Idyt, Idxx, Idyy, Idxy, It0, It1, nrows, ncols, (size_t)nrows * ncols);
+    hipLaunchKernelGGL(k_derivatives5_tiled<true>, dim3((nrows + D5_TR - 1) / D5_TR, (ncols + D5_TC - 1) / D5_TC, nframes), dim3(D5_TR, D5_TC), 0,
+                       static_cast<hipStream_t>(stream), Idxt, Idyt, Idxx, Idyy, Idxy, It0, It1, nrows, ncols, (size_t)nrows * ncols);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }
@@ -324,6 +324,39 @@ extern "C" int pdeip_flow_opdiffweights_dev(void *stream, const float *U, const 
                        V, dU, dV, nrows, ncols);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
+}
+
+// Self-check of single_inv_sqrt (pdeip_flow.hpp): n pseudo-random doubles over 1e-5 .. 1e7 plus, for every eighth of them, an
+// argument aimed at a single-precision rounding boundary (x = 1/m^2 for a midpoint m between two adjacent singles, nudged by
+// -3 .. +3 ulp), each compared with the exact sequence single(1.0 / sqrt(x)).
+static __global__ void k_selftest_inv_sqrt(unsigned long long n, unsigned seed, unsigned *mismatches)
+{
+    const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    unsigned long long h = (k + 1) * 0x9E3779B97F4A7C15ull + seed;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 29;
+    const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);   // [0, 1)
+    double x = exp(-11.5 + 27.6 * u);                                   // 1e-5 .. 1e7, log-uniform
+    if ((k & 7) == 0) {
+        const float f = (float)(1.0 / sqrt(x));
+        const double m = 0.5 * ((double)f + (double)__uint_as_float(__float_as_uint(f) + 1u)); // midpoint: a rounding boundary
+        x = 1.0 / (m * m);
+        const long long nudge = (long long)((h >> 3) % 7) - 3;
+        x = __longlong_as_double(__double_as_longlong(x) + nudge);
+    }
+    if (single_inv_sqrt(x) != (float)(1.0 / sqrt(x))) atomicAdd(mismatches, 1u);
+}
+
+extern "C" int pdeip_selftest_inv_sqrt(int n, unsigned seed)
+{
+    if (n <= 0) return 0;
+    unsigned *d = nullptr, h = 0;
+    if (hipMalloc(&d, sizeof(unsigned)) != hipSuccess) return -1;
+    if (hipMemset(d, 0, sizeof(unsigned)) != hipSuccess) { (void)hipFree(d); return -1; }
+    hipLaunchKernelGGL(k_selftest_inv_sqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (unsigned long long)n, seed, d);
+    const bool ok = hipMemcpy(&h, d, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    return ok ? (int)h : -1;
 }
 
 extern "C" int pdeip_median3_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out)

@@ -482,3 +482,12 @@ def test_disparity_level_with_spatial_apriori(pdeip, oracle, solver, mode, order
     same(dev.to_matlab(got), want, "disparity level with a-priori")
     plain = ms.disp_level(oracle, I0, I1, U0, param)
     assert not np.array_equal(plain, want)  # the term acts
+
+
+def test_weights_inverse_sqrt_shortcut_is_the_exact_sequence(pdeip):
+    """single(1 ./ sqrt(x)) in the diffusion-weight kernels: the short sequence (v_rsq_f64 + two Newton steps, exact fallback near a
+    single rounding boundary) against the exact one (double sqrt, double divide, one rounding) on 64 M arguments, an eighth of
+    them constructed to land within 3 ulp of a rounding boundary."""
+    lib = pdeip.capi.load()
+    for seed in (1, 2):
+        assert lib.pdeip_selftest_inv_sqrt(1 << 25, seed) == 0
