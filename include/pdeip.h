@@ -340,6 +340,14 @@ int pdeip_flow_assemble_gradmag_dev(void *stream, const float *It1, const float 
                                     const float *Ixt, const float *Iyt, const float *Ixx, const float *Iyy, const float *Ixy, int C2,
                                     float b2, const float *dU, const float *dV, float alpha, int nrows, int ncols, float *MGd,
                                     float *CuGd, float *CvGd, float *DuGd, float *DvGd);
+/* One inner iteration's nine coefficient planes in one pass: the assembly above (second term: three first-order planes with
+ * Iyy = Ixy = NULL, or the five gradient-magnitude planes Ixt, Iyt, Ixx, Iyy, Ixy) and OPdiffWeights(U+dU, V+dV) (:389-433,
+ * pdeip_flow_opdiffweights_dev) of the same iterate -- both only read dU, dV, so the drivers' two calls fuse into one launch. */
+int pdeip_flow_assemble_weights_dev(void *stream, const float *It1, const float *Ix1, const float *Iy1, int C1, float b1,
+                                    const float *A2, const float *B2, const float *C2p, const float *Iyy, const float *Ixy, int C2,
+                                    float b2, const float *U, const float *V, const float *dU, const float *dV, float alpha, int nrows,
+                                    int ncols, float *MGd, float *CuGd, float *CvGd, float *DuGd, float *DvGd, float *wW, float *wN,
+                                    float *wS, float *wE);
 /* disparity twin (matlab/disparity/DispEminND_llin_2D.m:236-238, :271) */
 int pdeip_disp_assemble_gradmag_dev(void *stream, const float *It1, const float *Ix1, int C1, float b1, const float *Ixt,
                                     const float *Iyt, const float *Ixx, const float *Ixy, int C2, float b2, const float *dU, float alpha,
@@ -424,6 +432,11 @@ int pdeip_fas_prepare_dev(void *stream, const float *It0, const float *It1, int 
 int pdeip_fas_assemble_dev(void *stream, const float *planes, const float *Cu, const float *Cv, const float *U, const float *V,
                            int nrows, int ncols, int frames, float b1, float b2, float k, int per_frame, float *MGd, float *CuGd,
                            float *CvGd, float *DuGd, float *DvGd, float *gd);
+/* The smoother's two calls of one firstLoop iteration in one launch: pdeip_fas_assemble_dev with per_frame = 0 and
+ * OPdiffWeights(U, V) (:392). */
+int pdeip_fas_assemble_weights_dev(void *stream, const float *planes, const float *Cu, const float *Cv, const float *U, const float *V,
+                                   int nrows, int ncols, int frames, float b1, float b2, float k, float *MGd, float *CuGd, float *CvGd,
+                                   float *DuGd, float *DvGd, float *wW, float *wN, float *wS, float *wE);
 /* imfilter(in*scale, [1 2 1;2 4 2;1 2 1]/16, 'replicate', 'conv')(1:2:end, 1:2:end, :) (:200, :212-217) */
 int pdeip_fas_restrict_dev(void *stream, const float *in, int nrows, int ncols, int frames, float scale, float *out);
 /* out = (R + A)./gd (:250-251) */

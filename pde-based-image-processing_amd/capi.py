@@ -77,12 +77,14 @@ SIGNATURES = {
     "pdeip_fas_down_dev": [_P, _P, _I, _I, _I, _P],
     "pdeip_fas_prepare_dev": [_P, _P, _P, _I, _I, _I, _F, _F, _P],
     "pdeip_fas_assemble_dev": [_P] * 6 + [_I, _I, _I, _F, _F, _F, _I] + [_P] * 6,
+    "pdeip_fas_assemble_weights_dev": [_P] * 6 + [_I, _I, _I, _F, _F, _F] + [_P] * 9,
     "pdeip_fas_restrict_dev": [_P, _P, _I, _I, _I, _F, _P],
     "pdeip_fas_rhs_dev": [_P, _P, _P, _P, _I, _I, _I, _P],
     "pdeip_fas_prolong_add_dev": [_P, _P, _I, _I, _P, _P, _I, _I, _F],
     "pdeip_fas_upscale_dev": [_P, _P, _I, _I, _F, _I, _I, _P],
     "pdeip_ad_weights_dev": [_P, _P, _I, _I, _I, ctypes.c_double] + [_P] * 8,
     "pdeip_tv4_assemble_dev": [_P, _P, _P, _I, _I, _I, _F] + [_P] * 6,
+    "pdeip_flow_assemble_weights_dev": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _F, _I, _I] + [_P] * 9,
     "pdeip_flow_assemble_gradmag_dev": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P, _I, _F, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
     "pdeip_disp_assemble_gradmag_dev": [_P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _F, _P, _F, _I, _I, _P, _P],
     "pdeip_rgb2grad_dev": [_P, _P, _I, _I, _I, _P],

@@ -90,9 +90,10 @@ __global__ void k_fas_prepare(float *planes, const float *It0, const float *It1,
 template <bool PER_FRAME>
 __global__ void k_fas_assemble(float *MGd, float *CuGd, float *CvGd, float *DuGd, float *DvGd, float *gd_out, const float *planes,
                                const float *Cu, const float *Cv, const float *U, const float *V, int C, float b1, float b2, float k,
-                               int nrows, int ncols)
+                               int nrows, int ncols, FlowWeightsOut W)
 {
     PDEIP_PIXEL_INDEX();
+    if (W.wW) opdiffweights_pixel(W.wW, W.wN, W.wS, W.wE, U, V, nullptr, nullptr, i, j, pos, nrows, ncols); // OPdiffWeights(U, V) (:392)
     const size_t n = (size_t)nrows * ncols, blk = n * C;
     const float u = U[pos], v = V[pos];
     float m = 0.0f, cu = 0.0f, cv = 0.0f, du = 0.0f, dv = 0.0f;

@@ -43,10 +43,21 @@ __device__ __forceinline__ void nan_add(float &acc, float v)
     if (!is_nan(v)) acc = acc + v;
 }
 
+__device__ __forceinline__ void opdiffweights_pixel(float *wW, float *wN, float *wS, float *wE, const float *U, const float *V,
+                                                    const float *dU, const float *dV, int i, int j, size_t pos, int nrows, int ncols);
+
+// One inner iteration's coefficient planes in one pass: the robust data terms below and, when the weight planes are given,
+// OPdiffWeights(U+dU, V+dV) of the same iterate (both only read dU, dV; the weights also their neighbours).
+struct FlowWeightsOut {
+    float *wW = nullptr, *wN = nullptr, *wS = nullptr, *wE = nullptr;
+    const float *U = nullptr, *V = nullptr;
+};
+
 __global__ void k_flow_assemble(float *MGd, float *CuGd, float *CvGd, float *DuGd, float *DvGd, FlowTerm t1, FlowTerm t2,
-                                const float *dU, const float *dV, float alpha, int nrows, int ncols)
+                                const float *dU, const float *dV, float alpha, int nrows, int ncols, FlowWeightsOut W)
 {
     PDEIP_PIXEL_INDEX();
+    if (W.wW) opdiffweights_pixel(W.wW, W.wN, W.wS, W.wE, W.U, W.V, dU, dV, i, j, pos, nrows, ncols);
     const size_t n = (size_t)nrows * ncols;
     const float du = dU[pos], dv = dV[pos];
     float m = 0.0f, cu = 0.0f, cv = 0.0f, Du = 0.0f, Dv = 0.0f;
@@ -247,10 +258,9 @@ __device__ __forceinline__ float single_inv_sqrt(double x)
 // east and the south weight of its pixel and also stores them as the west weight of its east neighbour and the north weight
 // of its south neighbour: half the double-precision work of evaluating four directions per pixel, every plane entry
 // written exactly once.
-__global__ void k_flow_opdiffweights(float *wW, float *wN, float *wS, float *wE, const float *U, const float *V,
-                                     const float *dU, const float *dV, int nrows, int ncols)
+__device__ __forceinline__ void opdiffweights_pixel(float *wW, float *wN, float *wS, float *wE, const float *U, const float *V,
+                                                    const float *dU, const float *dV, int i, int j, size_t pos, int nrows, int ncols)
 {
-    PDEIP_PIXEL_INDEX();
     // value of field f (0: U+dU, 1: V+dV) at (ii,jj), double
     auto F = [&](int f, int ii, int jj) -> double {
         const size_t p = (size_t)jj * nrows + ii;
@@ -283,6 +293,13 @@ __global__ void k_flow_opdiffweights(float *wW, float *wN, float *wS, float *wE,
     wW[(size_t)je * nrows + i] = we;
     wS[pos] = ws;
     wN[(size_t)j * nrows + is] = ws;
+}
+
+__global__ void k_flow_opdiffweights(float *wW, float *wN, float *wS, float *wE, const float *U, const float *V,
+                                     const float *dU, const float *dV, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    opdiffweights_pixel(wW, wN, wS, wE, U, V, dU, dV, i, j, pos, nrows, ncols);
 }
 
 // medfilt2(A + B, [3 3], 'symmetric') (:352-353): exact selection of the 5th of 9, symmetric padding

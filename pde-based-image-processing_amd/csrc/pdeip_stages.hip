@@ -129,7 +129,27 @@ extern "C" int pdeip_flow_assemble_dev(void *stream, const float *It1, const flo
     if (C2 < 0 || (C2 > 0 && (!It2 || !Ix2 || !Iy2))) return set_err(PDEIP_ERR_ARG, "%s: second data term needs its three derivative arrays", who);
     const FlowTerm t1{It1, Ix1, Iy1, C1, b1}, t2{It2, Ix2, Iy2, C2, b2};
     hipLaunchKernelGGL(k_flow_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), MGd, CuGd, CvGd, DuGd,
-                       DvGd, t1, t2, dU, dV, alpha, nrows, ncols);
+                       DvGd, t1, t2, dU, dV, alpha, nrows, ncols, FlowWeightsOut{});
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_flow_assemble_weights_dev(void *stream, const float *It1, const float *Ix1, const float *Iy1, int C1, float b1,
+                                               const float *A2, const float *B2, const float *C2p, const float *Iyy, const float *Ixy, int C2,
+                                               float b2, const float *U, const float *V, const float *dU, const float *dV, float alpha, int nrows,
+                                               int ncols, float *MGd, float *CuGd, float *CvGd, float *DuGd, float *DvGd, float *wW, float *wN,
+                                               float *wS, float *wE)
+{
+    const char *who = "pdeip_flow_assemble_weights_dev";
+    RC(check_dims(who, nrows, ncols, C1));
+    if (C2 < 0 || (C2 > 0 && (!A2 || !B2 || !C2p)) || ((Iyy != nullptr) != (Ixy != nullptr)))
+        return set_err(PDEIP_ERR_ARG, "%s: second data term needs its three (or, gradient magnitude, five) derivative arrays", who);
+    if (!U || !V || !dU || !dV || !wW || !wN || !wS || !wE) return set_err(PDEIP_ERR_ARG, "%s: missing plane", who);
+    const FlowTerm t1{It1, Ix1, Iy1, C1, b1}, t2{A2, B2, C2p, C2, b2, Iyy, Ixy};
+    FlowWeightsOut W;
+    W.wW = wW; W.wN = wN; W.wS = wS; W.wE = wE; W.U = U; W.V = V;
+    hipLaunchKernelGGL(k_flow_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), MGd, CuGd, CvGd, DuGd,
+                       DvGd, t1, t2, dU, dV, alpha, nrows, ncols, W);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }
@@ -158,7 +178,7 @@ extern "C" int pdeip_flow_assemble_gradmag_dev(void *stream, const float *It1, c
     if (C2 < 1 || !Ixt || !Iyt || !Ixx || !Iyy || !Ixy) return set_err(PDEIP_ERR_ARG, "%s: the gradient-magnitude term needs its five derivative arrays", who);
     const FlowTerm t1{It1, Ix1, Iy1, C1, b1}, t2{Ixt, Iyt, Ixx, C2, b2, Iyy, Ixy};
     hipLaunchKernelGGL(k_flow_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), MGd, CuGd, CvGd, DuGd,
-                       DvGd, t1, t2, dU, dV, alpha, nrows, ncols);
+                       DvGd, t1, t2, dU, dV, alpha, nrows, ncols, FlowWeightsOut{});
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }
@@ -268,10 +288,25 @@ extern "C" int pdeip_fas_assemble_dev(void *stream, const float *planes, const f
     const auto s = static_cast<hipStream_t>(stream);
     if (per_frame)
         hipLaunchKernelGGL(k_fas_assemble<true>, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, MGd, CuGd, CvGd, DuGd, DvGd, gd, planes, Cu, Cv, U,
-                           V, frames, b1, b2, k, nrows, ncols);
+                           V, frames, b1, b2, k, nrows, ncols, FlowWeightsOut{});
     else
         hipLaunchKernelGGL(k_fas_assemble<false>, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, MGd, CuGd, CvGd, DuGd, DvGd, gd, planes, Cu, Cv, U,
-                           V, frames, b1, b2, k, nrows, ncols);
+                           V, frames, b1, b2, k, nrows, ncols, FlowWeightsOut{});
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
+extern "C" int pdeip_fas_assemble_weights_dev(void *stream, const float *planes, const float *Cu, const float *Cv, const float *U, const float *V,
+                                              int nrows, int ncols, int frames, float b1, float b2, float k, float *MGd, float *CuGd, float *CvGd,
+                                              float *DuGd, float *DvGd, float *wW, float *wN, float *wS, float *wE)
+{
+    RC(check_dims("pdeip_fas_assemble_weights_dev", nrows, ncols, frames));
+    if (!MGd || !DuGd || !DvGd || (Cu && !CuGd) || (Cv && !CvGd) || !wW || !wN || !wS || !wE)
+        return set_err(PDEIP_ERR_ARG, "pdeip_fas_assemble_weights_dev: missing output plane");
+    FlowWeightsOut W;
+    W.wW = wW; W.wN = wN; W.wS = wS; W.wE = wE;
+    hipLaunchKernelGGL(k_fas_assemble<false>, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), MGd, CuGd, CvGd, DuGd,
+                       DvGd, nullptr, planes, Cu, Cv, U, V, frames, b1, b2, k, nrows, ncols, W);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

@@ -226,6 +226,23 @@ def flow_assemble(term1, term2, dU, dV, alpha, MGd, CuGd, CvGd, DuGd, DvGd):
               float(alpha), nrows, ncols, *_p(MGd, CuGd, CvGd, DuGd, DvGd))
 
 
+def flow_assemble_weights(term1, term2, U, V, dU, dV, alpha, MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wS, wE):
+    """flow_assemble + flow_opdiffweights(U, V, dU, dV) in one launch (both only read the iterate)."""
+    It1, Ix1, Iy1, b1 = term1
+    _chk(It1, Ix1, Iy1, U, V, dU, dV, MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wS, wE)
+    nrows, ncols, C1 = _dims(It1)
+    if term2 is None:
+        p2, C2, b2 = [None] * 5, 0, 0.0
+    elif len(term2) == 6:
+        _chk(*term2[:5])
+        p2, C2, b2 = _p(*term2[:5]), _dims(term2[0])[2], term2[5]
+    else:
+        _chk(*term2[:3])
+        p2, C2, b2 = _p(*term2[:3]) + [None, None], _dims(term2[0])[2], term2[3]
+    capi.call("pdeip_flow_assemble_weights_dev", _stream(), *_p(It1, Ix1, Iy1), C1, float(b1), *p2, C2, float(b2), *_p(U, V, dU, dV),
+              float(alpha), nrows, ncols, *_p(MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wS, wE))
+
+
 def flow_opdiffweights(U, V, dU, dV, wW, wN, wS, wE):
     """dU = dV = None: OPdiffWeights(U, V)."""
     _chk(U, V, wW, wN, wS, wE) if dU is None else _chk(U, V, dU, dV, wW, wN, wS, wE)
@@ -323,6 +340,15 @@ def fas_assemble(planes, Cu, Cv, U, V, b1, b2, k, per_frame, MGd, CuGd, CvGd, Du
     opt = lambda t: None if t is None else (_chk(t), t.data_ptr())[1]
     capi.call("pdeip_fas_assemble_dev", _stream(), planes.data_ptr(), opt(Cu), opt(Cv), *_p(U, V), nrows, ncols, F, float(b1),
               float(b2), float(k), int(bool(per_frame)), MGd.data_ptr(), opt(CuGd), opt(CvGd), DuGd.data_ptr(), DvGd.data_ptr(), opt(gd))
+
+
+def fas_assemble_weights(planes, Cu, Cv, U, V, b1, b2, k, MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wS, wE):
+    """fas_assemble(per_frame=False) + flow_opdiffweights(U, V, None, None) in one launch."""
+    _chk(planes, U, V, MGd, DuGd, DvGd, wW, wN, wS, wE)
+    nrows, ncols, _ = _dims(U)
+    opt = lambda t: None if t is None else (_chk(t), t.data_ptr())[1]
+    capi.call("pdeip_fas_assemble_weights_dev", _stream(), planes.data_ptr(), opt(Cu), opt(Cv), *_p(U, V), nrows, ncols, planes.shape[1],
+              float(b1), float(b2), float(k), MGd.data_ptr(), opt(CuGd), opt(CvGd), DuGd.data_ptr(), DvGd.data_ptr(), *_p(wW, wN, wS, wE))
 
 
 def fas_restrict(A, scale):

@@ -65,8 +65,8 @@ class FasFmgFlow:
         new = lambda: torch.empty_like(U)
         coef = [new() for _ in range(9)]   # MGd CuGd CvGd DuGd DvGd wW wN wE wS
         for _ in range(int(p["firstLoop"])):
-            dev.fas_assemble(pl, Cu, Cv, U, V, p["b1"], p["b2"], C * p["alpha"], False, *coef[:5])
-            dev.flow_opdiffweights(U, V, None, None, coef[5], coef[6], coef[8], coef[7])     # returns wW wN wS wE
+            # robust data weights (:377-397) and OPdiffWeights(U, V) (:392) of the same iterate: one launch (wW wN wS wE order)
+            dev.fas_assemble_weights(pl, Cu, Cv, U, V, p["b1"], p["b2"], C * p["alpha"], *coef[:5], coef[5], coef[6], coef[8], coef[7])
             self._solve(U, V, coef)
         if not residuals:
             return None

@@ -52,12 +52,12 @@ class FlowLlinLevel:
                     t2 = (d2[0], d2[1], d2[2], p["b2"])
             dU, dV = torch.zeros_like(U), torch.zeros_like(V)
             for k in range(int(p["secondLoop"])):
-                dev.flow_assemble(t1, t2, dU, dV, p["alpha"], *coef[:5])
+                # robust assembly and OPdiffWeights(U+dU, V+dV) of the same iterate in one launch (weights in wW wN wS wE order)
+                dev.flow_assemble_weights(t1, t2, U, V, dU, dV, p["alpha"], *coef[:5], coef[5], coef[6], coef[8], coef[7])
                 if Us is not None:
                     dev.flow_apriori(Us, U, dU, p["gammaS"], p["alpha"], as_diff, u_double and first == 0, k == 0, coef[1], coef[3])
                 if Vs is not None:
                     dev.flow_apriori(Vs, V, dV, p["gammaS"], p["alpha"], as_diff, u_double and first == 0, k == 0, coef[2], coef[4])
-                dev.flow_opdiffweights(U, V, dU, dV, coef[5], coef[6], coef[8], coef[7])   # returns wW wN wS wE
                 self._solve(U, V, dU, dV, coef)
             dev.median3(U, dU, Un)
             dev.median3(V, dV, Vn)
