@@ -322,6 +322,11 @@ int pdeip_snd_derivatives5_dev(void *stream, const float *It0, const float *It1,
  * checked against oracle/matlab_side.py, not against MATLAB ("parity unpinned"). */
 /* X = single((1:cols) + U), Y = single((1:rows)' + V): the warp coordinates (:223) */
 int pdeip_flow_coords_dev(void *stream, const float *U, const float *V, int nrows, int ncols, float *X, float *Y);
+/* The warp step of one firstLoop iteration in one launch (:223-231): W1 = bilinInterp2(I1, X+U, Y+V) and, with C2 > 0,
+ * W2 = bilinInterp2(I2, X+U, Y+V), X,Y = meshgrid(1:cols,1:rows), the sums rounded to single as pdeip_flow_coords_dev stores
+ * them.  V may be NULL (warp along x only). */
+int pdeip_flow_warp_dev(void *stream, const float *U, const float *V, const float *I1, int C1, const float *I2, int C2, int nrows,
+                        int ncols, float *W1, float *W2);
 /* robust data-term assembly (:283-327): gD = b./(alpha*sqrt((It - Ix.*dU - Iy.*dV).^2 + 1e-5)) per channel of one or
  * two data terms ([nrows x ncols x C] derivative arrays; C2 = 0: no second term), then nansum over all channels of
  * (Iy.*Ix).*gD -> MGd, (It.*Ix).*gD -> CuGd, (It.*Iy).*gD -> CvGd, (Ix.*Ix).*gD -> DuGd, (Iy.*Iy).*gD -> DvGd. */
@@ -455,6 +460,9 @@ int pdeip_tv_assemble_dev(void *stream, const float *Iout, const float *Iin, int
                           float *aE, float *aSE, float *aS, float *aSW);
 /* out = medfilt2(A + B, [3 3], 'symmetric') (:352); B may be NULL (out = medfilt2(A)); out must not alias A or B */
 int pdeip_median3_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out);
+/* Two fields in one launch: out0 = medfilt2(A0 + B0), out1 = medfilt2(A1 + B1) (:352-353 filters U+dU and V+dV). */
+int pdeip_median3_pair_dev(void *stream, const float *A0, const float *B0, const float *A1, const float *B1, int nrows, int ncols,
+                           float *out0, float *out1);
 
 #ifdef __cplusplus
 }

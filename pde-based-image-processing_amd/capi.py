@@ -68,6 +68,7 @@ SIGNATURES = {
     "pdeip_disp_alr_llin4_dev": _sig(1 + 8, [_I, _I, _I, _F, _I]),
     "pdeip_pde_alr4_dev": _sig(1 + 7, [_I, _I, _I, _I, _F, _I]),
     "pdeip_pde_alr8_dev": _sig(1 + 11, [_I, _I, _I, _I, _F, _I]),
+    "pdeip_flow_warp_dev": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P],
     "pdeip_flow_coords_dev": [_P, _P, _P, _I, _I, _P, _P],
     "pdeip_flow_assemble_dev": [_P, _P, _P, _P, _I, _F, _P, _P, _P, _I, _F, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
     "pdeip_disp_assemble_dev": [_P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _F, _I, _I, _P, _P],
@@ -98,6 +99,7 @@ SIGNATURES = {
     "pdeip_flow_opdiffweights_dev": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "pdeip_selftest_inv_sqrt": [_I, ctypes.c_uint],
     "pdeip_tv_assemble_dev": [_P, _P, _P, _I, _I, _I, _F] + [_P] * 10,
+    "pdeip_median3_pair_dev": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
     "pdeip_median3_dev": [_P, _P, _P, _I, _I, _P],
     "pdeip_oflow_res_elin4_dev": _sig(1 + 13, [_I, _I, _I]),
     "pdeip_oflow_lhs_elin4_dev": _sig(1 + 11, [_I, _I, _I]),

@@ -311,9 +311,16 @@ __device__ __forceinline__ void cswap(float &a, float &b)
     b = hi;
 }
 
-__global__ void k_median3_sum(float *out, const float *A, const float *B, int nrows, int ncols)
+// blockIdx.z = 1 filters the second field (out1 = medfilt2(A1 + B1)): the drivers filter U+dU and V+dV back to back
+__global__ void k_median3_sum(float *out, const float *A, const float *B, int nrows, int ncols, float *out1 = nullptr, const float *A1 = nullptr,
+                              const float *B1 = nullptr)
 {
     PDEIP_PIXEL_INDEX();
+    if (blockIdx.z == 1) {
+        out = out1;
+        A = A1;
+        B = B1;
+    }
     float v[9];
 #pragma unroll
     for (int dj = -1; dj <= 1; ++dj)

@@ -222,14 +222,15 @@ static __global__ void k_diffweights6(float *wW, float *wN, float *wE, float *wS
 
 // ---- bilinear warp: bilinInterp2 (imageInterpolation.c:44-140) --------------------------------
 
-static __global__ void k_warp_bilinear(float *Iout, const float *Iin, const float *X, const float *Y,
-                                int nrows, int ncols, int nframes)
+// One pixel of bilinInterp2 at the 1-based sampling position (Xp, Yp): every frame of up to two image stacks (the drivers warp
+// the first and the second constancy image with the same coordinates).
+__device__ __forceinline__ void warp_pixel(float Xp, float Yp, size_t pos, int nrows, int ncols, float *Iout, const float *Iin, int nframes,
+                                           float *Iout2, const float *Iin2, int nframes2)
 {
-    PDEIP_PIXEL_INDEX();
     const size_t n = (size_t)nrows * ncols;
     // :82-86.  The reference casts floor() to unsigned and lets negatives wrap out of range; HIP's
     // float->unsigned conversion saturates instead, so the range test is explicit and signed.
-    const float xm = X[pos] - 1.0f, ym = Y[pos] - 1.0f;
+    const float xm = Xp - 1.0f, ym = Yp - 1.0f;
     const float fx = floorf(xm), fy = floorf(ym);
     const bool inside = (fx >= 0.0f) && (fx < (float)ncols) && (fy >= 0.0f) && (fy < (float)nrows);
     if (inside) {
@@ -243,18 +244,36 @@ static __global__ void k_warp_bilinear(float *Iout, const float *Iin, const floa
         const size_t dx = (x < ncols - 1) ? (size_t)nrows : 0, dy = (y < nrows - 1) ? 1 : 0; // :105-110
         const size_t p10 = p00 + dx, p01 = p00 + dy;
         const size_t p11 = (x < ncols - 1 && y < nrows - 1) ? p00 + nrows + 1 : p00;
-        for (int k = 0; k < nframes; k++) {
-            const float *src = Iin + (size_t)k * n;
+        for (int k = 0; k < nframes + nframes2; k++) {
+            const float *src = k < nframes ? Iin + (size_t)k * n : Iin2 + (size_t)(k - nframes) * n;
             float r = w00 * src[p00]; // :120-123, left to right
             r = r + w10 * src[p10];
             r = r + w01 * src[p01];
             r = r + w11 * src[p11];
-            Iout[(size_t)k * n + pos] = r;
+            (k < nframes ? Iout + (size_t)k * n : Iout2 + (size_t)(k - nframes) * n)[pos] = r;
         }
     } else {
         const float nanv = __int_as_float(0x7fc00000);
         for (int k = 0; k < nframes; k++) Iout[(size_t)k * n + pos] = nanv; // :129-135
+        for (int k = 0; k < nframes2; k++) Iout2[(size_t)k * n + pos] = nanv;
     }
+}
+
+static __global__ void k_warp_bilinear(float *Iout, const float *Iin, const float *X, const float *Y,
+                                int nrows, int ncols, int nframes)
+{
+    PDEIP_PIXEL_INDEX();
+    warp_pixel(X[pos], Y[pos], pos, nrows, ncols, Iout, Iin, nframes, nullptr, nullptr, 0);
+}
+
+// The drivers' warp step in one launch (FlowEminND_llin_2D_v10.m:223-231): X,Y = meshgrid(1:cols,1:rows); both constancy images
+// sampled at single(X+U), single(Y+V) (V may be NULL: the disparity drivers warp along x only).
+static __global__ void k_flow_warp(float *Iout, const float *Iin, int nframes, float *Iout2, const float *Iin2, int nframes2, const float *U,
+                                   const float *V, int nrows, int ncols)
+{
+    PDEIP_PIXEL_INDEX();
+    const float Xp = (float)(j + 1) + U[pos], Yp = V ? (float)(i + 1) + V[pos] : (float)(i + 1);
+    warp_pixel(Xp, Yp, pos, nrows, ncols, Iout, Iin, nframes, Iout2, Iin2, nframes2);
 }
 
 // ---- Simoncelli derivatives: fstSimoncelli_c / sndSimoncelli_c (imageDerivatives.c:309-482) --------

@@ -221,7 +221,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
                 const int k = iter - it < per_launch ? iter - it : per_launch;
                 const bool gated = sp.nslabs > 1 && P.it_in[0] == P.it_out[0];
                 if (gated) d->persist_used = true; // a timed-out wait raises the sticky abort word
-                hipLaunchKernelGGL(k_sor_small<Mdl>, dim3((unsigned)sp.nslabs, (unsigned)nframes), dim3(SMALL_THREADS), sp.lds, s, P, nrows, ncols, k,
+                hipLaunchKernelGGL(k_sor_small<Mdl>, dim3((unsigned)sp.nslabs, (unsigned)nframes), dim3(SL::THREADS), sp.lds, s, P, nrows, ncols, k,
                                    omega, col0, n, sp.W, gated ? counter : nullptr, abort_word);
                 for (int f = 0; f < NIT; f++) P.it_in[f] = P.it_out[f]; // later launches of the call: in place on the result
             }

@@ -12,7 +12,7 @@
 //     pixel (u,v | du,dv,U,V | dU,U | x), split by row parity: pixel (i,j) sits at [(i&1)][j][i>>1].  The pixels of one
 //     colour in one column are then contiguous, so consecutive lanes read consecutive vectors: every neighbour is one
 //     conflict-free ds_read_b64/b128 instead of NIT+NRO strided dword reads;
-//   * every thread owns up to Q pixels of each colour (slot = thread + 1024 q of the colour's column-major enumeration)
+//   * every thread owns up to Q pixels of each colour (slot = thread + THREADS q of the colour's column-major enumeration)
 //     and keeps their coefficients -- divisors derived once, as the reference's first sweep does -- in registers for the
 //     whole launch, so a half-sweep is five LDS reads, Mdl::update(), one LDS write per pixel; one workgroup barrier per
 //     half-sweep; the border replicate (rows, then columns: opticalflowSolvers.c:161-179) in LDS after every sweep;
@@ -27,7 +27,7 @@
 
 namespace pdeip {
 
-constexpr int SMALL_THREADS = 1024;
+constexpr int SMALL_THREADS_MAX = 1024;
 constexpr int SMALL_MAX_SLABS = 128;   // workgroups per frame set: all co-resident (256 CUs, one workgroup each)
 constexpr int SMALL_MAX_SWEEPS = 4;    // sweeps per launch when the frame is cut into slabs (halo 2 x sweeps)
 constexpr size_t SMALL_LDS_CAP = (size_t)152 * 1024;
@@ -41,7 +41,10 @@ struct SmallPlan {
 template <class Mdl> struct SmallLayout {
     static constexpr int NV = Mdl::NIT + Mdl::NRO;   // floats per pixel vector
     static constexpr int VW = NV == 3 ? 4 : NV;      // padded to a power of two
-    static constexpr int Q = (NV >= 4) ? 3 : 4;      // pixels of one colour per thread (registers: 2 Q NCF coefficients)
+    // threads per workgroup and pixels of one colour per thread: 2 Q NCF coefficients stay in registers, and a workgroup of 16
+    // waves caps a wave at 128 VGPRs, one of 12 waves at 168 -- the four-field model needs the latter to reach 3840 slots
+    static constexpr int THREADS = (NV >= 4) ? 768 : 1024;
+    static constexpr int Q = (NV >= 4) ? 5 : 4;
     static_assert(VW == 1 || VW == 2 || VW == 4, "pixel vector width");
     __host__ __device__ static int pr(int nrows) { return (nrows - 1) / 2; }   // slots per column of one colour
     __host__ __device__ static int hr(int nrows) { return (nrows + 1) / 2; }   // rows per parity plane
@@ -49,7 +52,7 @@ template <class Mdl> struct SmallLayout {
     // widest slab (local columns, halo included) that q pixels per thread and colour cover and LDS holds
     static int max_local_cols(int nrows, int q)
     {
-        const long by_slots = (long)SMALL_THREADS * q / pr(nrows) + 2;
+        const long by_slots = (long)THREADS * q / pr(nrows) + 2;
         const long by_lds = (long)(SMALL_LDS_CAP / ((size_t)2 * hr(nrows) * VW * sizeof(float)));
         return (int)(by_slots < by_lds ? by_slots : by_lds);
     }
@@ -114,12 +117,12 @@ template <int VW, int N> __device__ __forceinline__ void small_write(float *lds,
 }
 
 template <class Mdl>
-__global__ void __launch_bounds__(SMALL_THREADS)
+__global__ void __launch_bounds__((SmallLayout<Mdl>::THREADS))
 k_sor_small(SweepPlanes<Mdl> P, int nrows, int ncols, int sweeps, float omega, int col0, size_t frame_stride, int W, unsigned *sync,
             unsigned *abort_flag)
 {
     using L = SmallLayout<Mdl>;
-    constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NRO1 = at_least_one<NRO>::value, NCF = Mdl::NCF, Q = L::Q, VW = L::VW;
+    constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NRO1 = at_least_one<NRO>::value, NCF = Mdl::NCF, Q = L::Q, VW = L::VW, SMALL_THREADS = L::THREADS;
     extern __shared__ __attribute__((aligned(16))) float small_lds[]; // [2 parities][ncl][HR] pixel vectors of VW floats
     const int tid = threadIdx.x;
     const size_t fo = (size_t)blockIdx.y * frame_stride;

@@ -119,6 +119,18 @@ extern "C" int pdeip_flow_coords_dev(void *stream, const float *U, const float *
     return PDEIP_OK;
 }
 
+extern "C" int pdeip_flow_warp_dev(void *stream, const float *U, const float *V, const float *I1, int C1, const float *I2, int C2, int nrows,
+                                   int ncols, float *W1, float *W2)
+{
+    const char *who = "pdeip_flow_warp_dev";
+    RC(check_dims(who, nrows, ncols, C1));
+    if (!U || !I1 || !W1 || C2 < 0 || (C2 > 0 && (!I2 || !W2))) return set_err(PDEIP_ERR_ARG, "%s: missing plane", who);
+    hipLaunchKernelGGL(k_flow_warp, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), W1, I1, C1, W2, I2, C2, U, V,
+                       nrows, ncols);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_flow_assemble_dev(void *stream, const float *It1, const float *Ix1, const float *Iy1, int C1, float b1,
                                        const float *It2, const float *Ix2, const float *Iy2, int C2, float b2, const float *dU,
                                        const float *dV, float alpha, int nrows, int ncols, float *MGd, float *CuGd, float *CvGd,
@@ -394,11 +406,23 @@ extern "C" int pdeip_selftest_inv_sqrt(int n, unsigned seed)
     return ok ? (int)h : -1;
 }
 
+extern "C" int pdeip_median3_pair_dev(void *stream, const float *A0, const float *B0, const float *A1, const float *B1, int nrows, int ncols,
+                                      float *out0, float *out1)
+{
+    RC(check_dims("pdeip_median3_pair_dev", nrows, ncols, 1));
+    if (!A0 || !A1 || !out0 || !out1 || out0 == A0 || out0 == B0 || out1 == A1 || out1 == B1 || out0 == A1 || out0 == B1 || out1 == A0 || out1 == B0)
+        return set_err(PDEIP_ERR_ARG, "pdeip_median3_pair_dev: outputs must not alias an input");
+    hipLaunchKernelGGL(k_median3_sum, pixel_grid(nrows, ncols, 2), dim3(256), 0, static_cast<hipStream_t>(stream), out0, A0, B0, nrows, ncols, out1,
+                       A1, B1);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_median3_dev(void *stream, const float *A, const float *B, int nrows, int ncols, float *out)
 {
     RC(check_dims("pdeip_median3_dev", nrows, ncols, 1));
     if (out == A || out == B) return set_err(PDEIP_ERR_ARG, "pdeip_median3_dev: output must not alias an input");
-    hipLaunchKernelGGL(k_median3_sum, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), out, A, B, nrows, ncols);
+    hipLaunchKernelGGL(k_median3_sum, pixel_grid(nrows, ncols, 1), dim3(256), 0, static_cast<hipStream_t>(stream), out, A, B, nrows, ncols, nullptr, nullptr, nullptr);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

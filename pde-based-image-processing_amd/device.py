@@ -205,6 +205,17 @@ def flow_coords(U, V, X, Y):
     capi.call("pdeip_flow_coords_dev", _stream(), *_p(U, V), nrows, ncols, *_p(X, Y))
 
 
+def flow_warp(U, V, I1, W1, I2=None, W2=None):
+    """W1 = warp(I1) and optionally W2 = warp(I2) at (X+U, Y+V) in one launch (flow_coords + warp_bilinear x 2)."""
+    _chk(U, V, I1, W1)
+    nrows, ncols, C1 = _dims(I1)
+    if I2 is None:
+        capi.call("pdeip_flow_warp_dev", _stream(), *_p(U, V, I1), C1, None, 0, nrows, ncols, W1.data_ptr(), None)
+    else:
+        _chk(I2, W2)
+        capi.call("pdeip_flow_warp_dev", _stream(), *_p(U, V, I1), C1, I2.data_ptr(), _dims(I2)[2], nrows, ncols, *_p(W1, W2))
+
+
 def flow_assemble(term1, term2, dU, dV, alpha, MGd, CuGd, CvGd, DuGd, DvGd):
     """term = (It, Ix, Iy, b) with [C, ncols, nrows] derivative arrays; term2 may be None, or the gradient-magnitude
     term (Ixt, Iyt, Ixx, Iyy, Ixy, b) built from snd_derivatives5."""
@@ -256,6 +267,13 @@ def median3(A, B, out):
     _chk(A, out) if B is None else _chk(A, B, out)
     nrows, ncols, _ = _dims(A)
     capi.call("pdeip_median3_dev", _stream(), A.data_ptr(), None if B is None else B.data_ptr(), nrows, ncols, out.data_ptr())
+
+
+def median3_pair(A0, B0, out0, A1, B1, out1):
+    """out0 = medfilt2(A0 + B0), out1 = medfilt2(A1 + B1) in one launch."""
+    _chk(A0, B0, out0, A1, B1, out1)
+    nrows, ncols, _ = _dims(A0)
+    capi.call("pdeip_median3_pair_dev", _stream(), *_p(A0, B0, A1, B1), nrows, ncols, *_p(out0, out1))
 
 
 def disp_assemble(term1, term2, dU, alpha, CuGd, DuGd):

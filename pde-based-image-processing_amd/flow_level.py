@@ -30,7 +30,6 @@ class FlowLlinLevel:
         as_diff = 2*(1/scl_factor)^-(scl-1); u_double: this is the coarsest scale (U is still a MATLAB double in its first firstLoop)."""
         p = self.p
         new = lambda like: torch.empty_like(like)
-        X, Y = new(U), new(U)
         w1, d1 = new(I1t1), [new(I1t1) for _ in range(3)]
         gradmag = str(p.get("sndTerm", "rgb")).lower() == "gradmag"   # second term through SndDerivatives5 (:253-258)
         w2, d2 = (new(I2t1), [new(I2t1) for _ in range(5 if gradmag else 3)]) if I2t1 is not None else (None, None)
@@ -38,19 +37,17 @@ class FlowLlinLevel:
         U, V = U.clone(), V.clone()
         Un, Vn = new(U), new(U)
         for first in range(int(p["firstLoop"])):
-            dev.flow_coords(U, V, X, Y)
-            dev.warp_bilinear(I1t1, X, Y, w1)
+            dev.flow_warp(U, V, I1t1, w1, I2t1, w2)                   # both constancy images at single(X+U), single(Y+V): one launch
             dev.fst_derivatives5(I1t0, w1, *d1)                      # Idt, Idx, Idy
             t1, t2 = (d1[0], d1[1], d1[2], p["b1"]), None
             if I2t1 is not None:
-                dev.warp_bilinear(I2t1, X, Y, w2)
                 if gradmag:
                     dev.snd_derivatives5(I2t0, w2, *d2)               # Ixt, Iyt, Ixx, Iyy, Ixy
                     t2 = (*d2, p["b2"])
                 else:
                     dev.fst_derivatives5(I2t0, w2, *d2)
                     t2 = (d2[0], d2[1], d2[2], p["b2"])
-            dU, dV = torch.zeros_like(U), torch.zeros_like(V)
+            dU, dV = torch.zeros((2,) + tuple(U.shape), dtype=U.dtype, device=U.device)   # one fill for both increments
             for k in range(int(p["secondLoop"])):
                 # robust assembly and OPdiffWeights(U+dU, V+dV) of the same iterate in one launch (weights in wW wN wS wE order)
                 dev.flow_assemble_weights(t1, t2, U, V, dU, dV, p["alpha"], *coef[:5], coef[5], coef[6], coef[8], coef[7])
@@ -59,8 +56,7 @@ class FlowLlinLevel:
                 if Vs is not None:
                     dev.flow_apriori(Vs, V, dV, p["gammaS"], p["alpha"], as_diff, u_double and first == 0, k == 0, coef[2], coef[4])
                 self._solve(U, V, dU, dV, coef)
-            dev.median3(U, dU, Un)
-            dev.median3(V, dV, Vn)
+            dev.median3_pair(U, dU, Un, V, dV, Vn)
             U, Un = Un, U
             V, Vn = Vn, V
         return U, V
