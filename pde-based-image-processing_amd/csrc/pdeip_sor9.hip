@@ -36,6 +36,7 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
         RC(ws_get(WS_PING, pde8_exact_scratch_floats(nrows, ncols, nframes, iter) * sizeof(float), &scratch));
         SweepTimer timer(s);
         const int nl = pde8_run_exact(s, P, scratch, nrows, ncols, nframes, iter, omega);
+        if (nl < 0) return PDEIP_ERR_DEVICE; // LDS opt-in refused (message set by ensure_lds)
         timer.stop(nl);
         g.last_launches += nl;
         HIPCHK(hipGetLastError());

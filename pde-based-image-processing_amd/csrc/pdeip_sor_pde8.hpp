@@ -669,12 +669,8 @@ inline int pde8_run_exact(hipStream_t s, Pde8Planes P, float *side, int nrows, i
     const int B = (ncols - 2 + 63) / 64;
     const int last_m = (A - 1) + P8_G * (B - 1) + P8_H * (iter - 1);
     const dim3 grid((unsigned)(B * iter), (unsigned)nframes);
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pde8_exact), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)Pde8Layout::LDS_BYTES);
-        lds_opt_in = true;
-    }
+    // > 64 KiB of dynamic LDS needs an explicit opt-in, per device (pdeip_ctx: ensure_lds)
+    if (ensure_lds(reinterpret_cast<const void *>(&k_pde8_exact), Pde8Layout::LDS_BYTES) != PDEIP_OK) return -1;
     int launches = 0;
     for (int m = 0; m <= last_m; m++) {
         hipLaunchKernelGGL(k_pde8_exact, grid, dim3(128), Pde8Layout::LDS_BYTES, s, P, side, nrows, ncols, A, B, iter, m, omega, n);

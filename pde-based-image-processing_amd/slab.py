@@ -144,43 +144,70 @@ def _hip_pde4(it, coef, n_sweeps, omega, col0):
     device.pde_sor4(it[0], *coef, n_sweeps, omega, mode=capi.MODE_RED_BLACK, col0=col0)
 
 
-HIP_SWEEPS = {"elin4": _hip_elin4, "llin4": _hip_llin4, "disp4": _hip_disp4, "pde4": _hip_pde4}
+def _hip_pde8(it, coef, n_sweeps, omega, col0):
+    from . import capi, device
+    device.pde_sor8(it[0], *coef, n_sweeps, omega, mode=capi.MODE_RED_BLACK, col0=col0)
+
+
+HIP_SWEEPS = {"elin4": _hip_elin4, "llin4": _hip_llin4, "disp4": _hip_disp4, "pde4": _hip_pde4, "pde8": _hip_pde8}
 
 
 class SlabSolver:
-    """`iter` red-black SOR sweeps of one 5-point solver on this rank's slab.
+    """`iter` red-black SOR sweeps of one point solver on this rank's slab, and the stencil stages around them.
 
     iterate : list of local planes relaxed in place (U,V / dU,dV / dU / X), each [ncols_local, nrows]
     coef    : list of local read-only planes in the order the kernel takes them
               elin4: M,Cu,Cv,Du,Dv,wW,wN,wE,wS   llin4: U,V,M,Cu,Cv,Du,Dv,wW,wN,wE,wS
               disp4: U,Cu,Du,wW,wN,wE,wS          pde4 : TRACE,B,wW,wN,wE,wS
+              pde8 : TRACE,B,wW,wNW,wN,wNE,wE,wSE,wS,wSW   (four-colour 9-point sweep: two columns per sweep as well)
     sweeps_per_exchange : k; the domain's halo must be >= 2k.
-    """
+
+    The halo is a budget of columns: after an exchange all `halo` columns next to a cut are exact; a sweep lets two of them go
+    stale, a stencil stage computed locally from the iterate (diffusion weights: radius 1; `stage`) as many as its radius, and
+    planes derived that way need no exchange of their own.  The budget carries across calls; an exchange happens when the next
+    step would overdraw it."""
 
     def __init__(self, domain, kind="elin4", sweeps_per_exchange=4, sweep_fn=None):
         if domain.world > 1 and domain.halo < 2 * sweeps_per_exchange:
             raise ValueError("halo %d < 2 * sweeps_per_exchange (%d)" % (domain.halo, sweeps_per_exchange))
         self.dom, self.k = domain, sweeps_per_exchange
         self.sweep_fn = sweep_fn if sweep_fn is not None else HIP_SWEEPS[kind]
-        self.since = None  # sweeps relaxed since the halo was last refreshed; None: unknown, exchange first
+        self.spent = None  # halo columns gone stale since the last refresh; None: unknown, exchange first
         self._alt = None   # second plane set of the out-of-place form (solve_pingpong)
 
     def invalidate(self):
-        """The iterate planes were changed from outside (or are different tensors): refresh the halo before the next sweep."""
-        self.since = None
+        """The iterate planes were changed from outside (or are different tensors): refresh the halo before the next step."""
+        self.spent = None
+
+    def _room(self, iterate):
+        """Sweeps the budget still covers; refreshes the halo when it covers none."""
+        cap = self.dom.halo
+        if self.spent is None or cap - self.spent < 2:
+            self.dom.exchange(iterate)
+            self.spent = 0
+        return (cap - self.spent) // 2
+
+    def stage(self, iterate, radius, fn):
+        """Runs fn() -- a stencil of `radius` columns evaluated on the local planes from the iterate (weights, a residual, a
+        warp of bounded reach) -- after making sure the halo covers it: what fn produces is exact in the owned columns and as far
+        into the halo as the iterate was, less `radius`; the sweeps that follow draw on the same budget."""
+        if self.dom.world > 1:
+            if radius > self.dom.halo:
+                raise ValueError("stage radius %d exceeds the halo (%d)" % (radius, self.dom.halo))
+            if self.spent is None or self.spent + radius > self.dom.halo:
+                self.dom.exchange(iterate)
+                self.spent = 0
+            self.spent += radius
+        return fn()
 
     def solve(self, iterate, coef, iters, omega):
         """The halo budget carries over from call to call: with sweeps_per_exchange = 8 and iters = 4 every second call
         exchanges (the owned columns are exact as long as no more than halo/2 sweeps ran since the last refresh)."""
         done = 0
         while done < iters:
-            room = 0 if self.since is None else self.k - self.since
-            if room <= 0:
-                self.dom.exchange(iterate)
-                self.since, room = 0, self.k
-            k = min(room, iters - done)
+            k = min(self._room(iterate), iters - done)
             self.sweep_fn(iterate, coef, k, omega, self.dom.col0)
-            self.since += k
+            self.spent += 2 * k
             done += k
 
     def solve_pingpong(self, iterate, coef, iters, omega):
@@ -195,15 +222,10 @@ class SlabSolver:
         cur, other = list(iterate), self._alt
         done = 0
         while done < iters:
-            room = 0 if self.since is None else self.k - self.since
-            if room <= 0:
-                self.dom.exchange(cur)
-                self.since, room = 0, self.k
-            k = min(room, iters - done)
+            k = min(self._room(cur), iters - done)
             self.sweep_fn(cur, coef, k, omega, self.dom.col0, out=other)
             cur, other = other, cur
-            self.since += k
+            self.spent += 2 * k
             done += k
         self._alt = other
         return cur
-
