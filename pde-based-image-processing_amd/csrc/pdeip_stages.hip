@@ -4,7 +4,6 @@
 // -ffp-contract=off is part of the parity contract: the reference is plain C built without FMA.
 #include "pdeip_ctx.hpp"
 
-#include <rocprim/rocprim.hpp>
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
 #include "pdeip_flow.hpp"
@@ -427,6 +426,27 @@ extern "C" int pdeip_median3_dev(void *stream, const float *A, const float *B, i
     return PDEIP_OK;
 }
 
+// lambda of the squared gradient norms by radix selection (pdeip_tv.hpp): six histogram + scan pairs on the stream
+static int tv_select_lambda(hipStream_t s, TvSelectState *st, double *lambda, const double *nrm, size_t n, double quantile)
+{
+    HIPCHK(hipMemsetAsync(st, 0, sizeof(TvSelectState), s));
+    const dim3 fat((unsigned)((n + 256 * 64 - 1) / (256 * 64))), thin((unsigned)((n + 256 * 16 - 1) / (256 * 16))), block(256);
+    hipLaunchKernelGGL((k_tvsel_hist<53, 11, 64, 64>), fat, block, 0, s, st, nrm, n);
+    hipLaunchKernelGGL((k_tvsel_scan<53, 11, true, false>), dim3(1), block, 0, s, st, lambda, n, quantile);
+    hipLaunchKernelGGL((k_tvsel_hist<42, 11, 53, 64>), fat, block, 0, s, st, nrm, n);
+    hipLaunchKernelGGL((k_tvsel_scan<42, 11, false, false>), dim3(1), block, 0, s, st, lambda, n, quantile);
+    hipLaunchKernelGGL((k_tvsel_hist<31, 11, 42, 16>), thin, block, 0, s, st, nrm, n);
+    hipLaunchKernelGGL((k_tvsel_scan<31, 11, false, false>), dim3(1), block, 0, s, st, lambda, n, quantile);
+    hipLaunchKernelGGL((k_tvsel_hist<20, 11, 31, 16>), thin, block, 0, s, st, nrm, n);
+    hipLaunchKernelGGL((k_tvsel_scan<20, 11, false, false>), dim3(1), block, 0, s, st, lambda, n, quantile);
+    hipLaunchKernelGGL((k_tvsel_hist<9, 11, 20, 16>), thin, block, 0, s, st, nrm, n);
+    hipLaunchKernelGGL((k_tvsel_scan<9, 11, false, false>), dim3(1), block, 0, s, st, lambda, n, quantile);
+    hipLaunchKernelGGL((k_tvsel_hist<0, 9, 9, 16>), thin, block, 0, s, st, nrm, n);
+    hipLaunchKernelGGL((k_tvsel_scan<0, 9, false, true>), dim3(1), block, 0, s, st, lambda, n, quantile);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 // One lagged-diffusivity iteration's MATLAB-side work of TVdenoise8 (pdeip_tv.hpp): ADdiffWeights(Iout) incl. the
 // quantile lambda, PsiData, TRACE, B and the alpha-scaled weights, ready for pdeip_pde_sor8_dev / pdeip_pde_alr8_dev.
 extern "C" int pdeip_tv_assemble_dev(void *stream, const float *Iout, const float *Iin, int nrows, int ncols, int nframes,
@@ -437,18 +457,14 @@ extern "C" int pdeip_tv_assemble_dev(void *stream, const float *Iout, const floa
     RC(check_dims(who, nrows, ncols, nframes));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = (size_t)nrows * ncols;
-    size_t temp_bytes = 0;
-    double *nul = nullptr;
-    HIPCHK(rocprim::radix_sort_keys(nullptr, temp_bytes, nul, nul, n, 0, 64, s));
-    const size_t doubles = 4 * n + 2 + (temp_bytes + 7) / 8; // gx, gy, norm, sorted, lambda, sort workspace
+    const size_t doubles = 3 * n + 2 + (sizeof(TvSelectState) + 7) / 8; // gx, gy, norm, lambda, selection state
     float *basef;
     RC(ws_get(WS_TV, doubles * sizeof(double), &basef));
-    double *gx = reinterpret_cast<double *>(basef), *gy = gx + n, *nrm = gy + n, *sorted = nrm + n, *lambda = sorted + n;
-    void *temp = lambda + 2;
+    double *gx = reinterpret_cast<double *>(basef), *gy = gx + n, *nrm = gy + n, *lambda = nrm + n;
+    TvSelectState *st = reinterpret_cast<TvSelectState *>(lambda + 2);
     hipLaunchKernelGGL(k_tv_gradient, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, gx, gy, nrm, Iout, nrows, ncols, nframes);
-    HIPCHK(rocprim::radix_sort_keys(temp, temp_bytes, nrm, sorted, n, 0, 64, s));
-    hipLaunchKernelGGL(k_tv_lambda, dim3(1), dim3(64), 0, s, lambda, sorted, n, -1.0);
-    hipLaunchKernelGGL(k_tv_assemble, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, TRACE, B, aW, aNW, aN, aNE, aE, aSE, aS, aSW, gx, gy,
+    RC(tv_select_lambda(s, st, lambda, nrm, n, -1.0));
+    hipLaunchKernelGGL(k_tv_assemble, dim3((nrows + TT_R - 1) / TT_R, (ncols + TT_C - 1) / TT_C), dim3(TT_R, TT_C), 0, s, TRACE, B, aW, aNW, aN, aNE, aE, aSE, aS, aSW, gx, gy,
                        nrm, lambda, Iout, Iin, alpha, nrows, ncols, nframes);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
@@ -546,18 +562,14 @@ extern "C" int pdeip_ad_weights_dev(void *stream, const float *D, int nrows, int
     if (!(quantile > 0.0 && quantile <= 1.0)) return set_err(PDEIP_ERR_ARG, "%s: quantile must be in (0, 1]", who);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = (size_t)nrows * ncols;
-    size_t temp_bytes = 0;
-    double *nul = nullptr;
-    HIPCHK(rocprim::radix_sort_keys(nullptr, temp_bytes, nul, nul, n, 0, 64, s));
-    const size_t doubles = 4 * n + 2 + (temp_bytes + 7) / 8;
+    const size_t doubles = 3 * n + 2 + (sizeof(TvSelectState) + 7) / 8;
     float *basef;
     RC(ws_get(WS_TV, doubles * sizeof(double), &basef));
-    double *gx = reinterpret_cast<double *>(basef), *gy = gx + n, *nrm = gy + n, *sorted = nrm + n, *lambda = sorted + n;
-    void *temp = lambda + 2;
+    double *gx = reinterpret_cast<double *>(basef), *gy = gx + n, *nrm = gy + n, *lambda = nrm + n;
+    TvSelectState *st = reinterpret_cast<TvSelectState *>(lambda + 2);
     hipLaunchKernelGGL(k_tv_gradient, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, gx, gy, nrm, D, nrows, ncols, nframes);
-    HIPCHK(rocprim::radix_sort_keys(temp, temp_bytes, nrm, sorted, n, 0, 64, s));
-    hipLaunchKernelGGL(k_tv_lambda, dim3(1), dim3(64), 0, s, lambda, sorted, n, quantile);
-    hipLaunchKernelGGL(k_ad_weights, pixel_grid(nrows, ncols, 1), dim3(256), 0, s, wW, wNW, wN, wNE, wE, wSE, wS, wSW, gx, gy, nrm, lambda, nrows,
+    RC(tv_select_lambda(s, st, lambda, nrm, n, quantile));
+    hipLaunchKernelGGL(k_ad_weights, dim3((nrows + TT_R - 1) / TT_R, (ncols + TT_C - 1) / TT_C), dim3(TT_R, TT_C), 0, s, wW, wNW, wN, wNE, wE, wSE, wS, wSW, gx, gy, nrm, lambda, nrows,
                        ncols);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;

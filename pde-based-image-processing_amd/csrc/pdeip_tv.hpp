@@ -57,69 +57,181 @@ __global__ void k_tv_gradient(double *gx, double *gy, double *nrm, const float *
     nrm[pos] = bx * bx + by * by;
 }
 
-// lambda = sorted_nonzero(round(numel * 0.5 + eps)) from the ascending array `sorted` (zeros first); 1 if all are zero.
+// lambda = sorted_nonzero(round(numel * 0.5 + eps)) of the squared gradient norms (zeros excluded; 1 if all are zero);
 // quantile >= 0: the flow driver's form sorted_nonzero(round(numel * quantile)) (FlowEminAD_llin_2D_v10.m:461-467).
-__global__ void k_tv_lambda(double *lambda, const double *sorted, size_t n, double quantile)
+// Round 1 sorted all n norms (rocPRIM radix sort, 0.55 ms at 4K) to read one element.  This is the selection alone: the norms
+// are non-negative doubles (NaN counts as non-zero and as the largest value, as in an ascending sort), so their bit patterns
+// order like unsigned integers; six histogram passes over the digits 11+11+11+11+11+9 bits, most significant first, each
+// narrowing the candidates to those that share the digits found so far, leave exactly the bits of the wanted element.
+constexpr int TVSEL_BINS = 2048;
+struct TvSelectState {
+    unsigned long long prefix;  // digits found so far (in place, lower bits zero)
+    unsigned long long rank;    // 0-based rank of the wanted element among the candidates that share the prefix
+    unsigned long long zeros;   // number of exact zeros (counted in pass 0)
+    unsigned int done;          // all zero: lambda = 1
+    unsigned int hist[TVSEL_BINS];
+};
+
+__device__ __forceinline__ unsigned long long tvsel_key(double v)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    size_t lo = 0, hi = n; // first index with sorted[idx] > 0 (norms are >= 0; NaN sorts last and counts as non-zero)
-    while (lo < hi) {
-        const size_t mid = lo + (hi - lo) / 2;
-        if (sorted[mid] > 0.0 || sorted[mid] != sorted[mid]) hi = mid;
-        else lo = mid + 1;
+    return v != v ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(v);
+}
+
+// pass P: histogram of digit P over the candidates.  SHIFT = position of the digit, PREV = position of the digit before it
+// RUN norms per thread: the first two passes see (nearly) all elements spread over many bins, where fewer, fatter workgroups
+// mean fewer global merges of the 2048 bins (64); the later passes count a handful of candidates and only stream (16).
+template <int SHIFT, int BITS, int PREV, int RUN>
+__global__ void __launch_bounds__(256) k_tvsel_hist(TvSelectState *st, const double *nrm, size_t n)
+{
+    __shared__ unsigned int h[TVSEL_BINS];
+    __shared__ unsigned int zc;
+    for (int b = threadIdx.x; b < TVSEL_BINS; b += 256) h[b] = 0;
+    if (threadIdx.x == 0) zc = 0;
+    __syncthreads();
+    const unsigned long long prefix = PREV < 64 ? st->prefix : 0ull;
+    if (PREV < 64 && st->done) return;
+    // a workgroup takes 256 x RUN consecutive norms, coalesced (lane = element); a thread merges equal consecutive digits of
+    // its share before it touches LDS (the exponent digits cluster)
+    const size_t base = (size_t)blockIdx.x * 256 * RUN + threadIdx.x;
+    unsigned int cur = 0xffffffffu, cnt = 0, zeros = 0;
+#pragma unroll 4
+    for (int e = 0; e < RUN; e++) {
+        const size_t p = base + (size_t)e * 256;
+        if (p >= n) break;
+        const unsigned long long k = tvsel_key(nrm[p]);
+        if (PREV >= 64) zeros += (k == 0ull);
+        if (PREV < 64 && (k >> PREV) != (prefix >> PREV)) continue;
+        const unsigned int d = (unsigned int)(k >> SHIFT) & ((1u << BITS) - 1u);
+        if (d != cur) {
+            if (cnt) atomicAdd(&h[cur], cnt);
+            cur = d;
+            cnt = 0;
+        }
+        cnt++;
     }
-    const size_t cnt = n - lo;
-    if (cnt == 0) {
-        *lambda = 1.0;
-        return;
+    if (cnt) atomicAdd(&h[cur], cnt);
+    if (PREV >= 64 && zeros) atomicAdd(&zc, zeros);
+    __syncthreads();
+    for (int b = threadIdx.x; b < (1 << BITS); b += 256)
+        if (h[b]) atomicAdd(&st->hist[b], h[b]);
+    if (PREV >= 64 && threadIdx.x == 0 && zc) atomicAdd(&st->zeros, (unsigned long long)zc);
+}
+
+// one workgroup: find the digit whose bin holds the wanted rank, extend the prefix, clear the histogram for the next pass;
+// FIRST: turn (count of non-zeros, quantile) into the rank first; LAST: write lambda.
+template <int SHIFT, int BITS, bool FIRST, bool LAST>
+__global__ void __launch_bounds__(256) k_tvsel_scan(TvSelectState *st, double *lambda, size_t n, double quantile)
+{
+    __shared__ unsigned long long part[256];
+    __shared__ unsigned long long s_rank;
+    __shared__ int s_done;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        s_done = FIRST ? 0 : (int)st->done;
+        if (FIRST) {
+            const unsigned long long cnt = (unsigned long long)n - st->zeros;
+            if (cnt == 0) {
+                s_done = 1;
+                st->done = 1;
+                *lambda = 1.0;
+            } else {
+                unsigned long long idx = (cnt + 1) / 2; // round(cnt*0.5 + eps), 1-based
+                if (quantile >= 0.0) {
+                    idx = (unsigned long long)floor((double)cnt * quantile + 0.5);
+                    idx = idx < 1 ? 1 : (idx > cnt ? cnt : idx);
+                }
+                st->rank = st->zeros + idx - 1; // zeros sort first
+                st->done = 0;
+            }
+        }
+        s_rank = st->rank;
     }
-    size_t idx = (cnt + 1) / 2; // round(cnt*0.5 + eps), 1-based
-    if (quantile >= 0.0) {
-        idx = (size_t)floor((double)cnt * quantile + 0.5);
-        idx = idx < 1 ? 1 : (idx > cnt ? cnt : idx);
+    __syncthreads();
+    constexpr int NB = 1 << BITS, PER = (NB + 255) / 256;
+    unsigned long long loc[PER], sum = 0;
+#pragma unroll
+    for (int e = 0; e < PER; e++) {
+        const int b = t * PER + e;
+        loc[e] = b < NB ? st->hist[b] : 0;
+        sum += loc[e];
     }
-    *lambda = sorted[lo + idx - 1];
+    part[t] = sum;
+    __syncthreads();
+    if (!s_done) {
+        unsigned long long before = 0;
+        for (int q = 0; q < t; q++) before += part[q]; // 256 x 256 adds: negligible
+        const unsigned long long rank = s_rank;
+        if (rank >= before && rank < before + sum) {
+            unsigned long long acc = before;
+#pragma unroll
+            for (int e = 0; e < PER; e++) {
+                if (rank >= acc && rank < acc + loc[e]) {
+                    const unsigned long long pre = st->prefix | ((unsigned long long)(t * PER + e) << SHIFT);
+                    st->prefix = FIRST ? ((unsigned long long)(t * PER + e) << SHIFT) : pre;
+                    st->rank = rank - acc;
+                    if (LAST) *lambda = __longlong_as_double((long long)(FIRST ? ((unsigned long long)(t * PER + e) << SHIFT) : pre));
+                }
+                acc += loc[e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = t; b < TVSEL_BINS; b += 256) st->hist[b] = 0;
+    if (LAST && t == 0) st->zeros = 0;
 }
 
 // The eight weights (times alpha, as single), TRACE and B of one outer iteration (TVdenoise8.m:82-86).
-__global__ void k_tv_assemble(float *TRACE, float *B, float *aW, float *aNW, float *aN, float *aNE, float *aE, float *aSE,
-                              float *aS, float *aSW, const double *gx, const double *gy, const double *nrm,
-                              const double *lambda_p, const float *Iout, const float *Iin, float alpha_f, int nrows, int ncols,
-                              int nframes)
+// Tile form of the tensor stencils below: a workgroup of 64 x 4 threads owns 64 rows x 4 columns and evaluates the diffusion
+// tensor (one double division per pixel) ONCE for its 66 x 6 neighbourhood into LDS -- circshift wrap-around at the frame
+// edges as the drivers have it -- instead of nine times per output pixel.  Same expressions, same bits.
+constexpr int TT_R = 64, TT_C = 4;
+struct TensorTile {
+    double dyy[TT_C + 2][TT_R + 2], dxx[TT_C + 2][TT_R + 2], dxy[TT_C + 2][TT_R + 2];
+};
+
+__device__ __forceinline__ void tensor_tile_fill(TensorTile &T, const double *gx, const double *gy, const double *nrm, double lambda, int i0,
+                                                 int j0, int nrows, int ncols)
 {
-    PDEIP_PIXEL_INDEX();
-    const size_t n = (size_t)nrows * ncols;
-    const double lambda = *lambda_p, alpha = (double)alpha_f;
-    // tensor entries at (ii,jj) with circshift wrap-around
-    auto tens = [&](int ii, int jj, double &dyy, double &dxx, double &dxy) {
+    const int tid = threadIdx.y * TT_R + threadIdx.x;
+    for (int e = tid; e < (TT_C + 2) * (TT_R + 2); e += TT_R * TT_C) {
+        const int c = e / (TT_R + 2), r = e - c * (TT_R + 2);
+        int ii = i0 - 1 + r, jj = j0 - 1 + c;
+        if (ii > nrows || jj > ncols) continue; // beyond the wrap position: no output pixel reads it
         ii = ii < 0 ? nrows - 1 : (ii > nrows - 1 ? 0 : ii);
         jj = jj < 0 ? ncols - 1 : (jj > ncols - 1 ? 0 : jj);
         const size_t p = (size_t)jj * nrows + ii;
         const double x = gx[p], y = gy[p];
         const double multip = 1.0 / (nrm[p] + 2.0 * lambda);
-        dyy = multip * (y * y + lambda);
-        dxx = multip * (x * x + lambda);
-        dxy = -multip * (x * y);
-    };
-    double dyy, dxx, dxy, a, b, c;
-    tens(i, j, dyy, dxx, dxy);
+        T.dyy[c][r] = multip * (y * y + lambda);
+        T.dxx[c][r] = multip * (x * x + lambda);
+        T.dxy[c][r] = -multip * (x * y);
+    }
+}
+
+__global__ void __launch_bounds__(TT_R *TT_C)
+k_tv_assemble(float *TRACE, float *B, float *aW, float *aNW, float *aN, float *aNE, float *aE, float *aSE, float *aS, float *aSW,
+              const double *gx, const double *gy, const double *nrm, const double *lambda_p, const float *Iout, const float *Iin,
+              float alpha_f, int nrows, int ncols, int nframes)
+{
+    __shared__ TensorTile T;
+    const int i0 = blockIdx.x * TT_R, j0 = blockIdx.y * TT_C;
+    const double lambda = *lambda_p, alpha = (double)alpha_f;
+    tensor_tile_fill(T, gx, gy, nrm, lambda, i0, j0, nrows, ncols);
+    __syncthreads();
+    const int i = i0 + threadIdx.x, j = j0 + threadIdx.y;
+    if (i >= nrows || j >= ncols) return;
+    const size_t n = (size_t)nrows * ncols, pos = (size_t)j * nrows + i;
+    const int r = threadIdx.x + 1, c = threadIdx.y + 1;
+    const double dyy = T.dyy[c][r], dxx = T.dxx[c][r], dxy = T.dxy[c][r];
     const bool c0 = j == 0, cE = j == ncols - 1, r0 = i == 0, rE = i == nrows - 1;
-    tens(i, j - 1, a, b, c);
-    const double W = c0 ? 0.0 : 0.5 * (dyy + a);
-    tens(i - 1, j - 1, a, b, c);
-    const double NW = (c0 || r0) ? 0.0 : 0.25 * (dxy + c);
-    tens(i - 1, j, a, b, c);
-    const double N = r0 ? 0.0 : 0.5 * (dxx + b);
-    tens(i - 1, j + 1, a, b, c);
-    const double NE = (cE || r0) ? 0.0 : -0.25 * (dxy + c);
-    tens(i, j + 1, a, b, c);
-    const double E = cE ? 0.0 : 0.5 * (dyy + a);
-    tens(i + 1, j + 1, a, b, c);
-    const double SE = (cE || rE) ? 0.0 : 0.25 * (dxy + c);
-    tens(i + 1, j, a, b, c);
-    const double S = rE ? 0.0 : 0.5 * (dxx + b);
-    tens(i + 1, j - 1, a, b, c);
-    const double SW = (rE || c0) ? 0.0 : -0.25 * (dxy + c);
+    const double W = c0 ? 0.0 : 0.5 * (dyy + T.dyy[c - 1][r]);
+    const double NW = (c0 || r0) ? 0.0 : 0.25 * (dxy + T.dxy[c - 1][r - 1]);
+    const double N = r0 ? 0.0 : 0.5 * (dxx + T.dxx[c][r - 1]);
+    const double NE = (cE || r0) ? 0.0 : -0.25 * (dxy + T.dxy[c + 1][r - 1]);
+    const double E = cE ? 0.0 : 0.5 * (dyy + T.dyy[c + 1][r]);
+    const double SE = (cE || rE) ? 0.0 : 0.25 * (dxy + T.dxy[c + 1][r + 1]);
+    const double S = rE ? 0.0 : 0.5 * (dxx + T.dxx[c][r + 1]);
+    const double SW = (rE || c0) ? 0.0 : -0.25 * (dxy + T.dxy[c - 1][r + 1]);
     double sum = W + NW; // wW+wNW+wN+wNE+wE+wSE+wS+wSW, left to right
     sum = sum + N;
     sum = sum + NE;
@@ -192,39 +304,27 @@ __global__ void k_tv4_assemble(float *TRACE, float *B, float *aW, float *aN, flo
 
 // The eight weights of the flow driver's ADdiffWeights (FlowEminAD_llin_2D_v10.m:469-487): the same tensor, circshift
 // wrap-around kept at the frame edges (nothing zeroed), handed to Oflow_sor_llin8_2d as single.
-__global__ void k_ad_weights(float *wW, float *wNW, float *wN, float *wNE, float *wE, float *wSE, float *wS, float *wSW, const double *gx,
-                             const double *gy, const double *nrm, const double *lambda_p, int nrows, int ncols)
+__global__ void __launch_bounds__(TT_R *TT_C)
+k_ad_weights(float *wW, float *wNW, float *wN, float *wNE, float *wE, float *wSE, float *wS, float *wSW, const double *gx, const double *gy,
+             const double *nrm, const double *lambda_p, int nrows, int ncols)
 {
-    PDEIP_PIXEL_INDEX();
-    const double lambda = *lambda_p;
-    auto tens = [&](int ii, int jj, double &dyy, double &dxx, double &dxy) {
-        ii = ii < 0 ? nrows - 1 : (ii > nrows - 1 ? 0 : ii);
-        jj = jj < 0 ? ncols - 1 : (jj > ncols - 1 ? 0 : jj);
-        const size_t p = (size_t)jj * nrows + ii;
-        const double x = gx[p], y = gy[p];
-        const double multip = 1.0 / (nrm[p] + 2.0 * lambda);
-        dyy = multip * (y * y + lambda);
-        dxx = multip * (x * x + lambda);
-        dxy = -multip * (x * y);
-    };
-    double dyy, dxx, dxy, a, b, c;
-    tens(i, j, dyy, dxx, dxy);
-    tens(i, j - 1, a, b, c);
-    wW[pos] = (float)(0.5 * (dyy + a));
-    tens(i - 1, j - 1, a, b, c);
-    wNW[pos] = (float)(0.25 * (dxy + c));
-    tens(i - 1, j, a, b, c);
-    wN[pos] = (float)(0.5 * (dxx + b));
-    tens(i - 1, j + 1, a, b, c);
-    wNE[pos] = (float)(-0.25 * (dxy + c));
-    tens(i, j + 1, a, b, c);
-    wE[pos] = (float)(0.5 * (dyy + a));
-    tens(i + 1, j + 1, a, b, c);
-    wSE[pos] = (float)(0.25 * (dxy + c));
-    tens(i + 1, j, a, b, c);
-    wS[pos] = (float)(0.5 * (dxx + b));
-    tens(i + 1, j - 1, a, b, c);
-    wSW[pos] = (float)(-0.25 * (dxy + c));
+    __shared__ TensorTile T;
+    const int i0 = blockIdx.x * TT_R, j0 = blockIdx.y * TT_C;
+    tensor_tile_fill(T, gx, gy, nrm, *lambda_p, i0, j0, nrows, ncols);
+    __syncthreads();
+    const int i = i0 + threadIdx.x, j = j0 + threadIdx.y;
+    if (i >= nrows || j >= ncols) return;
+    const size_t pos = (size_t)j * nrows + i;
+    const int r = threadIdx.x + 1, c = threadIdx.y + 1;
+    const double dyy = T.dyy[c][r], dxx = T.dxx[c][r], dxy = T.dxy[c][r];
+    wW[pos] = (float)(0.5 * (dyy + T.dyy[c - 1][r]));
+    wNW[pos] = (float)(0.25 * (dxy + T.dxy[c - 1][r - 1]));
+    wN[pos] = (float)(0.5 * (dxx + T.dxx[c][r - 1]));
+    wNE[pos] = (float)(-0.25 * (dxy + T.dxy[c + 1][r - 1]));
+    wE[pos] = (float)(0.5 * (dyy + T.dyy[c + 1][r]));
+    wSE[pos] = (float)(0.25 * (dxy + T.dxy[c + 1][r + 1]));
+    wS[pos] = (float)(0.5 * (dxx + T.dxx[c][r + 1]));
+    wSW[pos] = (float)(-0.25 * (dxy + T.dxy[c - 1][r + 1]));
 }
 
 } // namespace pdeip

@@ -1,0 +1,22 @@
+"""Kernel mix of the resident levels bench.py times for BASELINE configs C3 (TV-8 loop, 2160x3840) and C5 (disparity level,
+1988x2880x3, 'grad','gradmag'), red-black SOR: two runs each, for rocprofv3 --kernel-trace --stats."""
+import importlib, sys
+sys.path.insert(0, "."); import numpy as np, torch
+fl = importlib.import_module("pde-based-image-processing_amd.flow_level"); dev = importlib.import_module("pde-based-image-processing_amd.device")
+which = sys.argv[1] if len(sys.argv) > 1 else "tv,disp,sym"
+if "tv" in which:
+    gI = torch.empty((3840, 2160), device="cuda", dtype=torch.float32).uniform_(0, 1)
+    lv = fl.TvLevel(dict(alpha=500.0, omega=1.75, outer_iter=20, inner_iter=4, solver=1), mode=1)
+    for _ in range(2):
+        lv.run(gI, gI); torch.cuda.synchronize()
+if "disp" in which or "sym" in which:
+    jj, ii = np.meshgrid(np.arange(2880), np.arange(1988))
+    tex5 = lambda dj, c: (np.sin(0.021 * ii + c) * np.cos(0.017 * (jj + dj) - c) + 0.3 * np.sin(0.11 * ii + 0.07 * (jj + dj))).astype(np.float32)
+    dL = dev.to_device(np.stack([tex5(0, c) for c in range(3)], axis=2)); dR = dev.to_device(np.stack([tex5(1.3, c) for c in range(3)], axis=2))
+    gL, gR = dev.rgb2grad(dL), dev.rgb2grad(dR)
+    dZ5 = torch.zeros((2880, 1988), device="cuda")
+    dp = dict(firstLoop=1, secondLoop=4, iter=4, omega=1.5, alpha=0.15, b1=0.25, b2=0.72, beta=0.4, sndTerm="gradmag", solver=1)
+    for _ in range(2):
+        if "disp" in which: fl.DispLlinLevel(dp, mode=1).run(gL, gR, dZ5, dL, dR)
+        if "sym" in which: fl.DispSymLevel(dp, mode=1).run(dL, dR, dZ5, dZ5, 2.0)
+        torch.cuda.synchronize()
