@@ -151,7 +151,13 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             // word 0: abort (sticky: cleared only by pdeip_persist_error(), so a timed-out wait cannot be lost under the next
             // call's reset); word 1: ticket; words 4..: progress counters
             HIPCHK(hipMemsetAsync(reinterpret_cast<unsigned *>(ctl_f) + 1, 0, (3 + nprog) * sizeof(unsigned), s));
+            // west-edge mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, field, row), tags clear at the start of a call
+            float *mail_f = nullptr;
+            const size_t mail_bytes = nprog * NIT * (size_t)nrows * sizeof(unsigned long long);
+            RC(ws_get(WS_MAIL, mail_bytes, &mail_f));
+            HIPCHK(hipMemsetAsync(mail_f, 0, mail_bytes, s));
             PersistCtl ctl;
+            ctl.mail = reinterpret_cast<unsigned long long *>(mail_f);
             ctl.abort_flag = reinterpret_cast<unsigned *>(ctl_f);
             ctl.ticket = ctl.abort_flag + 1;
             ctl.progress = ctl.abort_flag + 4;

@@ -400,11 +400,19 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
 // Persistent form: one launch per call.  A workgroup owns one (strip b, sweep t) and walks down the
 // strip chunk by chunk (same mover/compute pair and LDS layout as k_sor_exact, no tile boundaries, no
 // cold start); the launch-per-front ordering is replaced by progress counters:
-//   chunk c of (b,t) needs   progress[b-1][t]   >= c+5   (west column relaxed, and its readers done)
+//   chunk c of (b,t) needs   the west strip's east column of sweep t at the 16 rows lane 0 relaxes in chunk c
 //                            progress[b][t-1]   >= c+2   (own columns' south rows of sweep t-1)
 //                            progress[b+1][t-1] >= c-2   (east column of sweep t-1)
-// (rows relaxed by lane 63 trail lane 0 by 63 rows = 4 chunks, hence the +5).  The same three
-// conditions cover the write-after-read hazards.
+// These conditions also cover the write-after-read hazards.
+// West edge.  The one value a strip needs from its west neighbour of the SAME sweep is that neighbour's last column.  Routing
+// it through the iterate plane (store, drain, publish a counter, poll, load: four round trips, and the whole chunk fetch
+// gated on it two chunks ahead) made every strip trail its neighbour by ~12 chunk times where the dependency needs 5.  It
+// travels by a mailbox instead: the compute wave's lane 63 stores every result as one 8-byte {value, tag} word (write-
+// through, no drain: the tag makes the word self-validating), and a wave of the east strip polls the 16 words of the
+// next chunk and puts them into the LDS edge slot -- one round trip.  (That wave is the storer: its stores of the previous chunk
+// are issued first, the polls queue behind them, and the first poll to return also proves the stores drained -- the publish needs
+// no wait of its own.  A fifth wave would halve every wave's register budget; the loader holds a whole chunk in registers.)  The chunk fetch
+// itself (old values and coefficients) no longer waits for the west strip at all.
 // Hand-off (cdna_hip_programming.md Guideline 16, recipe R1): the iterate is stored write-through
 // (buffer_store ... sc1) by the mover wave only, which drains (s_waitcnt vmcnt(0)) and then publishes
 // the counter with one relaxed agent-scope atomic store; a consumer's mover polls relaxed and reads
@@ -419,6 +427,7 @@ struct PersistCtl {
     unsigned *abort_flag; // [1]
     unsigned *progress;  // [nframes][T][B] chunks completed and visible
     const int *order;    // [B*T] packed b | (t << 16), dependency-respecting order
+    unsigned long long *mail; // [nframes][T][B][NIT][nrows] east-column results of a strip, {value, tag}: see "West edge" below
 };
 
 // Wave-wide wait: lane k polls counter ptrs[k] (k < 3) until it reaches need[k]; the three polls are ONE
@@ -467,7 +476,7 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
     // LOADER polls, fetches and stashes; the STORER writes the relaxed chunk back and publishes the counter.  The coupled
     // models update u from the OLD v of the same pixel and vice versa (opticalflowSolvers.c:129-149), so their two fields are
     // relaxed by two COMPUTE waves that never exchange anything: half the instructions per step each.
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 compute (field 0 / all), 1 loader, 2 storer, 3 compute (field 1)
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 compute (field 0 / all), 1 loader, 2 storer + west edge, 3 compute (field 1)
     const bool mover = role == 1;
     if (threadIdx.x == 0) *s_ticket = atomicAdd(ctl.ticket, 1u);
     __syncthreads();
@@ -504,12 +513,13 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
         // ================================ mover wave ==========================================
         f4u preA[NP][4], preB[(NP <= 11) ? NP : 1][4], epreA[NF], epreB[NF];
         constexpr bool TWO_SETS = (NP <= 11);
-        // lane 0 watches the west strip, lane 1 this strip's previous sweep, lane 2 the east strip's previous sweep
-        const unsigned *my_ptr = lane == 0 ? prog_west : (lane == 1 ? prog_prev : (lane == 2 ? prog_east : nullptr));
+        // lane 1 watches this strip's previous sweep, lane 2 the east strip's previous sweep
+        const unsigned *my_ptr = lane == 1 ? prog_prev : (lane == 2 ? prog_east : nullptr); // the west strip: role 4
         auto wait_deps = [&](int c) __attribute__((always_inline)) {
             const int need = lane == 0 ? c + 5 : (lane == 1 ? c + 2 : c - 2);
             persist_wait3(my_ptr, (unsigned)(need < 0 ? 0 : (need < NC ? need : NC)), ctl.abort_flag);
         };
+        const bool west_by_mail = (b > 0);
         auto fetch = [&](int c, f4u (&pre)[NP][4], f4u (&epre)[NF]) __attribute__((always_inline)) {
             const int i00 = 1 + EX_CH * c;
 #pragma unroll
@@ -525,6 +535,8 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
                     as_f4u(v, pre[p][g]);
                 }
             }
+            // edge columns: east (old values) of every field; west of the read-only fields, and of the iterate fields only for
+            // the first strip (the frame's border column) -- a later strip's west iterate column is the mailbox's (role 4)
             const int which = (lane >> 2) & 1;
             const int ecol = which ? (jbase + 64 < ncols - 1 ? jbase + 64 : ncols - 1) : jbase - 1;
             const int erow = (which ? i00 - 63 : i00) + 4 * (lane & 3);
@@ -551,8 +563,9 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
                 const int which = (lane >> 2) & 1;
 #pragma unroll
                 for (int f = 0; f < NF; f++)
-                    *reinterpret_cast<float4 *>(&edge[(which * NF + f) * EX_CH + 4 * (lane & 3)]) =
-                        make_float4(epre[f].v[0], epre[f].v[1], epre[f].v[2], epre[f].v[3]);
+                    if (which == 1 || f >= NIT || !west_by_mail)
+                        *reinterpret_cast<float4 *>(&edge[(which * NF + f) * EX_CH + 4 * (lane & 3)]) =
+                            make_float4(epre[f].v[0], epre[f].v[1], epre[f].v[2], epre[f].v[3]);
             }
         };
         // chunk c is fetched two barriers before it is relaxed and stashed one barrier before.  Per interval: issue the
@@ -567,6 +580,9 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
             if (__all(my_ptr == nullptr || seen >= un)) return;
             persist_wait3(my_ptr, un, ctl.abort_flag); // not there yet: the bounded spin
         };
+        // Measured and dropped: a fetch distance of three chunks through two register sets (two intervals for a chunk to arrive)
+        // with the mailbox polled by this wave, and a publish on a counted wait one interval late in the storer -- no gain at 4K
+        // (neither the load latency nor the store drain sets the pace there), 20 % slower at iter = 20 on small frames.
         wait_deps(0);
         fetch(0, preA, epreA);
         stash(preA, epreA, 0);
@@ -634,18 +650,53 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
                     }
                 }
         };
-        // publish progress = c+1 once every store of this wave has left (recipe R1: drain, then the flag); this wave issues
-        // nothing but those stores, so the drain is a plain vmcnt(0)
+        // publish progress = c+1 once every store of this wave has left (recipe R1: drain, then the flag)
         auto publish = [&](int c) __attribute__((always_inline)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(prog_mine, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        lds_barrier(); // chunk 0 is in buffer 0
-        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: write chunk k-1 back
-            if (k >= 1) {
-                store_out(k - 1);
-                publish(k - 1);
+        // West edge of chunk c (see the header): lane = 16 f + row polls the west strip's mailbox word of that row until its tag is
+        // set and hands the value to the compute waves through the edge slot of the chunk's LDS buffer.  The polls queue behind the
+        // stores of the previous chunk, so once the first one has returned those stores have drained: publish `pub` then.
+        const int mf = lane >> 4, r16 = lane & 15;
+        const bool polls = (b > 0) && (lane < 16 * NIT);
+        const unsigned long long *mail_w = ctl.mail + ((((size_t)frame * T + t) * B + (b > 0 ? b - 1 : 0)) * NIT + (polls ? mf : 0)) * (size_t)nrows;
+        auto take = [&](int c, int pub) __attribute__((always_inline)) {
+            if (b > 0 && c < NC) { // the first strip's west column is the frame border: the loader stages it
+                const int row = 1 + EX_CH * c + r16;
+                const bool want = polls && row <= nrows - 2;
+                float v = 0.0f;
+                bool ok = !want;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+                for (;;) {
+                    if (!ok) {
+                        const unsigned long long w = __hip_atomic_load(mail_w + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(w >> 32) != 0u) {
+                            v = __uint_as_float((unsigned)w);
+                            ok = true;
+                        }
+                    }
+                    if (pub >= 0) {
+                        publish(pub);
+                        pub = -1;
+                    }
+                    if (__all(ok)) break;
+                    if (__hip_atomic_load(ctl.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) { // 0.5 s: drain the grid, the host reports it
+                        __hip_atomic_store(ctl.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (polls) (smem + (c & 1) * L::BUF + L::STAGE)[mf * EX_CH + r16] = v; // edge[(which = 0) * NF + f][row]
             }
+            if (pub >= 0) publish(pub);
+        };
+        take(0, -1);
+        lds_barrier(); // chunk 0 is in buffer 0
+        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: write chunk k-1 back, fetch the west values of chunk k+1
+            if (k >= 1) store_out(k - 1);
+            take(k + 1, k >= 1 ? k - 1 : -1);
             lds_barrier();
         }
         store_out(NC - 1);
@@ -653,12 +704,16 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
         return;
     }
 
+    // mailbox rows of this strip (written by its compute waves) and of its west neighbour (read by role 4): [NIT][nrows] words
+    unsigned long long *const mail_mine = ctl.mail + ((((size_t)frame * T + t) * B + b) * NIT) * (size_t)nrows;
     // ================================== compute wave ===========================================
     const int j = jbase + lane;
     const bool col_ok = j <= ncols - 2;
     const int jc = j < ncols - 1 ? j : ncols - 1;
     const float om1 = 1.0f - omega;
     const bool first_sweep = (t == 0);
+    const bool mails = (lane == 63) && (b + 1 < B); // my column is the next strip's west column
+    const __amdgpu_buffer_rsrc_t rs_mail = __builtin_amdgcn_make_buffer_rsrc(mail_mine, 0, (unsigned)((size_t)NIT * nrows * 8), 0x00020000);
     const int i0 = 1 - lane; // row of this lane at step 0 of chunk 0
 
     auto compute_wave = [&](auto f0_tag, auto nfw_tag) __attribute__((always_inline)) {
@@ -755,6 +810,24 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
             }
 #pragma unroll
             for (int f = F0; f < F0 + NFW; f++) *reinterpret_cast<float4 *>(&outb[(f * 64 + lane) * EX_STR + 4 * mq]) = res[f];
+            if (mails) { // lane 63: four more rows of the east strip's west column, as self-validating {value, tag} words
+                typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int f = F0; f < F0 + NFW; f++) {
+                    const float rv[4] = {res[f].x, res[f].y, res[f].z, res[f].w};
+                    const int ig = i0 + EX_CH * k + 4 * mq; // first row of the group
+                    const unsigned off = (unsigned)((f * nrows + ig) * 8); // >= 0 where a row is stored
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        if (INTERIOR || (ig + x >= 1 && ig + x <= nrows - 2)) {
+                            v2u_t wv;
+                            wv.x = __float_as_uint(rv[x]);
+                            wv.y = 1u;
+                            __builtin_amdgcn_raw_buffer_store_b64(wv, rs_mail, off + 8 * x, 0, 16); // sc1: written through
+                        }
+                    }
+                }
+            }
         }
         };
         {
