@@ -41,9 +41,13 @@ template <class Mdl, int S> struct RbpLayout {
     // g + 3s + 1 and keeps it in registers for the step after; its slot is refilled by group g + NK, issued in step
     // g + NK - p, which has to come after wave S-1's read.
     static constexpr int nk_for(int p) { return p + 3 * (S - 1) + 2; }
+    // The read-only fields (late-linearisation models) live in a ring of their own: they ride one column ahead of the
+    // coefficients (the red half reads them at x+1) into register windows, so wave s reads group g once, in step g + 3s;
+    // the last reader is wave S-1 in step g + 3(S-1): one column fewer than the coefficient ring needs.
+    static constexpr int nq_for(int p) { return NRO > 0 ? p + 3 * (S - 1) + 1 : 0; }
     static constexpr size_t lds_for(int p)
     {
-        return (size_t)(nk_for(p) * NRING * COL + (p + 1) * NIT * COL + (S - 1) * 2 * NIT * COL) * sizeof(float);
+        return (size_t)(nk_for(p) * NCF * COL + nq_for(p) * NRO * COL + (p + 1) * NIT * COL + (S - 1) * 2 * NIT * COL) * sizeof(float);
     }
     // DMA lead in steps: what is in flight per CU (lead x GROUP KiB) has to cover an HBM round trip at the rate the
     // kernel consumes it, so take the longest lead the 160 KiB of LDS and the 6-bit vmcnt counter allow (at most 8)
@@ -60,15 +64,17 @@ template <class Mdl, int S> struct RbpLayout {
     static constexpr int P = pick_lead();
 #endif
     static constexpr int NK = nk_for(P);
+    static constexpr int NQ = nq_for(P) > 0 ? nq_for(P) : 1;
     static constexpr int NO = P + 1;                   // O-ring columns
-    static constexpr int K_FLOATS = NK * NRING * COL;
+    static constexpr int K_FLOATS = NK * NCF * COL;
+    static constexpr int Q_FLOATS = nq_for(P) * NRO * COL;
     static constexpr int O_FLOATS = NO * NIT * COL;
     static constexpr int H_FLOATS = (S - 1) * 2 * NIT * COL;
-    static constexpr size_t LDS_BYTES = (size_t)(K_FLOATS + O_FLOATS + H_FLOATS) * sizeof(float);
+    static constexpr size_t LDS_BYTES = (size_t)(K_FLOATS + Q_FLOATS + O_FLOATS + H_FLOATS) * sizeof(float);
     static constexpr int NW = (NIT == 2) ? 2 : 1;      // waves per sweep: the two fields of a coupled model are relaxed by two waves
     static constexpr int THREADS = 64 * (S * NW + 1);  // sweep waves + the loader wave
     static constexpr int HALO = 2 * S;                 // columns per side
-    static constexpr bool FITS = P >= 3 && LDS_BYTES <= 160 * 1024 && (P - 1) * GROUP <= 63;
+    static constexpr bool FITS = P >= 2 && LDS_BYTES <= 160 * 1024 && (P - 1) * GROUP <= 63;
     // wave S-1 finishes column j1-1 in step TJ + 5S - 2 (two warm-up steps, 2S halo columns, three columns of lag per sweep)
     __host__ __device__ static constexpr int nsteps(int tj) { return tj + 5 * S - 1; }
 };
@@ -153,7 +159,7 @@ __device__ __forceinline__ void rbp_phase(float (&OUT)[NF][4], const float (&C)[
 
 // The march of one sweep wave: sweep s of the launch, fields [F0, F0+NF) of the model.
 template <class Mdl, int S, bool FIRST, int F0, int NF>
-__device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float *dout0, float *dout1, float *Kring, float *Oring, float *Hring,
+__device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float *dout0, float *dout1, float *Kring, float *Qring, float *Oring, float *Hring,
                                                int s, int lane, int r, int nrows, int ncols, int j0, int j1, int xbase, int nsteps,
                                                float omega, int col0, size_t fo)
 {
@@ -190,13 +196,13 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
     }
     // ring positions: K ring slot of column x (group x - xbase - 1 = t - 3s - 1; a wave that is still in front of the first
     // fetched column reads some slot whose content it never uses), O ring slot of column x+1 (sweep 0), H ring parity
-    int ki = ((-3 * s - 1) % L::NK + L::NK) % L::NK, oi = 0, hp = 1;
+    int ki = ((-3 * s - 1) % L::NK + L::NK) % L::NK, qi = ((-3 * s) % L::NQ + L::NQ) % L::NQ, oi = 0, hp = 1;
 
     auto step = [&](int t, float (&Om)[NIT][4], float (&Oc)[NIT][4], float (&Op)[NIT][4], float (&Rpp)[NF][4], float (&Rp)[NF][4],
                     float (&Rc)[NF][4], const float (&Kp)[NCF][4], float (&Kc)[NCF][4]) __attribute__((always_inline)) {
         const int x = xbase + t - 3 * s; // this wave's red column; black on x-1
         // ---- take in column x+1 of the previous sweep's result, and the coefficients of columns x and x-1 ----
-        float *const ks = Kring + (size_t)ki * NRING * COL; // column x; column x-1 (Kp) is the Kc of the previous step, kept in registers
+        float *const ks = Kring + (size_t)ki * NCF * COL; // column x; column x-1 (Kp) is the Kc of the previous step, kept in registers
         {
             const float *src = (s == 0) ? Oring + (size_t)oi * NIT * COL : Hring + (size_t)((s - 1) * 2 + hp) * NIT * COL;
 #pragma unroll
@@ -213,7 +219,7 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
                         Q0[f][e] = Qn[f][e];
                     }
                     // read-only fields ride one column ahead of the coefficients (the red half reads them at x+1)
-                    rbp_lds_read(Qn[f], Kring + (size_t)(ki + 1 == L::NK ? 0 : ki + 1) * NRING * COL + (NCF + (NRO > 0 ? f : 0)) * COL, lane);
+                    rbp_lds_read(Qn[f], Qring + ((size_t)qi * NRO + (NRO > 0 ? f : 0)) * COL, lane);
                 }
         }
         const int p = (x + col0) & 1;
@@ -335,6 +341,7 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
             }
         }
         ki = (ki + 1 == L::NK) ? 0 : ki + 1;
+        qi = (qi + 1 == L::NQ) ? 0 : qi + 1;
         oi = (oi + 1 == L::NO) ? 0 : oi + 1;
         hp ^= 1;
         rbp_barrier();
@@ -361,7 +368,8 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
     constexpr int NIT = L::NIT, NRO = L::NRO, NCF = L::NCF, NRING = L::NRING, COL = L::COL, NW = L::NW;
     extern __shared__ __attribute__((aligned(16))) float rbp_lds[];
     float *const Kring = rbp_lds;
-    float *const Oring = Kring + L::K_FLOATS;
+    float *const Qring = Kring + L::K_FLOATS;
+    float *const Oring = Qring + L::Q_FLOATS;
     float *const Hring = Oring + L::O_FLOATS;
 
     const int lane = threadIdx.x & 63;
@@ -385,23 +393,24 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
         // =========================================== loader wave =============================================
         // group g = column xbase + 1 + g, consumed by sweep 0 in step g
         const int rr = r < 0 ? 0 : (r > nrows - 4 ? nrows - 4 : r);
-        int kslot = 0, oslot = 0;
+        int kslot = 0, qslot = 0, oslot = 0;
         auto issue = [&](int g) __attribute__((always_inline)) {
             const int y = xbase + 1 + g;
             const int cc = y < 0 ? 0 : (y > ncols - 1 ? ncols - 1 : y);
             const size_t off = fo + (size_t)cc * nrows + rr;
-            float *kdst = Kring + (size_t)kslot * NRING * COL;
+            float *kdst = Kring + (size_t)kslot * NCF * COL, *qdst = Qring + (size_t)qslot * NRO * COL;
 #pragma unroll
             for (int f = 0; f < NCF; f++)
                 __builtin_amdgcn_global_load_lds(RBP_GLB(P.cf[f] + off), RBP_LDS(kdst + f * COL), 16, 0, RBP_AUX_COEF);
 #pragma unroll
             for (int f = 0; f < NRO; f++)
-                __builtin_amdgcn_global_load_lds(RBP_GLB(P.ro[f] + off), RBP_LDS(kdst + (NCF + f) * COL), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(RBP_GLB(P.ro[f] + off), RBP_LDS(qdst + f * COL), 16, 0, 0);
             float *odst = Oring + (size_t)oslot * NIT * COL;
 #pragma unroll
             for (int f = 0; f < NIT; f++)
                 __builtin_amdgcn_global_load_lds(RBP_GLB(P.it_in[f] + off), RBP_LDS(odst + f * COL), 16, 0, 0);
             kslot = (kslot + 1 == L::NK) ? 0 : kslot + 1;
+            qslot = (qslot + 1 == L::NQ) ? 0 : qslot + 1;
             oslot = (oslot + 1 == L::NO) ? 0 : oslot + 1;
         };
         for (int g = 0; g < L::P; g++) issue(g);
@@ -422,10 +431,10 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
     // waves per SIMD, which is what keeps the VALUs busy while a wave waits for LDS or the barrier.
     if constexpr (NW == 2) {
         const int s = wave >> 1;
-        if ((wave & 1) == 0) rbp_sweep_wave<Mdl, S, FIRST, 0, 1>(P, dout0, dout1, Kring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
-        else rbp_sweep_wave<Mdl, S, FIRST, 1, 1>(P, dout0, dout1, Kring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
+        if ((wave & 1) == 0) rbp_sweep_wave<Mdl, S, FIRST, 0, 1>(P, dout0, dout1, Kring, Qring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
+        else rbp_sweep_wave<Mdl, S, FIRST, 1, 1>(P, dout0, dout1, Kring, Qring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
     } else {
-        rbp_sweep_wave<Mdl, S, FIRST, 0, NIT>(P, dout0, dout1, Kring, Oring, Hring, wave, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
+        rbp_sweep_wave<Mdl, S, FIRST, 0, NIT>(P, dout0, dout1, Kring, Qring, Oring, Hring, wave, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
     }
 }
 
