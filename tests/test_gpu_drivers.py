@@ -140,6 +140,12 @@ def test_graph_replay_gives_the_eager_bits(pdeip):
         want = D.FlowEminNDFASFMG_elin_2D_v10(frames, 1, solver=1, omega=1.0, **{"mode": pdeip.MODE_RED_BLACK})
         got = D.FlowEminNDFASFMG_elin_2D_v10(frames, 1, solver=1, omega=1.0, graph=True, **{"mode": pdeip.MODE_RED_BLACK})
         assert pb.bit_equal(got[0], want[0]) and pb.bit_equal(got[1], want[1])
+    # a larger frame regrows the library's scratch buffers (pdeip_workspace_generation changes): the cached graph is re-captured
+    big = np.kron(I, np.ones((2, 2, 1), dtype=np.float32))
+    D.FlowEminND_llin_2D_v10(big, 1, "grad", "gradmag", **kw)
+    want = D.FlowEminND_llin_2D_v10(I, 1, "grad", "gradmag", **kw)
+    got = D.FlowEminND_llin_2D_v10(I, 1, "grad", "gradmag", graph=True, **kw)
+    assert pb.bit_equal(got[0], want[0]) and pb.bit_equal(got[1], want[1])
     # exact order: graph=True is accepted and runs eagerly
     a = D.FlowEminND_llin_2D_v10(I, 1, "rgb", "none", solver=1, graph=True)
     b = D.FlowEminND_llin_2D_v10(I, 1, "rgb", "none", solver=1)

@@ -491,3 +491,53 @@ def test_weights_inverse_sqrt_shortcut_is_the_exact_sequence(pdeip):
     lib = pdeip.capi.load()
     for seed in (1, 2):
         assert lib.pdeip_selftest_inv_sqrt(1 << 25, seed) == 0
+
+
+def test_fused_stage_launches_equal_their_parts(pdeip):
+    """pdeip_flow_assemble_weights_dev == flow_assemble + flow_opdiffweights, pdeip_fas_assemble_weights_dev == fas_assemble +
+    OPdiffWeights(U, V), pdeip_flow_warp_dev == flow_coords + two warps, pdeip_median3_pair_dev == two medians: bit for bit,
+    NaN-laced data, odd sizes, both kinds of second term."""
+    import torch
+
+    dev = importlib.import_module("pde-based-image-processing_amd.device")
+    rng = np.random.default_rng(77)
+    for nrows, ncols, C in ((37, 53, 3), (64, 40, 1), (5, 7, 2)):
+        def P(c=None, lo=-1.0, hi=1.0, nan=0.0):
+            a = rng.uniform(lo, hi, (nrows, ncols) if c is None else (nrows, ncols, c)).astype(np.float32)
+            if nan:
+                a[rng.random(a.shape) < nan] = np.nan
+            return dev.to_device(a)
+        U, V, dU, dV = P(), P(), P(lo=-0.2, hi=0.2), P(lo=-0.2, hi=0.2)
+        new = lambda n: [torch.empty_like(U) for _ in range(n)]
+        t1 = (P(C, nan=0.02), P(C), P(C), 0.7)
+        for t2 in (None, (P(C), P(C, nan=0.02), P(C), 0.3), (P(C), P(C), P(C), P(C), P(C, nan=0.02), 0.3)):
+            a, b = new(9), new(9)
+            dev.flow_assemble(t1, t2, dU, dV, 0.05, *a[:5])
+            dev.flow_opdiffweights(U, V, dU, dV, *a[5:])
+            dev.flow_assemble_weights(t1, t2, U, V, dU, dV, 0.05, *b[:5], *b[5:])
+            for x, y in zip(a, b):
+                assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+        planes = torch.stack([P(C) for _ in range(13)])                      # fas_prepare layout [13][C][ncols][nrows]
+        Cu, Cv = P(C), P(C)
+        a, b = new(9), new(9)
+        dev.fas_assemble(planes, Cu, Cv, U, V, 0.03, 0.97, 0.1, False, *a[:5])
+        dev.flow_opdiffweights(U, V, None, None, *a[5:])
+        dev.fas_assemble_weights(planes, Cu, Cv, U, V, 0.03, 0.97, 0.1, *b[:5], *b[5:])
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+        I1, I2 = P(C, lo=0, hi=255), P(2, lo=0, hi=255)
+        Uw, Vw = P(lo=-3, hi=3), P(lo=-3, hi=3)
+        X, Y = torch.empty_like(U), torch.empty_like(U)
+        w1a, w2a, w1b, w2b = torch.empty_like(I1), torch.empty_like(I2), torch.empty_like(I1), torch.empty_like(I2)
+        dev.flow_coords(Uw, Vw, X, Y)
+        dev.warp_bilinear(I1, X, Y, w1a)
+        dev.warp_bilinear(I2, X, Y, w2a)
+        dev.flow_warp(Uw, Vw, I1, w1b, I2, w2b)
+        assert torch.equal(w1a.view(torch.int32), w1b.view(torch.int32)) and torch.equal(w2a.view(torch.int32), w2b.view(torch.int32))
+        w1c = torch.empty_like(I1)
+        dev.flow_warp(Uw, Vw, I1, w1c)
+        assert torch.equal(w1a.view(torch.int32), w1c.view(torch.int32))
+        m = new(4)
+        dev.median3(U, dU, m[0]); dev.median3(V, dV, m[1])
+        dev.median3_pair(U, dU, m[2], V, dV, m[3])
+        assert torch.equal(m[0].view(torch.int32), m[2].view(torch.int32)) and torch.equal(m[1].view(torch.int32), m[3].view(torch.int32))
