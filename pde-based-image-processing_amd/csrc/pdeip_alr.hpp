@@ -715,6 +715,246 @@ __global__ void __launch_bounds__(64) k_alr_zebra(typename Mdl::Ctx q, float *x,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Zebra order on a small frame: the whole call in ONE launch, one workgroup per frame.
+//
+// On the coarse scales of the drivers' pyramids a zebra call is ~45 launches (coefficient transposes, factor passes, per
+// iteration four colour passes per field and two iterate transposes) of ~10 us each for a few microseconds of work: 0.4-0.5 ms
+// per call whatever the frame size below ~135 x 240, and these scales take most of the calls (240 of 324 in the 4K multigrid
+// run).  Here one workgroup of 1024 threads runs the same sequence with a workgroup barrier where the launches were:
+//   * the coefficient planes are transposed into their twins once, the iterate planes around every row pass (as run_alr does);
+//   * the coefficient-only half of the Thomas recurrences (cp and the divisors) is run once per call into factor planes,
+//     as k_alr_zebra3<ZB_FACTOR> does;
+//   * a colour pass has three stages: every thread builds tridiagonal rows of the colour's lines -- the same Model::coef as
+//     everywhere -- into LDS next to the line's factors and old x, in parallel over lines AND elements; one lane per line
+//     runs the two short recurrences out of LDS (three dependent instructions per element going down, two coming back);
+//     every thread copies the blended lines back to the plane.
+// Bit-identical to k_alr_zebra3 / k_alr_zebra.  Frames whose largest colour pass fits 150 KB of LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int ALR_SMALL_THREADS = 1024;
+constexpr int ALR_SMALL_MAXTR = 24;
+template <class Mdl> struct AlrSmallArgs {
+    typename Mdl::Ctx q[2], qt[2];
+    float *x[2], *xt[2];
+    float *cp[2][2], *dv[2][2]; // per-call factor planes [field][column pass 0 / row pass 1]: k_alr_zebra3<ZB_FACTOR>'s contents
+    const float *tin[ALR_SMALL_MAXTR];
+    float *tout[ALR_SMALL_MAXTR];
+    int ntr, nch, nrows, ncols, iter;
+    float omega;
+    size_t fs;
+};
+
+// floats the row part of the LDS image takes (the old / new x part follows it)
+__host__ __device__ inline size_t alr_small_lds_bytes_dev(int nrows, int ncols, bool interior_lines)
+{
+    const int lo = interior_lines ? 1 : 0;
+    const size_t col_lines = (size_t)(ncols - 2 * lo + 1) / 2, row_lines = (size_t)(nrows - 2 * lo + 1) / 2;
+    const size_t a = col_lines * (size_t)(nrows | 1), b = row_lines * (size_t)(ncols | 1);
+    return (a > b ? a : b) * 4;
+}
+// LDS per colour pass: a row (a, divisor, cp, d) and the old / new x of every element of the colour's lines; lines padded to an
+// odd number of rows so that the lanes of the recurrence stage (one per line) hit different banks
+__host__ __device__ inline int alr_small_stride(int n) { return n | 1; }
+inline size_t alr_small_lds_bytes(int nrows, int ncols, bool interior_lines)
+{
+    const int lo = interior_lines ? 1 : 0;
+    const size_t col_lines = (size_t)(ncols - 2 * lo + 1) / 2, row_lines = (size_t)(nrows - 2 * lo + 1) / 2;
+    const size_t a = col_lines * alr_small_stride(nrows), b = row_lines * alr_small_stride(ncols);
+    return (a > b ? a : b) * (sizeof(float4) + sizeof(float));
+}
+
+// FACTOR = true: once per call and direction, the coefficient-only recurrence of every line of one colour:
+//   cp[0] = c/b, divisor[0] = b;  middle: den = b - cp' a, cp = c * (1/den), divisor = 1/den  (a dividing south row: cp = c/den,
+//   divisor = den);  last: divisor = b - cp' a.                                     -> the cp / dv planes
+// FACTOR = false: one relaxation of the lines of one colour with those planes:
+//   dp[0] = d / divisor[0];  middle: dp = (d - dp' a) * divisor (dividing south row: / divisor);  last: dp = (d - dp' a) / divisor;
+//   back-substitution x[k] = dp[k] - cp[k] x[k+1] with the lagged SOR blend (opticalflowSolvers.c:1890-1958).
+// The same statements as k_alr_zebra with 1/den hoisted out of the iteration, as k_alr_zebra3 does.
+template <class Mdl, bool VERT, bool FACTOR>
+__device__ __forceinline__ void alr_small_pass(const typename Mdl::Ctx &q, float *x, float *cpP, float *dvP, float4 *T, float *X, int nrows,
+                                               int ncols, int colour, float omega)
+{
+    const int tid = threadIdx.x;
+    const int lo = Mdl::INTERIOR_LINES ? 1 : 0, hi = (VERT ? ncols : nrows) - 1 - lo;
+    const int first = lo + (((lo & 1) != colour) ? 1 : 0);
+    if (first > hi) return; // uniform
+    const int count = (hi - first) / 2 + 1, n = VERT ? nrows : ncols, S = alr_small_stride(n);
+    for (int e = tid; e < count * n; e += ALR_SMALL_THREADS) { // stage 1, all threads: the rows of every line of this colour
+        const int li = e / n, k = e - li * n;
+        const int l = first + 2 * li;
+        const Tri c = line_coef<Mdl, VERT>(q, l, k, nrows, ncols);
+        const size_t pos = (size_t)l * n + k;
+        if (FACTOR) {
+            T[li * S + k] = make_float4(c.a, c.b, c.c, 0.0f);
+        } else {
+            T[li * S + k] = make_float4(c.a, dvP[pos], cpP[pos], c.d);
+            X[li * S + k] = x[pos];
+        }
+    }
+    __syncthreads();
+    if (tid < count) { // stage 2, one lane per line: the recurrences, out of LDS
+        const int l = first + 2 * tid;
+        float4 *L = T + (size_t)tid * S;
+        const bool tdiv = Mdl::SOUTH_TRUEDIV && !VERT && l == nrows - 1;
+        if (FACTOR) {
+            const size_t base = (size_t)l * n;
+            float4 c = L[0];
+            float cpv = c.z / c.y;
+            cpP[base] = cpv;
+            dvP[base] = c.y;
+            for (int k = 1; k <= n - 2; k++) {
+                c = L[k];
+                const float den = c.y - cpv * c.x;
+                float dvv;
+                if (tdiv) {
+                    cpv = c.z / den;
+                    dvv = den;
+                } else {
+                    dvv = 1.0f / den;
+                    cpv = c.z * dvv;
+                }
+                cpP[base + k] = cpv;
+                dvP[base + k] = dvv;
+            }
+            c = L[n - 1];
+            cpP[base + n - 1] = 0.0f;
+            dvP[base + n - 1] = c.y - cpv * c.x;
+        } else {
+            float *Xl = X + (size_t)tid * S;
+            const float om1 = 1.0f - omega;
+            constexpr int CH = 8; // rows per trip: the LDS loads of a trip are issued together, ahead of the dependent chain
+            float4 c = L[0];
+            float dpv = c.w / c.y;
+            L[0].w = dpv;
+            int k = 1;
+            for (; k + CH - 1 <= n - 2; k += CH) {
+                float4 r[CH];
+                float dpo[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) r[u] = L[k + u];
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    dpv = tdiv ? (r[u].w - dpv * r[u].x) / r[u].y : (r[u].w - dpv * r[u].x) * r[u].y;
+                    dpo[u] = dpv;
+                }
+#pragma unroll
+                for (int u = 0; u < CH; u++) L[k + u].w = dpo[u];
+            }
+            for (; k <= n - 2; k++) {
+                c = L[k];
+                dpv = tdiv ? (c.w - dpv * c.x) / c.y : (c.w - dpv * c.x) * c.y;
+                L[k].w = dpv;
+            }
+            c = L[n - 1];
+            dpv = (c.w - dpv * c.x) / c.y;
+            // back-substitution; element k+1 gets its blend once it has been used
+            float xs = dpv, old = Xl[n - 1];
+            k = n - 2;
+            for (; k - (CH - 1) >= 0; k -= CH) {
+                float dpk[CH], cpk[CH], xo[CH], xn[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    const float4 t = L[k - u];
+                    dpk[u] = t.w;
+                    cpk[u] = t.z;
+                    xo[u] = Xl[k - u];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    const float xk = dpk[u] - cpk[u] * xs;
+                    xn[u] = omega * xs + om1 * old; // the blended x of element k - u + 1
+                    old = xo[u];
+                    xs = xk;
+                }
+#pragma unroll
+                for (int u = 0; u < CH; u++) Xl[k - u + 1] = xn[u];
+            }
+            for (; k >= 0; k--) {
+                const float xk = L[k].w - L[k].z * xs;
+                const float xo = Xl[k];
+                Xl[k + 1] = omega * xs + om1 * old;
+                old = xo;
+                xs = xk;
+            }
+            Xl[0] = omega * xs + om1 * old;
+        }
+    }
+    __syncthreads();
+    if (!FACTOR) {
+        for (int e = tid; e < count * n; e += ALR_SMALL_THREADS) { // stage 3, all threads: the relaxed lines back to the plane
+            const int li = e / n, k = e - li * n;
+            x[(size_t)(first + 2 * li) * n + k] = X[li * S + k];
+        }
+        __syncthreads();
+    }
+}
+
+template <class Mdl>
+__global__ void __launch_bounds__(ALR_SMALL_THREADS) k_alr_small(AlrSmallArgs<Mdl> A)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 alr_small_lds[];
+    const int tid = threadIdx.x, nrows = A.nrows, ncols = A.ncols, n = nrows * ncols;
+    const size_t fo = (size_t)blockIdx.x * A.fs;
+    float4 *const T = alr_small_lds;
+    float *const X = reinterpret_cast<float *>(alr_small_lds) + alr_small_lds_bytes_dev(nrows, ncols, Mdl::INTERIOR_LINES);
+    // two fields at most; named copies rather than arrays indexed at run time (those would live in scratch memory)
+    typename Mdl::Ctx q0 = A.q[0], q1 = A.q[1], qt0 = A.qt[0], qt1 = A.qt[1];
+    q0.shift(fo);
+    q1.shift(fo);
+    qt0.shift(fo);
+    qt1.shift(fo);
+    const bool two = A.nch > 1;
+    float *const x0 = A.x[0] + fo, *const xt0 = A.xt[0] + fo;
+    float *const x1 = two ? A.x[1] + fo : nullptr, *const xt1 = two ? A.xt[1] + fo : nullptr;
+    float *const cp00 = A.cp[0][0] + fo, *const dv00 = A.dv[0][0] + fo, *const cp01 = A.cp[0][1] + fo, *const dv01 = A.dv[0][1] + fo;
+    float *const cp10 = two ? A.cp[1][0] + fo : nullptr, *const dv10 = two ? A.dv[1][0] + fo : nullptr;
+    float *const cp11 = two ? A.cp[1][1] + fo : nullptr, *const dv11 = two ? A.dv[1][1] + fo : nullptr;
+    // out(i, j) at i * ncols + j  <-  in(i, j) at j * nrows + i
+    auto to_rows = [&](float *out, const float *in) {
+        for (int idx = tid; idx < n; idx += ALR_SMALL_THREADS) {
+            const int j = idx / nrows, i = idx - j * nrows;
+            out[(size_t)i * ncols + j] = in[idx];
+        }
+    };
+    auto to_cols = [&](float *out, const float *in) {
+        for (int idx = tid; idx < n; idx += ALR_SMALL_THREADS) {
+            const int j = idx / nrows, i = idx - j * nrows;
+            out[idx] = in[(size_t)i * ncols + j];
+        }
+    };
+    for (int k = 0; k < A.ntr; k++) to_rows(A.tout[k] + fo, A.tin[k] + fo);
+    __syncthreads();
+    for (int colour = 0; colour < 2; colour++) { // the factor planes: coefficients only, once per call
+        alr_small_pass<Mdl, true, true>(q0, nullptr, cp00, dv00, T, X, nrows, ncols, colour, A.omega);
+        alr_small_pass<Mdl, false, true>(qt0, nullptr, cp01, dv01, T, X, nrows, ncols, colour, A.omega);
+        if (two) {
+            alr_small_pass<Mdl, true, true>(q1, nullptr, cp10, dv10, T, X, nrows, ncols, colour, A.omega);
+            alr_small_pass<Mdl, false, true>(qt1, nullptr, cp11, dv11, T, X, nrows, ncols, colour, A.omega);
+        }
+    }
+    for (int it = 0; it < A.iter; it++) {
+        // columns of field 0 then field 1, rows of field 1 then field 0 (opticalflowSolvers.c:231-258)
+        alr_small_pass<Mdl, true, false>(q0, x0, cp00, dv00, T, X, nrows, ncols, 0, A.omega);
+        alr_small_pass<Mdl, true, false>(q0, x0, cp00, dv00, T, X, nrows, ncols, 1, A.omega);
+        if (two) {
+            alr_small_pass<Mdl, true, false>(q1, x1, cp10, dv10, T, X, nrows, ncols, 0, A.omega);
+            alr_small_pass<Mdl, true, false>(q1, x1, cp10, dv10, T, X, nrows, ncols, 1, A.omega);
+        }
+        to_rows(xt0, x0);
+        if (two) to_rows(xt1, x1);
+        __syncthreads();
+        if (two) {
+            alr_small_pass<Mdl, false, false>(qt1, xt1, cp11, dv11, T, X, nrows, ncols, 0, A.omega);
+            alr_small_pass<Mdl, false, false>(qt1, xt1, cp11, dv11, T, X, nrows, ncols, 1, A.omega);
+        }
+        alr_small_pass<Mdl, false, false>(qt0, xt0, cp01, dv01, T, X, nrows, ncols, 0, A.omega);
+        alr_small_pass<Mdl, false, false>(qt0, xt0, cp01, dv01, T, X, nrows, ncols, 1, A.omega);
+        to_cols(x0, xt0);
+        if (two) to_cols(x1, xt1);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Zebra order, 4-neighbour models: one workgroup = 16 lines of the active colour, one SOLVER wave
 // (lane = line, runs the recurrences) fed by seven MOVER waves.
 //

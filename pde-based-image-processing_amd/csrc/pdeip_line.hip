@@ -191,7 +191,7 @@ static int alr_transpose_many(hipStream_t s, float *const *out, const float *con
 
 template <class Ctx>
 static int alr_make_twins(hipStream_t s, const Ctx *q, Ctx *qt, int nch, float *const *x, float **xt, int nrows, int ncols, int nframes,
-                          AlrTwin *tw)
+                          AlrTwin *tw, const float **defer_in = nullptr, float **defer_out = nullptr, int *defer_n = nullptr)
 {
     static_assert(sizeof(Ctx) % sizeof(float *) == 0, "a line-relaxation context is a struct of plane pointers");
     constexpr int NP = (int)(sizeof(Ctx) / sizeof(float *));
@@ -219,7 +219,15 @@ static int alr_make_twins(hipStream_t s, const Ctx *q, Ctx *qt, int nch, float *
             ins[nco++] = tw->orig[k];
         }
     }
-    RC(alr_transpose_many(s, outs, ins, nco, nrows, ncols, nframes));
+    if (defer_n) { // the caller's kernel transposes the coefficient planes itself (k_alr_small)
+        for (int k = 0; k < nco; k++) {
+            defer_in[k] = ins[k];
+            defer_out[k] = outs[k];
+        }
+        *defer_n = nco;
+    } else {
+        RC(alr_transpose_many(s, outs, ins, nco, nrows, ncols, nframes));
+    }
     for (int c = 0; c < nch; c++) {
         const float *tp[NP];
         for (int k = 0; k < NP; k++) tp[k] = ptrs[c][k] ? tw->find(ptrs[c][k]) : nullptr;
@@ -245,6 +253,49 @@ static int run_alr(const char *who, hipStream_t s, const typename Mdl::Ctx *q, f
     typename Mdl::Ctx qt[2];
     float *xt[2] = {nullptr, nullptr};
     AlrTwin tw;
+    // zebra order on a small frame: the whole call in one launch (k_alr_small); PDEIP_ALR_SMALL=0 disables
+    if (mode == PDEIP_MODE_RED_BLACK && env_int("PDEIP_ALR_SMALL", 1) != 0) {
+        const size_t lds = alr_small_lds_bytes(nrows, ncols, Mdl::INTERIOR_LINES);
+        // one CU evaluates every row of the call: worth it where a pass is a few microseconds of work, i.e. up to ~60 x 100
+        // (tools/time_alr_small.py: 34x60 348 -> 161 us, 17x30 294 -> 94 us, 61x108 407 -> 367 us, 68x120 392 -> 434 us)
+        if (lds <= (size_t)150 * 1024 && nrows >= 3 && ncols >= 3 && (long)nrows * ncols <= 6144) {
+            AlrSmallArgs<Mdl> A{};
+            const float *tin[AlrTwin::MAXP];
+            float *tout[AlrTwin::MAXP];
+            int ntr = 0;
+            RC(alr_make_twins(s, q, qt, nch, x, xt, nrows, ncols, nframes, &tw, tin, tout, &ntr));
+            if (ntr <= ALR_SMALL_MAXTR) {
+                for (int c = 0; c < nch; c++) {
+                    A.q[c] = q[c];
+                    A.qt[c] = qt[c];
+                    A.x[c] = x[c];
+                    A.xt[c] = xt[c];
+                }
+                for (int k = 0; k < ntr; k++) {
+                    A.tin[k] = tin[k];
+                    A.tout[k] = tout[k];
+                }
+                float *fbase;
+                const size_t fplane = (size_t)nrows * ncols * nframes;
+                RC(ws_get(WS_ALR, fplane * 8 * sizeof(float), &fbase));
+                for (int c = 0; c < nch; c++)
+                    for (int d = 0; d < 2; d++) {
+                        A.cp[c][d] = fbase + fplane * (size_t)((c * 2 + d) * 2);
+                        A.dv[c][d] = A.cp[c][d] + fplane;
+                    }
+                A.ntr = ntr; A.nch = nch; A.nrows = nrows; A.ncols = ncols; A.iter = iter; A.omega = omega;
+                A.fs = (size_t)nrows * ncols;
+                RC(ensure_lds(reinterpret_cast<const void *>(&k_alr_small<Mdl>), lds));
+                SweepTimer timer(s);
+                hipLaunchKernelGGL(k_alr_small<Mdl>, dim3((unsigned)nframes), dim3(ALR_SMALL_THREADS), lds, s, A);
+                timer.stop(iter);
+                g.last_launches++;
+                HIPCHK(hipGetLastError());
+                return PDEIP_OK;
+            }
+            tw = AlrTwin{}; // too many planes for the argument block: the launch-per-pass path
+        }
+    }
     RC(alr_make_twins(s, q, qt, nch, x, xt, nrows, ncols, nframes, &tw));
     AlrFactors f{};
     static const bool zebra1 = env_int("PDEIP_ALR_ZEBRA1", 0) != 0; // the one-lane-per-line kernel for every model (A/B timing)

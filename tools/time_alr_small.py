@@ -1,0 +1,20 @@
+"""Zebra line relaxation per call (iter = 4, elin4 / llin4 / disp4) on the pyramids' coarse scales: us per call."""
+import importlib, sys, time
+import torch
+sys.path.insert(0, ".")
+dev = importlib.import_module("pde-based-image-processing_amd.device")
+for nr, nc in [(135, 240), (82, 145), (68, 120), (34, 60), (17, 30), (61, 108)]:
+    g = torch.Generator(device="cuda").manual_seed(1)
+    P = lambda lo, hi: torch.empty((nc, nr), device="cuda").uniform_(lo, hi, generator=g)
+    U, V, dU, dV = P(-1, 1), P(-1, 1), P(-0.1, 0.1), P(-0.1, 0.1)
+    coef = [P(-0.5, 0.5) for _ in range(3)] + [P(0.1, 1), P(0.1, 1)] + [P(0.5, 5) for _ in range(4)]
+    calls = {"elin4": lambda: dev.oflow_alr_elin4(U, V, *coef, 4, 1.5, 1), "llin4": lambda: dev.oflow_alr_llin4(U, V, dU, dV, *coef, 4, 1.5, 1)}
+    row = []
+    for name, fn in calls.items():
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20): fn()
+        torch.cuda.synchronize()
+        row.append("%s %7.1f" % (name, (time.perf_counter() - t0) / 20 * 1e6))
+    print("%9s  %s" % ("%dx%d" % (nr, nc), "  ".join(row)), flush=True)
