@@ -153,7 +153,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             HIPCHK(hipMemsetAsync(reinterpret_cast<unsigned *>(ctl_f) + 1, 0, (3 + nprog) * sizeof(unsigned), s));
             // west-edge mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, field, row), tags clear at the start of a call
             float *mail_f = nullptr;
-            const size_t mail_bytes = nprog * NIT * (size_t)nrows * sizeof(unsigned long long);
+            const size_t mail_bytes = nprog * NIT * (size_t)NC * EX_CH * sizeof(unsigned long long);
             RC(ws_get(WS_MAIL, mail_bytes, &mail_f));
             HIPCHK(hipMemsetAsync(mail_f, 0, mail_bytes, s));
             PersistCtl ctl;

@@ -660,7 +660,9 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
         // stores of the previous chunk, so once the first one has returned those stores have drained: publish `pub` then.
         const int mf = lane >> 4, r16 = lane & 15;
         const bool polls = (b > 0) && (lane < 16 * NIT);
-        const unsigned long long *mail_w = ctl.mail + ((((size_t)frame * T + t) * B + (b > 0 ? b - 1 : 0)) * NIT + (polls ? mf : 0)) * (size_t)nrows;
+        // word of row r of field f of a strip: [(f * NC) * 16 + r - 1]: the 16 words of a chunk are one aligned 128-byte line
+        const size_t mpitch = (size_t)NC * EX_CH;
+        const unsigned long long *mail_w = ctl.mail + ((((size_t)frame * T + t) * B + (b > 0 ? b - 1 : 0)) * NIT + (polls ? mf : 0)) * mpitch;
         auto take = [&](int c, int pub) __attribute__((always_inline)) {
             if (b > 0 && c < NC) { // the first strip's west column is the frame border: the loader stages it
                 const int row = 1 + EX_CH * c + r16;
@@ -670,7 +672,7 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
                 for (;;) {
                     if (!ok) {
-                        const unsigned long long w = __hip_atomic_load(mail_w + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long w = __hip_atomic_load(mail_w + row - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((unsigned)(w >> 32) != 0u) {
                             v = __uint_as_float((unsigned)w);
                             ok = true;
@@ -705,15 +707,16 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
     }
 
     // mailbox rows of this strip (written by its compute waves) and of its west neighbour (read by role 4): [NIT][nrows] words
-    unsigned long long *const mail_mine = ctl.mail + ((((size_t)frame * T + t) * B + b) * NIT) * (size_t)nrows;
+    unsigned long long *const mail_mine = ctl.mail + ((((size_t)frame * T + t) * B + b) * NIT) * ((size_t)NC * EX_CH);
     // ================================== compute wave ===========================================
     const int j = jbase + lane;
     const bool col_ok = j <= ncols - 2;
     const int jc = j < ncols - 1 ? j : ncols - 1;
     const float om1 = 1.0f - omega;
     const bool first_sweep = (t == 0);
-    const bool mails = (lane == 63) && (b + 1 < B); // my column is the next strip's west column
-    const __amdgpu_buffer_rsrc_t rs_mail = __builtin_amdgcn_make_buffer_rsrc(mail_mine, 0, (unsigned)((size_t)NIT * nrows * 8), 0x00020000);
+    const bool has_east = (b + 1 < B); // my last column is the next strip's west column
+    const int i0w63 = 1 - 63;          // lane 63's row at step 0 of chunk 0
+    const __amdgpu_buffer_rsrc_t rs_mail = __builtin_amdgcn_make_buffer_rsrc(mail_mine, 0, (unsigned)((size_t)NIT * NC * EX_CH * 8), 0x00020000);
     const int i0 = 1 - lane; // row of this lane at step 0 of chunk 0
 
     auto compute_wave = [&](auto f0_tag, auto nfw_tag) __attribute__((always_inline)) {
@@ -810,24 +813,6 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
             }
 #pragma unroll
             for (int f = F0; f < F0 + NFW; f++) *reinterpret_cast<float4 *>(&outb[(f * 64 + lane) * EX_STR + 4 * mq]) = res[f];
-            if (mails) { // lane 63: four more rows of the east strip's west column, as self-validating {value, tag} words
-                typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int f = F0; f < F0 + NFW; f++) {
-                    const float rv[4] = {res[f].x, res[f].y, res[f].z, res[f].w};
-                    const int ig = i0 + EX_CH * k + 4 * mq; // first row of the group
-                    const unsigned off = (unsigned)((f * nrows + ig) * 8); // >= 0 where a row is stored
-#pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        if (INTERIOR || (ig + x >= 1 && ig + x <= nrows - 2)) {
-                            v2u_t wv;
-                            wv.x = __float_as_uint(rv[x]);
-                            wv.y = 1u;
-                            __builtin_amdgcn_raw_buffer_store_b64(wv, rs_mail, off + 8 * x, 0, 16); // sc1: written through
-                        }
-                    }
-                }
-            }
         }
         };
         {
@@ -835,6 +820,24 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
             const bool interior = (lo_row >= 2) && (hi_row <= nrows - 3) && (jbase >= 2) && (jbase + 63 <= ncols - 3);
             if (interior) relax_chunk(std::true_type{});
             else relax_chunk(std::false_type{});
+        }
+        if (has_east) {
+            // Mailbox: lane 63's 16 results of this chunk (rows i0 + 16k .. + 15 of my last column) go out as ONE 128-byte line of
+            // self-validating {value, tag} words per field -- lanes 0..15 pick them up from the out buffer this wave just wrote
+            // (LDS operations of one wave complete in order) and store 8 bytes each.  A full-line store needs no read of the
+            // line it replaces; the piecemeal form (lane 63 storing four words at a time) stalled on exactly that once the
+            // planes had pushed the mailbox out of the Infinity Cache.
+            typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+            const int r = (i0w63 + EX_CH * k) + (lane & 15); // row of word (lane & 15)
+            if (lane < 16 && r >= 1 && r <= nrows - 2) {
+#pragma unroll
+                for (int f = F0; f < F0 + NFW; f++) {
+                    v2u_t wv;
+                    wv.x = __float_as_uint(outb[(f * 64 + 63) * EX_STR + lane]);
+                    wv.y = 1u;
+                    __builtin_amdgcn_raw_buffer_store_b64(wv, rs_mail, (unsigned)(((size_t)f * NC * EX_CH + r - 1) * 8), 0, 16); // sc1
+                }
+            }
         }
         lds_barrier();
     }    };
