@@ -54,20 +54,66 @@ __global__ void k_fas_down(float *out, const float *in, int nrows_in, int ncols_
 // [13][C][ncols][nrows] in the order Idt, Idx, Idy, Idxx, Idyy, Idxy, Idxt, Idyt, M, Cu, Cv, Du, Dv.
 enum { FAS_IDT, FAS_IDX, FAS_IDY, FAS_IDXX, FAS_IDYY, FAS_IDXY, FAS_IDXT, FAS_IDYT, FAS_M, FAS_CU, FAS_CV, FAS_DU, FAS_DV, FAS_NPLANES };
 
-__global__ void k_fas_prepare(float *planes, const float *It0, const float *It1, int C, float b1, float b2, int nrows, int ncols)
+// Tiled like k_derivatives5_tiled: a 64 x 4 tile stages its 68 x 8 neighbourhood of both frames (clamped coordinates =
+// 'replicate') and of S = ((It0 + It1) * 0.55) / 255 in LDS, evaluates each of the seven first-pass results once, then the nine
+// second passes -- instead of nine 25-tap evaluations per pixel.  Products and left-to-right sums as hs_v5 / hs_h5 have them.
+constexpr int FP_TR = 64, FP_TC = 4, FP_IR = FP_TR + 4, FP_IC = FP_TC + 4;
+
+__global__ void __launch_bounds__(FP_TR *FP_TC)
+k_fas_prepare(float *planes, const float *It0, const float *It1, int C, float b1, float b2, int nrows, int ncols)
 {
-    PDEIP_PIXEL_INDEX();
+    __shared__ float inS[FP_IC][FP_IR], in0[FP_IC][FP_IR], in1[FP_IC][FP_IR];
+    __shared__ float VS[FP_IC][FP_TR], V0[FP_IC][FP_TR], V1[FP_IC][FP_TR];                       // V5(pre) at own rows, columns j-2..j+2
+    __shared__ float HS[FP_TC][FP_IR], HD[FP_TC][FP_IR], H0[FP_TC][FP_IR], H1[FP_TC][FP_IR];    // H5(pre) S, H5(d1f) S, H5(pre) It0 / It1
+    const int tr = threadIdx.x, tc = threadIdx.y, tid = tc * FP_TR + tr;
+    const int i0 = blockIdx.x * FP_TR, j0 = blockIdx.y * FP_TC;
     const size_t n = (size_t)nrows * ncols, c = blockIdx.z, blk = n * C;
-    const HsImage S{It0 + c * n, It1 + c * n, 3, nrows, ncols}, A0{It0 + c * n, It1 + c * n, 1, nrows, ncols},
-        A1{It0 + c * n, It1 + c * n, 2, nrows, ncols};
-    const float Idt = (It0[c * n + pos] - It1[c * n + pos]) / 255.0f;
-    const float Idx = hs_vh(S, HS_PRE, HS_D1F, i, j);
-    const float Idy = hs_hv(S, HS_PRE, HS_D1F, i, j);
-    const float Idxx = hs_vh(S, HS_PRE, HS_D2, i, j);
-    const float Idyy = hs_hv(S, HS_PRE, HS_D2, i, j);
-    const float Idxy = hs_hv(S, HS_D1F, HS_D1F, i, j);
-    const float Idxt = hs_vh(A0, HS_PRE, FAS_D1F_SCL, i, j) - hs_vh(A1, HS_PRE, FAS_D1F_SCL, i, j);
-    const float Idyt = hs_hv(A0, HS_PRE, FAS_D1F_SCL, i, j) - hs_hv(A1, HS_PRE, FAS_D1F_SCL, i, j);
+    const float *a = It0 + c * n, *b = It1 + c * n;
+    for (int e = tid; e < FP_IC * FP_IR; e += FP_TR * FP_TC) {
+        const int cc = e / FP_IR, r = e - cc * FP_IR;
+        const int ii = min(max(i0 - 2 + r, 0), nrows - 1), jj = min(max(j0 - 2 + cc, 0), ncols - 1);
+        const size_t g = (size_t)jj * nrows + ii;
+        const float va = a[g], vb = b[g];
+        in0[cc][r] = va;
+        in1[cc][r] = vb;
+        inS[cc][r] = ((va + vb) * 0.55f) / 255.0f; // HsImage mode 3
+    }
+    __syncthreads();
+    auto five = [](float k0, float x0, float k1, float x1, float k2, float x2, float k3, float x3, float k4, float x4) {
+        float s = k0 * x0; // hs_v5 / hs_h5: products summed left to right
+        s = s + k1 * x1;
+        s = s + k2 * x2;
+        s = s + k3 * x3;
+        s = s + k4 * x4;
+        return s;
+    };
+    for (int e = tid; e < FP_IC * FP_TR; e += FP_TR * FP_TC) { // vertical first passes
+        const int cc = e / FP_TR, r = e - cc * FP_TR;
+        VS[cc][r] = five(HS_PRE[0], inS[cc][r], HS_PRE[1], inS[cc][r + 1], HS_PRE[2], inS[cc][r + 2], HS_PRE[3], inS[cc][r + 3], HS_PRE[4], inS[cc][r + 4]);
+        V0[cc][r] = five(HS_PRE[0], in0[cc][r], HS_PRE[1], in0[cc][r + 1], HS_PRE[2], in0[cc][r + 2], HS_PRE[3], in0[cc][r + 3], HS_PRE[4], in0[cc][r + 4]);
+        V1[cc][r] = five(HS_PRE[0], in1[cc][r], HS_PRE[1], in1[cc][r + 1], HS_PRE[2], in1[cc][r + 2], HS_PRE[3], in1[cc][r + 3], HS_PRE[4], in1[cc][r + 4]);
+    }
+    for (int e = tid; e < FP_TC * FP_IR; e += FP_TR * FP_TC) { // horizontal first passes
+        const int cc = e / FP_IR, r = e - cc * FP_IR;
+        HS[cc][r] = five(HS_PRE[0], inS[cc][r], HS_PRE[1], inS[cc + 1][r], HS_PRE[2], inS[cc + 2][r], HS_PRE[3], inS[cc + 3][r], HS_PRE[4], inS[cc + 4][r]);
+        HD[cc][r] = five(HS_D1F[0], inS[cc][r], HS_D1F[1], inS[cc + 1][r], HS_D1F[2], inS[cc + 2][r], HS_D1F[3], inS[cc + 3][r], HS_D1F[4], inS[cc + 4][r]);
+        H0[cc][r] = five(HS_PRE[0], in0[cc][r], HS_PRE[1], in0[cc + 1][r], HS_PRE[2], in0[cc + 2][r], HS_PRE[3], in0[cc + 3][r], HS_PRE[4], in0[cc + 4][r]);
+        H1[cc][r] = five(HS_PRE[0], in1[cc][r], HS_PRE[1], in1[cc + 1][r], HS_PRE[2], in1[cc + 2][r], HS_PRE[3], in1[cc + 3][r], HS_PRE[4], in1[cc + 4][r]);
+    }
+    __syncthreads();
+    const int i = i0 + tr, j = j0 + tc;
+    if (i >= nrows || j >= ncols) return;
+    const size_t pos = (size_t)j * nrows + i;
+    auto h5 = [&](const float (&V)[FP_IC][FP_TR], const float *k) { return five(k[0], V[tc][tr], k[1], V[tc + 1][tr], k[2], V[tc + 2][tr], k[3], V[tc + 3][tr], k[4], V[tc + 4][tr]); };
+    auto v5 = [&](const float (&H)[FP_TC][FP_IR], const float *k) { return five(k[0], H[tc][tr], k[1], H[tc][tr + 1], k[2], H[tc][tr + 2], k[3], H[tc][tr + 3], k[4], H[tc][tr + 4]); };
+    const float Idt = (in0[tc + 2][tr + 2] - in1[tc + 2][tr + 2]) / 255.0f;
+    const float Idx = h5(VS, HS_D1F);
+    const float Idy = v5(HS, HS_D1F);
+    const float Idxx = h5(VS, HS_D2);
+    const float Idyy = v5(HS, HS_D2);
+    const float Idxy = v5(HD, HS_D1F);
+    const float Idxt = h5(V0, FAS_D1F_SCL) - h5(V1, FAS_D1F_SCL);
+    const float Idyt = v5(H0, FAS_D1F_SCL) - v5(H1, FAS_D1F_SCL);
     float *o = planes + c * n + pos;
     o[FAS_IDT * blk] = Idt;
     o[FAS_IDX * blk] = Idx;

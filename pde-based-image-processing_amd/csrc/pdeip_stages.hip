@@ -283,7 +283,7 @@ extern "C" int pdeip_fas_prepare_dev(void *stream, const float *It0, const float
                                      float *planes)
 {
     RC(check_dims("pdeip_fas_prepare_dev", nrows, ncols, frames));
-    hipLaunchKernelGGL(k_fas_prepare, pixel_grid(nrows, ncols, frames), dim3(256), 0, static_cast<hipStream_t>(stream), planes, It0, It1, frames,
+    hipLaunchKernelGGL(k_fas_prepare, dim3((nrows + FP_TR - 1) / FP_TR, (ncols + FP_TC - 1) / FP_TC, frames), dim3(FP_TR, FP_TC), 0, static_cast<hipStream_t>(stream), planes, It0, It1, frames,
                        b1, b2, nrows, ncols);
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
