@@ -169,9 +169,17 @@ def check(rc):
         raise PdeipError(rc, last_error())
 
 
+_fn_cache = {}
+
+
 def call(name, *args):
     """Call an int-returning entry point and raise PdeipError on a non-zero status."""
-    check(getattr(load(), name)(*args))
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(load(), name)
+    rc = fn(*args)
+    if rc != PDEIP_OK:
+        raise PdeipError(rc, last_error())
 
 
 def set_mode(mode):

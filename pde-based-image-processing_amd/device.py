@@ -46,7 +46,14 @@ def _dims(t):
     return int(t.shape[-1]), int(t.shape[-2]), (int(t.shape[0]) if t.dim() == 3 else 1)  # nrows, ncols, F
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Raw handle of torch's current stream on the current device (the library only enqueues there).  The private accessor
+    skips building a Stream object per call -- a solver call on a coarse pyramid scale is shorter than that took."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
