@@ -348,6 +348,14 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
 
 } // namespace
 
+#ifdef PDEIP_RBP_STAMPS
+extern "C" int pdeip_debug_read_rbp_stamps(unsigned long long *out)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rbp_stamps), 256 * sizeof(unsigned long long)));
+    return PDEIP_OK;
+}
+#endif
 #ifdef PDEIP_EXACT_STAMPS
 extern "C" int pdeip_debug_read_stamps(unsigned long long *out)
 {

@@ -97,6 +97,21 @@ __device__ __forceinline__ void rbp_lds_write(float *col, int lane, const float 
 #define RBP_LDS(p) ((__attribute__((address_space(3))) void *)(p))
 #define RBP_GLB(p) ((const __attribute__((address_space(1))) void *)(p))
 
+#ifdef PDEIP_RBP_STAMPS // diagnostic build only (tools/rbp_stamps.py): where one sweep wave's step goes; never in the product
+__device__ unsigned long long g_rbp_stamps[256];
+#define RBP_STAMP_T0 60
+#define RBP_STAMP(n)                                                                                              \
+    do {                                                                                                          \
+        if (stamp_on) {                                                                                           \
+            unsigned long long t_;                                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
+            if (lane == 0) g_rbp_stamps[(t - RBP_STAMP_T0) * 8 + (n)] = t_;                                        \
+        }                                                                                                         \
+    } while (0)
+#else
+#define RBP_STAMP(n)
+#endif
+
 // LDS traffic only: the loader's DMA stays in flight across it (a __syncthreads() would drain vmcnt)
 __device__ __forceinline__ void rbp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -201,6 +216,10 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
     auto step = [&](int t, float (&Om)[NIT][4], float (&Oc)[NIT][4], float (&Op)[NIT][4], float (&Rpp)[NF][4], float (&Rp)[NF][4],
                     float (&Rc)[NF][4], const float (&Kp)[NCF][4], float (&Kc)[NCF][4]) __attribute__((always_inline)) {
         const int x = xbase + t - 3 * s; // this wave's red column; black on x-1
+#ifdef PDEIP_RBP_STAMPS
+        const bool stamp_on = (blockIdx.x == 100) && (s == RBP_STAMP_SWEEP) && (F0 == 0) && (t >= RBP_STAMP_T0) && (t < RBP_STAMP_T0 + 24);
+#endif
+        RBP_STAMP(0);
         // ---- take in column x+1 of the previous sweep's result, and the coefficients of columns x and x-1 ----
         float *const ks = Kring + (size_t)ki * NCF * COL; // column x; column x-1 (Kp) is the Kc of the previous step, kept in registers
         {
@@ -223,6 +242,10 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
                 }
         }
         const int p = (x + col0) & 1;
+#ifdef PDEIP_RBP_STAMPS
+        if (stamp_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        RBP_STAMP(1); // the step's LDS reads have landed
 
         if (FIRST && s == 0) {
             // Sweep 1 of a call builds the divisor planes as it goes (opticalflowSolvers.c:111-127): column x was just read
@@ -327,6 +350,7 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
             }
         }
 #undef PDEIP_RBP_PHASE
+        RBP_STAMP(2); // both half-sweeps issued
         if (s < S - 1) {
             float *dst = Hring + (size_t)(s * 2 + (hp ^ 1)) * NIT * COL;
 #pragma unroll
@@ -344,7 +368,13 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
         qi = (qi + 1 == L::NQ) ? 0 : qi + 1;
         oi = (oi + 1 == L::NO) ? 0 : oi + 1;
         hp ^= 1;
+        RBP_STAMP(3); // hand-off written / stores issued, bookkeeping done
+#ifdef PDEIP_RBP_STAMPS
+        if (stamp_on) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        RBP_STAMP(4); // LDS writes acknowledged
         rbp_barrier();
+        RBP_STAMP(5); // through the barrier
     };
 
     rbp_barrier(); // group 0 is in LDS
