@@ -213,14 +213,19 @@ def flow_coords(U, V, X, Y):
 
 
 def flow_warp(U, V, I1, W1, I2=None, W2=None):
-    """W1 = warp(I1) and optionally W2 = warp(I2) at (X+U, Y+V) in one launch (flow_coords + warp_bilinear x 2)."""
-    _chk(U, V, I1, W1)
+    """W1 = warp(I1) and optionally W2 = warp(I2) at (X+U, Y+V) in one launch (flow_coords + warp_bilinear x 2).
+    V = None: the disparity drivers' warp along x only (Y = the row grid itself)."""
+    _chk(U, I1, W1)
+    v = None
+    if V is not None:
+        _chk(V)
+        v = V.data_ptr()
     nrows, ncols, C1 = _dims(I1)
     if I2 is None:
-        capi.call("pdeip_flow_warp_dev", _stream(), *_p(U, V, I1), C1, None, 0, nrows, ncols, W1.data_ptr(), None)
+        capi.call("pdeip_flow_warp_dev", _stream(), U.data_ptr(), v, I1.data_ptr(), C1, None, 0, nrows, ncols, W1.data_ptr(), None)
     else:
         _chk(I2, W2)
-        capi.call("pdeip_flow_warp_dev", _stream(), *_p(U, V, I1), C1, I2.data_ptr(), _dims(I2)[2], nrows, ncols, *_p(W1, W2))
+        capi.call("pdeip_flow_warp_dev", _stream(), U.data_ptr(), v, I1.data_ptr(), C1, I2.data_ptr(), _dims(I2)[2], nrows, ncols, *_p(W1, W2))
 
 
 def flow_assemble(term1, term2, dU, dV, alpha, MGd, CuGd, CvGd, DuGd, DvGd):

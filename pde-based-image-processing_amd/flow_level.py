@@ -134,7 +134,6 @@ class DispLlinLevel:
         246-248, :277-292), as_diff = 1.75*(1/scl_factor)^-(scl-1), u_double: U is still MATLAB's double array (coarsest scale)."""
         p = self.p
         new = lambda like: torch.empty_like(like)
-        X, Y, zero = new(U), new(U), torch.zeros_like(U)
         w1, d1 = new(I1t1), [new(I1t1) for _ in range(3)]
         gradmag = str(p.get("sndTerm", "rgb")).lower() == "gradmag"   # DispEminND_llin_2D.m:236-238
         w2, d2 = (new(I2t1), [new(I2t1) for _ in range(5 if gradmag else 3)]) if I2t1 is not None else (None, None)
@@ -143,12 +142,10 @@ class DispLlinLevel:
         U, Un = U.clone(), new(U)
         solve = dev.disp_sor_llin4 if int(p["solver"]) == 1 else dev.disp_alr_llin4
         for first in range(int(p["firstLoop"])):
-            dev.flow_coords(U, zero, X, Y)                           # single(X+U), single(Y)
-            dev.warp_bilinear(I1t1, X, Y, w1)
+            dev.flow_warp(U, None, I1t1, w1, I2t1, w2)                # both constancy images at single(X+U), Y: one launch
             dev.fst_derivatives5(I1t0, w1, *d1)
             t1, t2 = (d1[0], d1[1], p["b1"]), None
             if I2t1 is not None:
-                dev.warp_bilinear(I2t1, X, Y, w2)
                 if gradmag:
                     dev.snd_derivatives5(I2t0, w2, *d2)
                     t2 = (d2[0], d2[1], d2[2], d2[4], p["b2"])        # Ixt, Iyt, Ixx, Ixy
