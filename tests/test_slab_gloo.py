@@ -210,3 +210,10 @@ def test_split_columns_and_halo_checks():
         slab.SlabDomain(40, 10, 0, 8, halo=8)
     with pytest.raises(ValueError):
         slab.SlabSolver(slab.SlabDomain(3840, 2160, 1, 2, halo=4), sweeps_per_exchange=4)
+    # a stencil stage wider than the halo can never be covered by an exchange
+    sv = slab.SlabSolver(slab.SlabDomain(3840, 2160, 1, 2, halo=8), sweeps_per_exchange=4, sweep_fn=lambda *a: None)
+    with pytest.raises(ValueError):
+        sv.stage([], 9, lambda: None)
+    # one rank: no halo, no exchange, the stage just runs
+    one = slab.SlabSolver(slab.SlabDomain(64, 32, 0, 1, halo=0), sweeps_per_exchange=4, sweep_fn=lambda *a: None)
+    assert one.stage([], 3, lambda: 7) == 7
