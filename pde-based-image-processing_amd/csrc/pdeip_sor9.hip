@@ -7,6 +7,8 @@
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
 #include "pdeip_sor_pde8.hpp"
+#include "pdeip_sor_pde8_persist.hpp"
+#include <vector>
 #include "pdeip_sor_rb.hpp"
 
 using namespace pdeip;
@@ -34,6 +36,44 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
         const float *cf[ModelPde8::NCF] = {bt, inv, wW, wNW, wN, wNE, wE, wSE, wS, wSW};
         for (int f = 0; f < ModelPde8::NCF; f++) P.cf[f] = cf[f];
         RC(ws_get(WS_PING, pde8_exact_scratch_floats(nrows, ncols, nframes, iter) * sizeof(float), &scratch));
+        // One launch per call (progress counters) or one per front?  PDEIP_PDE8_PERSIST = 0 keeps the launch-per-front form.
+        const int B = (ncols - 2 + 63) / 64;
+        static const bool persist = env_int("PDEIP_PDE8_PERSIST", 1) != 0;
+        if (persist && B <= 0xffff && iter <= 0x7fff && n * sizeof(float) < 0xffff0000ull) {
+            float *ctl_f = nullptr, *order_f = nullptr;
+            const size_t nprog = (size_t)nframes * iter * B;
+            RC(ws_get(WS_CTL, (4 + nprog) * sizeof(unsigned), &ctl_f));
+            RC(ws_get(WS_ORDER, (size_t)B * iter * sizeof(int), &order_f));
+            DeviceState *dst = cur_dev(); // after the ws_get calls: a regrown WS_ORDER has dropped its cached shape
+            if (dst->order_B != B || dst->order_T != iter) { // (b,t) in an order where every dependency comes earlier (same table as pdeip_sor5.hip)
+                std::vector<int> ord;
+                ord.reserve((size_t)B * iter);
+                for (int key = 0; key <= (B - 1) + 2 * (iter - 1); key++)
+                    for (int t = 0; t < iter; t++) {
+                        const int b = key - 2 * t;
+                        if (b >= 0 && b < B) ord.push_back(b | (t << 16));
+                    }
+                HIPCHK(hipMemcpyAsync(order_f, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, s));
+                HIPCHK(hipStreamSynchronize(s)); // `ord` is about to go out of scope
+                dst->order_B = B;
+                dst->order_T = iter;
+            }
+            // word 0: abort (sticky, cleared by pdeip_persist_error()); word 1: ticket; words 4..: progress counters
+            HIPCHK(hipMemsetAsync(reinterpret_cast<unsigned *>(ctl_f) + 1, 0, (3 + nprog) * sizeof(unsigned), s));
+            PersistCtl ctl{};
+            ctl.abort_flag = reinterpret_cast<unsigned *>(ctl_f);
+            ctl.ticket = ctl.abort_flag + 1;
+            ctl.progress = ctl.abort_flag + 4;
+            ctl.order = reinterpret_cast<const int *>(order_f);
+            dst->persist_used = true;
+            SweepTimer timer(s);
+            const int nl = pde8_run_exact_persist(s, P, scratch, ctl, nrows, ncols, nframes, iter, omega);
+            if (nl < 0) return PDEIP_ERR_DEVICE;
+            timer.stop(1);
+            g.last_launches += nl;
+            HIPCHK(hipGetLastError());
+            return PDEIP_OK;
+        }
         SweepTimer timer(s);
         const int nl = pde8_run_exact(s, P, scratch, nrows, ncols, nframes, iter, omega);
         if (nl < 0) return PDEIP_ERR_DEVICE; // LDS opt-in refused (message set by ensure_lds)

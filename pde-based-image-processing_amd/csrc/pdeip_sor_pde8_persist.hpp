@@ -1,0 +1,320 @@
+// pdeip_sor_pde8_persist.hpp -- GS_SOR_8_2d (pdeSolvers.c:184-262) in the reference's lexicographic order, ONE launch per call.
+//
+// k_pde8_exact (pdeip_sor_pde8.hpp) runs one launch per front m = a + 3b + 4t of 64-step tiles: 225 launches for a 4K frame at
+// iter = 4, each a cold start (launch gap, first fetch, store tail), and the tile grid makes a strip trail its west neighbour
+// by 192 rows where the stencil needs 128.  Here a workgroup owns one (strip b, sweep t) and walks down the strip chunk by
+// chunk (16 steps), as k_sor_exact_persist does for the 5-point models; the front ordering is replaced by progress counters:
+//   chunk c of (b,t) needs   progress[b-1][t]   >= c+9   west column, new values, down to the row lane 0 relaxes last + 1
+//                            progress[b][t-1]   >= c+2   own columns, 20 staged rows of sweep t-1
+//                            progress[b+1][t-1] >= c-6   east column of sweep t-1 (and: that strip has read what I overwrite)
+// (derivation in DESIGN.md 5.3b; every condition is checked before the chunk is FETCHED, two chunks ahead of its relaxation).
+//
+// Geometry: lane l owns column jbase + l and relaxes row 16c - 1 - 2l + q at step q of chunk c (two rows of skew per lane: the
+// south-west tap (i+1, j-1) is the west lane's result of the step before).  Every lane starts above the image and falls
+// through: a cell that is not relaxed (a border cell, a row outside the image) hands its staged value on unchanged, so the
+// north tap of row 1 and the west lane's taps of rows 0 and nrows-1 are the border cells without any start-up state.
+// Border cells hold the previous sweep's replicate (pdeSolvers.c:249-262 runs after the sweep): sweep t records its ring
+// (top/bottom/left/right) in a side array of its own, sweep t+1's loader substitutes ring values while staging.
+//
+// Hand-off as in k_sor_exact_persist: the iterate and the ring are stored write-through (sc1), drained, then the counter is
+// published with a relaxed agent-scope store; consumers poll relaxed and read with sc1 loads.  Tickets map to (b,t) in an
+// order in which every dependency has a smaller ticket; every spin is bounded and raises the sticky abort word.
+#pragma once
+#include "pdeip_sor_pde8.hpp"
+
+namespace pdeip {
+
+constexpr int P8P_THREADS = 192; // compute, loader, storer
+
+inline int pde8_persist_chunks(int nrows) { return (nrows + 126 + EX_CH - 1) / EX_CH; } // lane 63 reaches row nrows-2
+
+__global__ void __launch_bounds__(P8P_THREADS)
+k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int ncols, int B, int T, int NC, int nframes, float omega,
+                     size_t frame_stride)
+{
+    using L = Pde8Layout;
+    constexpr int NCF = ModelPde8::NCF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *outb_base = smem + 2 * L::BUF;
+    unsigned *s_ticket = reinterpret_cast<unsigned *>(smem + 2 * L::BUF + 2 * L::OUTB); // behind the 16-byte aligned region
+
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 compute, 1 loader, 2 storer
+    if (threadIdx.x == 0) *s_ticket = atomicAdd(ctl.ticket, 1u);
+    __syncthreads();
+    const unsigned tk = *s_ticket;
+    const int frame = (int)(tk % (unsigned)nframes);
+    const int packed = ctl.order[tk / (unsigned)nframes];
+    const int b = packed & 0xffff, t = packed >> 16;
+    const size_t fo = (size_t)frame * frame_stride;
+    unsigned *prog_mine = ctl.progress + ((size_t)frame * T + t) * B + b;
+    const unsigned *prog_west = (b > 0) ? prog_mine - 1 : nullptr;
+    const unsigned *prog_prev = (t > 0) ? prog_mine - B : nullptr;
+    const unsigned *prog_east = (t > 0 && b + 1 < B) ? prog_mine - B + 1 : nullptr;
+
+    // every plane through a range-checked buffer descriptor (an access outside the plane reads 0 / writes nothing)
+    const unsigned plane_bytes = (unsigned)((size_t)nrows * ncols * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(P.x + fo, 0, plane_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_cf[NCF];
+#pragma unroll
+    for (int f = 0; f < NCF; f++) rs_cf[f] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.cf[f]) + fo, 0, plane_bytes, 0x00020000);
+    // border ring after sweep t-1 (read) and after sweep t (written): top[ncols] bot[ncols] left[nrows] right[nrows]
+    const size_t sstride = pde8_side_stride(nrows, ncols);
+    float *ring_w = side + ((size_t)frame * T + t) * sstride;
+    const unsigned ring_bytes = (unsigned)(sstride * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_ring_w = __builtin_amdgcn_make_buffer_rsrc(ring_w, 0, ring_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ring_r = __builtin_amdgcn_make_buffer_rsrc(t > 0 ? ring_w - sstride : ring_w, 0, ring_bytes, 0x00020000);
+
+    const int jbase = 1 + 64 * b;
+    auto ccol = [&](int jj) { return jj < 0 ? 0 : (jj > ncols - 1 ? ncols - 1 : jj); };
+    auto crow = [&](int i) { return i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i); };
+    auto boff = [&](int jj, int row) { return (unsigned)(((long)jj * nrows + row) * 4); }; // negative -> out of range -> 0
+    auto row0 = [&](int c) { return EX_CH * c - 1; };                                       // lane 0's row at step 0 of chunk c
+    const int lcol = lane >> 2, lrq = lane & 3;
+    auto as_f4u = [](v4u_t v, f4u &o) {
+        o.v[0] = __uint_as_float(v.x); o.v[1] = __uint_as_float(v.y); o.v[2] = __uint_as_float(v.z); o.v[3] = __uint_as_float(v.w);
+    };
+
+    if (role == 1) {
+        // ================================ loader wave ==========================================
+        f4u cA[NCF][4], cB[NCF][4], xA[6], xB[6];
+        const unsigned *my_ptr = lane == 0 ? prog_west : (lane == 1 ? prog_prev : (lane == 2 ? prog_east : nullptr));
+        auto wait_deps = [&](int c) __attribute__((always_inline)) {
+            const int need = lane == 0 ? c + 9 : (lane == 1 ? c + 2 : c - 6);
+            persist_wait3(my_ptr, (unsigned)(need < 0 ? 0 : (need < NC ? need : NC)), ctl.abort_flag);
+        };
+        // the replicate of sweep t-1 for a border cell of the image (t > 0)
+        auto ring_cell = [&](int ii, int jj) __attribute__((always_inline)) -> float {
+            int idx;
+            if (ii == 0) idx = jj;
+            else if (ii == nrows - 1) idx = ncols + jj;
+            else if (jj == 0) idx = 2 * ncols + ii;
+            else idx = 2 * ncols + nrows + ii;
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_ring_r, (unsigned)idx * 4u, 0, 16));
+        };
+        // replace the border cells among rows row..row+3 of column jj by the previous sweep's ring values
+        auto patch = [&](f4u &v, int row, int jj) __attribute__((always_inline)) {
+            if (jj < 0 || jj > ncols - 1) return;
+            const bool colb = (jj == 0) || (jj == ncols - 1);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int ii = row + e;
+                if (ii >= 0 && ii <= nrows - 1 && (colb || ii == 0 || ii == nrows - 1)) v.v[e] = ring_cell(ii, jj);
+            }
+        };
+        auto fetch = [&](int c, f4u (&cpre)[NCF][4], f4u (&xpre)[6]) __attribute__((always_inline)) {
+            const int r0 = row0(c);
+            // does a staged window hold border cells of sweep t-1's ring?  rows r0-128 .. r0+19, columns jbase-1 .. jbase+64
+            const bool ringed = (t > 0) && ((r0 - 128 <= 0 && r0 + 19 >= 0) || (r0 - 128 <= nrows - 1 && r0 + 19 >= nrows - 1) ||
+                                            jbase - 1 == 0 || jbase + 64 >= ncols - 1);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 16 * g + lcol;
+                const int jj = ccol(jbase + col);
+                const int row = r0 - P8_SKEW * col + 4 * lrq;
+#pragma unroll
+                for (int f = 0; f < NCF; f++) as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_cf[f], boff(jj, row), 0, 0), cpre[f][g]);
+                as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_x, boff(jj, row), 0, 16), xpre[g]);
+            }
+            const int row4 = r0 - P8_SKEW * lane + 16; // fifth quad (rows +16..+19) of every own column: lane -> column
+            as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_x, boff(ccol(jbase + lane), row4), 0, 16), xpre[4]);
+            // lanes 0-4: east edge column (as lane 64); lanes 5-9: west edge column, rows r0-1 ...; the others repeat
+            const int w = lane % 10;
+            const bool west = w >= 5;
+            const int ej = west ? jbase - 1 : jbase + 64;
+            const int erow = west ? r0 - 1 + 4 * (w - 5) : r0 - P8_SKEW * 64 + 4 * w;
+            // row by row, clamped: the first strip's west column is column 0, where a negative row is a negative offset (the whole
+            // vector would read as out of range, valid rows included)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                xpre[5].v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, boff(ccol(ej), crow(erow + e)), 0, 16));
+            if (ringed) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) patch(xpre[g], r0 - P8_SKEW * (16 * g + lcol) + 4 * lrq, jbase + 16 * g + lcol);
+                patch(xpre[4], row4, jbase + lane);
+                patch(xpre[5], erow, ej);
+            }
+        };
+        auto stash = [&](const f4u (&cpre)[NCF][4], const f4u (&xpre)[6], int buf) __attribute__((always_inline)) {
+            float *cst = smem + buf * L::BUF, *xst = cst + L::CST, *wed = xst + L::XST;
+            auto put = [&](float *dst, const f4u &v) { *reinterpret_cast<float4 *>(dst) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]); };
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 16 * g + lcol;
+#pragma unroll
+                for (int f = 0; f < NCF; f++) put(&cst[(f * 64 + col) * EX_STR + 4 * lrq], cpre[f][g]);
+                put(&xst[col * EX_STR + 4 * lrq], xpre[g]);
+            }
+            put(&xst[lane * EX_STR + 16], xpre[4]);
+            if (lane < 5) put(&xst[64 * EX_STR + 4 * lane], xpre[5]);
+            else if (lane < 10) put(&wed[4 * (lane - 5)], xpre[5]);
+        };
+        // chunk c is fetched two barriers before it is relaxed and stashed one barrier before (two register sets)
+        wait_deps(0);
+        fetch(0, cA, xA);
+        stash(cA, xA, 0);
+        if (NC > 1) {
+            wait_deps(1);
+            fetch(1, cB, xB);
+        }
+        lds_barrier(); // chunk 0 is in buffer 0
+        for (int c = 0; c < NC; c += 2) {
+            // ---- while chunk c (buffer 0) is relaxed ----
+            if (c + 1 < NC) stash(cB, xB, 1);
+            if (c + 2 < NC) {
+                wait_deps(c + 2);
+                fetch(c + 2, cA, xA);
+            }
+            lds_barrier();
+            if (c + 1 >= NC) break;
+            // ---- while chunk c+1 (buffer 1) is relaxed ----
+            if (c + 2 < NC) stash(cA, xA, 0);
+            if (c + 3 < NC) {
+                wait_deps(c + 3);
+                fetch(c + 3, cB, xB);
+            }
+            lds_barrier();
+        }
+        return;
+    }
+
+    if (role == 2) {
+        // ================================ storer wave =========================================
+        auto store_out = [&](int c) __attribute__((always_inline)) {
+            const float *outb = outb_base + (c & 1) * L::OUTB;
+            const int r0 = row0(c);
+            const bool all_valid = (r0 - 126 >= 1) && (r0 + EX_CH - 1 <= nrows - 2) && (jbase + 63 <= ncols - 2);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 16 * g + lcol;
+                const int jj = jbase + col;
+                const int row = r0 - P8_SKEW * col + 4 * lrq;
+                const float4 v = *reinterpret_cast<const float4 *>(&outb[col * EX_STR + 4 * lrq]);
+                if (all_valid) {
+                    v4u_t u;
+                    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(u, rs_x, boff(jj, row), 0, 16);
+                } else if (jj <= ncols - 2) {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (row + e >= 1 && row + e <= nrows - 2)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[e]), rs_x, boff(jj, row + e), 0, 16);
+                }
+            }
+        };
+        // progress = c+1 once every store of chunk c has left (the compute wave drained its ring stores before the barrier)
+        auto publish = [&](int c) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(prog_mine, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        lds_barrier(); // chunk 0 is in buffer 0
+        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: write chunk k-1 back
+            if (k >= 1) {
+                store_out(k - 1);
+                publish(k - 1);
+            }
+            lds_barrier();
+        }
+        store_out(NC - 1);
+        publish(NC - 1);
+        return;
+    }
+
+    // ================================== compute wave ===========================================
+    const int j = jbase + lane;
+    const bool col_ok = j <= ncols - 2;
+    const float om1 = 1.0f - omega;
+    float prev = 0.0f, w = 0.0f, nw = 0.0f;
+    lds_barrier(); // chunk 0 is in buffer 0
+
+    for (int k = 0; k < NC; k++) {
+        const float *cst = smem + (k & 1) * L::BUF, *xst = cst + L::CST, *wed = xst + L::XST;
+        float *outb = outb_base + (k & 1) * L::OUTB;
+        const int i0 = row0(k) - P8_SKEW * lane; // my row at step 0 of this chunk
+        auto relax_chunk = [&](auto interior_tag) __attribute__((always_inline)) {
+            constexpr bool INTERIOR = decltype(interior_tag)::value;
+#pragma unroll
+            for (int mq = 0; mq < EX_CH / 4; mq++) {
+                float4 ck[NCF], res;
+                float xo[8], xe[8], we[8];
+#pragma unroll
+                for (int f = 0; f < NCF; f++) ck[f] = *reinterpret_cast<const float4 *>(&cst[(f * 64 + lane) * EX_STR + 4 * mq]);
+                {
+                    const float4 a0 = *reinterpret_cast<const float4 *>(&xst[lane * EX_STR + 4 * mq]);
+                    const float4 a1 = *reinterpret_cast<const float4 *>(&xst[lane * EX_STR + 4 * mq + 4]);
+                    const float4 b0 = *reinterpret_cast<const float4 *>(&xst[(lane + 1) * EX_STR + 4 * mq]);
+                    const float4 b1 = *reinterpret_cast<const float4 *>(&xst[(lane + 1) * EX_STR + 4 * mq + 4]);
+                    const float4 c0 = *reinterpret_cast<const float4 *>(&wed[4 * mq]);
+                    const float4 c1 = *reinterpret_cast<const float4 *>(&wed[4 * mq + 4]);
+                    xo[0] = a0.x; xo[1] = a0.y; xo[2] = a0.z; xo[3] = a0.w; xo[4] = a1.x; xo[5] = a1.y; xo[6] = a1.z; xo[7] = a1.w;
+                    xe[0] = b0.x; xe[1] = b0.y; xe[2] = b0.z; xe[3] = b0.w; xe[4] = b1.x; xe[5] = b1.y; xe[6] = b1.z; xe[7] = b1.w;
+                    we[0] = c0.x; we[1] = c0.y; we[2] = c0.z; we[3] = c0.w; we[4] = c1.x; we[5] = c1.y; we[6] = c1.z; we[7] = c1.w;
+                }
+#pragma unroll
+                for (int xq = 0; xq < 4; xq++) {
+                    const int i = i0 + 4 * mq + xq;
+                    const bool active = INTERIOR || (col_ok && (i >= 1) && (i <= nrows - 2));
+                    auto el = [&](const float4 &v) { return xq == 0 ? v.x : (xq == 1 ? v.y : (xq == 2 ? v.z : v.w)); };
+                    // south-west (new): lane l-1 relaxed (i+1, j-1) one step ago; lane 0 reads the west edge column
+                    const float sw = dpp_from_lower_lane(prev, we[xq + 2]);
+                    float kk[NCF];
+#pragma unroll
+                    for (int f = 0; f < NCF; f++) kk[f] = el(ck[f]);
+                    // update(xc, xW, xE, xN, xS, xNW, xNE, xSW, xSE)
+                    const float v = ModelPde8::update(xo[xq], w, xe[xq + 2], prev, xo[xq + 1], nw, xe[xq + 1], sw, xe[xq + 3], kk, omega, om1);
+                    prev = active ? v : xo[xq]; // a cell that is not relaxed hands its value on: border rows feed the taps of rows 1 / nrows-2
+                    if (xq == 0) res.x = v; else if (xq == 1) res.y = v; else if (xq == 2) res.z = v; else res.w = v;
+                    if (!INTERIOR && active) { // border ring after this sweep: nearest-interior replicate (pdeSolvers.c:249-262)
+                        const unsigned uv = __float_as_uint(v);
+                        auto put = [&](int idx) { __builtin_amdgcn_raw_buffer_store_b32(uv, rs_ring_w, (unsigned)idx * 4u, 0, 16); };
+                        const int top = 0, bot = ncols, left = 2 * ncols, right = 2 * ncols + nrows;
+                        if (i == 1) {
+                            put(top + j);
+                            if (j == 1) { put(top); put(left); }
+                            if (j == ncols - 2) { put(top + ncols - 1); put(right); }
+                        }
+                        if (i == nrows - 2) {
+                            put(bot + j);
+                            if (j == 1) { put(bot); put(left + nrows - 1); }
+                            if (j == ncols - 2) { put(bot + ncols - 1); put(right + nrows - 1); }
+                        }
+                        if (j == 1) put(left + i);
+                        if (j == ncols - 2) put(right + i);
+                    }
+                    nw = w;
+                    w = sw;
+                }
+                *reinterpret_cast<float4 *>(&outb[lane * EX_STR + 4 * mq]) = res;
+            }
+        };
+        {
+            const int lo_row = row0(k) - 126, hi_row = row0(k) + EX_CH - 1;
+            const bool interior = (lo_row >= 2) && (hi_row <= nrows - 3) && (jbase >= 2) && (jbase + 63 <= ncols - 3);
+            if (interior) relax_chunk(std::true_type{});
+            else {
+                relax_chunk(std::false_type{});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring stores have left before the storer publishes this chunk
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// One launch + the final border replicate.  Returns the number of launches, or -1 (message set).
+inline int pde8_run_exact_persist(hipStream_t s, Pde8Planes P, float *side, PersistCtl ctl, int nrows, int ncols, int nframes, int iter,
+                                  float omega)
+{
+    const size_t n = (size_t)nrows * ncols;
+    const int B = (ncols - 2 + 63) / 64;
+    const int NC = pde8_persist_chunks(nrows);
+    constexpr size_t lds = Pde8Layout::LDS_BYTES + 16;
+    if (ensure_lds(reinterpret_cast<const void *>(&k_pde8_exact_persist), lds) != PDEIP_OK) return -1;
+    hipLaunchKernelGGL(k_pde8_exact_persist, dim3((unsigned)(B * iter * nframes)), dim3(P8P_THREADS), lds, s, P, side, ctl, nrows, ncols, B, iter,
+                       NC, nframes, omega, n);
+    const int nb = 2 * ncols + 2 * (nrows - 2);
+    hipLaunchKernelGGL(k_fill_borders, dim3((nb + 255) / 256, nframes, 1), dim3(256), 0, s, P.x, P.x, 1, nrows, ncols, n);
+    return 2;
+}
+
+} // namespace pdeip
