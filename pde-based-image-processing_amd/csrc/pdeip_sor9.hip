@@ -60,7 +60,13 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
             }
             // word 0: abort (sticky, cleared by pdeip_persist_error()); word 1: ticket; words 4..: progress counters
             HIPCHK(hipMemsetAsync(reinterpret_cast<unsigned *>(ctl_f) + 1, 0, (3 + nprog) * sizeof(unsigned), s));
+            // west-edge mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, step of the walk), tags clear at the start of a call
+            float *mail_f = nullptr;
+            const size_t mail_bytes = nprog * (size_t)pde8_persist_chunks(nrows) * EX_CH * sizeof(unsigned long long);
+            RC(ws_get(WS_MAIL, mail_bytes, &mail_f));
+            HIPCHK(hipMemsetAsync(mail_f, 0, mail_bytes, s));
             PersistCtl ctl{};
+            ctl.mail = reinterpret_cast<unsigned long long *>(mail_f);
             ctl.abort_flag = reinterpret_cast<unsigned *>(ctl_f);
             ctl.ticket = ctl.abort_flag + 1;
             ctl.progress = ctl.abort_flag + 4;

@@ -4,10 +4,15 @@
 // iter = 4, each a cold start (launch gap, first fetch, store tail), and the tile grid makes a strip trail its west neighbour
 // by 192 rows where the stencil needs 128.  Here a workgroup owns one (strip b, sweep t) and walks down the strip chunk by
 // chunk (16 steps), as k_sor_exact_persist does for the 5-point models; the front ordering is replaced by progress counters:
-//   chunk c of (b,t) needs   progress[b-1][t]   >= c+9   west column, new values, down to the row lane 0 relaxes last + 1
-//                            progress[b][t-1]   >= c+2   own columns, 20 staged rows of sweep t-1
+//   chunk c of (b,t) needs   progress[b][t-1]   >= c+2   own columns, 20 staged rows of sweep t-1
 //                            progress[b+1][t-1] >= c-6   east column of sweep t-1 (and: that strip has read what I overwrite)
-// (derivation in DESIGN.md 5.3b; every condition is checked before the chunk is FETCHED, two chunks ahead of its relaxation).
+//                            the west strip's east column of sweep t down to row 16c+15: its chunk c+8 -- by mailbox, see below
+// (derivation in DESIGN.md 5.3b; the two counters are checked before the chunk is FETCHED, two chunks ahead of its relaxation).
+// West edge: lane 63's 16 results of a chunk (a border row's handed-on value included) leave as one 128-byte line of
+// {value, tag} words, written through by the compute wave itself; the east strip's storer polls the 18 words the next chunk
+// needs and puts them into that chunk's LDS edge slot.  One round trip, and the bulk fetch does not wait for the west strip
+// at all: a strip trails its neighbour by ~10 chunks instead of 14 (through the plane: store, drain, publish, poll, fetch two
+// chunks ahead).  The first strip's west column is the image border: its loader stages it from the plane / the ring.
 //
 // Geometry: lane l owns column jbase + l and relaxes row 16c - 1 - 2l + q at step q of chunk c (two rows of skew per lane: the
 // south-west tap (i+1, j-1) is the west lane's result of the step before).  Every lane starts above the image and falls
@@ -26,7 +31,7 @@ namespace pdeip {
 
 constexpr int P8P_THREADS = 192; // compute, loader, storer
 
-inline int pde8_persist_chunks(int nrows) { return (nrows + 126 + EX_CH - 1) / EX_CH; } // lane 63 reaches row nrows-2
+inline int pde8_persist_chunks(int nrows) { return (nrows + 127 + EX_CH - 1) / EX_CH; } // lane 63 reaches row nrows-1 (handed on to the east strip)
 
 __global__ void __launch_bounds__(P8P_THREADS)
 k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int ncols, int B, int T, int NC, int nframes, float omega,
@@ -48,7 +53,6 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
     const int b = packed & 0xffff, t = packed >> 16;
     const size_t fo = (size_t)frame * frame_stride;
     unsigned *prog_mine = ctl.progress + ((size_t)frame * T + t) * B + b;
-    const unsigned *prog_west = (b > 0) ? prog_mine - 1 : nullptr;
     const unsigned *prog_prev = (t > 0) ? prog_mine - B : nullptr;
     const unsigned *prog_east = (t > 0 && b + 1 < B) ? prog_mine - B + 1 : nullptr;
 
@@ -78,9 +82,9 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
     if (role == 1) {
         // ================================ loader wave ==========================================
         f4u cA[NCF][4], cB[NCF][4], xA[6], xB[6];
-        const unsigned *my_ptr = lane == 0 ? prog_west : (lane == 1 ? prog_prev : (lane == 2 ? prog_east : nullptr));
+        const unsigned *my_ptr = lane == 1 ? prog_prev : (lane == 2 ? prog_east : nullptr); // the west strip: by mailbox (storer)
         auto wait_deps = [&](int c) __attribute__((always_inline)) {
-            const int need = lane == 0 ? c + 9 : (lane == 1 ? c + 2 : c - 6);
+            const int need = lane == 1 ? c + 2 : c - 6;
             persist_wait3(my_ptr, (unsigned)(need < 0 ? 0 : (need < NC ? need : NC)), ctl.abort_flag);
         };
         // the replicate of sweep t-1 for a border cell of the image (t > 0)
@@ -147,7 +151,7 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
             }
             put(&xst[lane * EX_STR + 16], xpre[4]);
             if (lane < 5) put(&xst[64 * EX_STR + 4 * lane], xpre[5]);
-            else if (lane < 10) put(&wed[4 * (lane - 5)], xpre[5]);
+            else if (lane < 10 && b == 0) put(&wed[4 * (lane - 5)], xpre[5]); // a later strip's west column: the mailbox
         };
         // chunk c is fetched two barriers before it is relaxed and stashed one barrier before (two register sets)
         wait_deps(0);
@@ -208,12 +212,47 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(prog_mine, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        lds_barrier(); // chunk 0 is in buffer 0
-        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: write chunk k-1 back
-            if (k >= 1) {
-                store_out(k - 1);
-                publish(k - 1);
+        // West edge of chunk c: lane r polls the west strip's mailbox word of row 16c - 2 + r (r < 18) until its tag is set and
+        // puts the value into the chunk's LDS edge slot.  The polls queue behind the stores of the previous chunk, so once the
+        // first one has returned those stores have drained: publish `pub` then.
+        const size_t mpitch = (size_t)NC * EX_CH;
+        const unsigned long long *mail_w = ctl.mail + (((size_t)frame * T + t) * B + (b > 0 ? b - 1 : 0)) * mpitch;
+        auto take = [&](int c, int pub) __attribute__((always_inline)) {
+            if (b > 0 && c < NC) {
+                const int row = row0(c) - 1 + lane;
+                const bool want = lane < 18 && row >= 0 && row <= nrows - 1;
+                float v = 0.0f;
+                bool ok = !want;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+                for (;;) {
+                    if (!ok) {
+                        const unsigned long long wd = __hip_atomic_load(mail_w + row + 127, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(wd >> 32) != 0u) {
+                            v = __uint_as_float((unsigned)wd);
+                            ok = true;
+                        }
+                    }
+                    if (pub >= 0) {
+                        publish(pub);
+                        pub = -1;
+                    }
+                    if (__all(ok)) break;
+                    if (__hip_atomic_load(ctl.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) { // 0.5 s: drain the grid, the host reports it
+                        __hip_atomic_store(ctl.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (lane < 18) (smem + (c & 1) * L::BUF + L::CST + L::XST)[lane] = v;
             }
+            if (pub >= 0) publish(pub);
+        };
+        take(0, -1);
+        lds_barrier(); // chunk 0 is in buffer 0
+        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: write chunk k-1 back, fetch the west values of chunk k+1
+            if (k >= 1) store_out(k - 1);
+            take(k + 1, k >= 1 ? k - 1 : -1);
             lds_barrier();
         }
         store_out(NC - 1);
@@ -226,6 +265,9 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
     const bool col_ok = j <= ncols - 2;
     const float om1 = 1.0f - omega;
     float prev = 0.0f, w = 0.0f, nw = 0.0f;
+    const bool has_east = (b + 1 < B); // my last column is the next strip's west column
+    unsigned long long *const mail_mine = ctl.mail + (((size_t)frame * T + t) * B + b) * ((size_t)NC * EX_CH);
+    const __amdgpu_buffer_rsrc_t rs_mail = __builtin_amdgcn_make_buffer_rsrc(mail_mine, 0, (unsigned)((size_t)NC * EX_CH * 8), 0x00020000);
     lds_barrier(); // chunk 0 is in buffer 0
 
     for (int k = 0; k < NC; k++) {
@@ -264,7 +306,7 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
                     // update(xc, xW, xE, xN, xS, xNW, xNE, xSW, xSE)
                     const float v = ModelPde8::update(xo[xq], w, xe[xq + 2], prev, xo[xq + 1], nw, xe[xq + 1], sw, xe[xq + 3], kk, omega, om1);
                     prev = active ? v : xo[xq]; // a cell that is not relaxed hands its value on: border rows feed the taps of rows 1 / nrows-2
-                    if (xq == 0) res.x = v; else if (xq == 1) res.y = v; else if (xq == 2) res.z = v; else res.w = v;
+                    if (xq == 0) res.x = prev; else if (xq == 1) res.y = prev; else if (xq == 2) res.z = prev; else res.w = prev;
                     if (!INTERIOR && active) { // border ring after this sweep: nearest-interior replicate (pdeSolvers.c:249-262)
                         const unsigned uv = __float_as_uint(v);
                         auto put = [&](int idx) { __builtin_amdgcn_raw_buffer_store_b32(uv, rs_ring_w, (unsigned)idx * 4u, 0, 16); };
@@ -296,6 +338,16 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
                 relax_chunk(std::false_type{});
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring stores have left before the storer publishes this chunk
             }
+        }
+        if (has_east && lane < 16) {
+            // mailbox: lane 63's 16 values of this chunk (rows 16k - 127 .. 16k - 112 of my last column) as ONE 128-byte line of
+            // self-validating words -- lanes 0..15 pick them up from the out buffer this wave just wrote (LDS operations of one wave
+            // complete in order).  A full-line store needs no read of the line it replaces.
+            typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+            v2u_t wv;
+            wv.x = __float_as_uint(outb[63 * EX_STR + lane]);
+            wv.y = 1u;
+            __builtin_amdgcn_raw_buffer_store_b64(wv, rs_mail, (unsigned)((EX_CH * k + lane) * 8), 0, 16); // sc1
         }
         lds_barrier();
     }
