@@ -38,7 +38,7 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
         RC(ws_get(WS_PING, pde8_exact_scratch_floats(nrows, ncols, nframes, iter) * sizeof(float), &scratch));
         // One launch per call (progress counters) or one per front?  PDEIP_PDE8_PERSIST = 0 keeps the launch-per-front form.
         const int B = (ncols - 2 + 63) / 64;
-        static const bool persist = env_int("PDEIP_PDE8_PERSIST", 1) != 0;
+        const bool persist = env_int("PDEIP_PDE8_PERSIST", 1) != 0;
         if (persist && B <= 0xffff && iter <= 0x7fff && n * sizeof(float) < 0xffff0000ull) {
             float *ctl_f = nullptr, *order_f = nullptr;
             const size_t nprog = (size_t)nframes * iter * B;

@@ -29,7 +29,7 @@
 
 namespace pdeip {
 
-constexpr int P8P_THREADS = 192; // compute, loader, storer
+constexpr int P8P_THREADS = 256; // compute, loader, storer, west-edge poller: one wave per SIMD
 
 inline int pde8_persist_chunks(int nrows) { return (nrows + 127 + EX_CH - 1) / EX_CH; } // lane 63 reaches row nrows-1 (handed on to the east strip)
 
@@ -44,7 +44,7 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
     unsigned *s_ticket = reinterpret_cast<unsigned *>(smem + 2 * L::BUF + 2 * L::OUTB); // behind the 16-byte aligned region
 
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 compute, 1 loader, 2 storer
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 compute, 1 loader, 2 storer, 3 west edge
     if (threadIdx.x == 0) *s_ticket = atomicAdd(ctl.ticket, 1u);
     __syncthreads();
     const unsigned tk = *s_ticket;
@@ -188,6 +188,9 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
             const float *outb = outb_base + (c & 1) * L::OUTB;
             const int r0 = row0(c);
             const bool all_valid = (r0 - 126 >= 1) && (r0 + EX_CH - 1 <= nrows - 2) && (jbase + 63 <= ncols - 2);
+            // does the chunk relax a pixel next to the image border?
+            const bool ringed = (r0 - 126 <= 1 && r0 + EX_CH - 1 >= 1) || (r0 - 126 <= nrows - 2 && r0 + EX_CH - 1 >= nrows - 2) ||
+                                jbase == 1 || jbase + 63 >= ncols - 2;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int col = 16 * g + lcol;
@@ -205,6 +208,31 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
                         if (row + e >= 1 && row + e <= nrows - 2)
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[e]), rs_x, boff(jj, row + e), 0, 16);
                 }
+                // border ring after this sweep: nearest-interior replicate (pdeSolvers.c:249-262).  Written here, not by the compute
+                // wave: these stores and their drain would sit in every chunk of the first strip, which paces all the others.
+                if (ringed && jj <= ncols - 2) {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    const int top = 0, bot = ncols, left = 2 * ncols, right = 2 * ncols + nrows;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int i = row + e;
+                        if (i < 1 || i > nrows - 2) continue;
+                        const unsigned uv = __float_as_uint(vv[e]);
+                        auto put = [&](int idx) { __builtin_amdgcn_raw_buffer_store_b32(uv, rs_ring_w, (unsigned)idx * 4u, 0, 16); };
+                        if (i == 1) {
+                            put(top + jj);
+                            if (jj == 1) { put(top); put(left); }
+                            if (jj == ncols - 2) { put(top + ncols - 1); put(right); }
+                        }
+                        if (i == nrows - 2) {
+                            put(bot + jj);
+                            if (jj == 1) { put(bot); put(left + nrows - 1); }
+                            if (jj == ncols - 2) { put(bot + ncols - 1); put(right + nrows - 1); }
+                        }
+                        if (jj == 1) put(left + i);
+                        if (jj == ncols - 2) put(right + i);
+                    }
+                }
             }
         };
         // progress = c+1 once every store of chunk c has left (the compute wave drained its ring stores before the barrier)
@@ -212,12 +240,27 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(prog_mine, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
+        lds_barrier(); // chunk 0 is in buffer 0
+        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: write chunk k-1 back
+            if (k >= 1) {
+                store_out(k - 1);
+                publish(k - 1);
+            }
+            lds_barrier();
+        }
+        store_out(NC - 1);
+        publish(NC - 1);
+        return;
+    }
+
+    if (role == 3) {
+        // ================================ west-edge wave =======================================
         // West edge of chunk c: lane r polls the west strip's mailbox word of row 16c - 2 + r (r < 18) until its tag is set and
-        // puts the value into the chunk's LDS edge slot.  The polls queue behind the stores of the previous chunk, so once the
-        // first one has returned those stores have drained: publish `pub` then.
+        // puts the value into the chunk's LDS edge slot.  A wave of its own: behind the storer's write-through stores a poll
+        // would wait for their drain first (vmcnt counts in order), and that round trip would be every chunk's.
         const size_t mpitch = (size_t)NC * EX_CH;
         const unsigned long long *mail_w = ctl.mail + (((size_t)frame * T + t) * B + (b > 0 ? b - 1 : 0)) * mpitch;
-        auto take = [&](int c, int pub) __attribute__((always_inline)) {
+        auto take = [&](int c) __attribute__((always_inline)) {
             if (b > 0 && c < NC) {
                 const int row = row0(c) - 1 + lane;
                 const bool want = lane < 18 && row >= 0 && row <= nrows - 1;
@@ -232,10 +275,6 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
                             ok = true;
                         }
                     }
-                    if (pub >= 0) {
-                        publish(pub);
-                        pub = -1;
-                    }
                     if (__all(ok)) break;
                     if (__hip_atomic_load(ctl.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) { // 0.5 s: drain the grid, the host reports it
@@ -246,17 +285,13 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
                 }
                 if (lane < 18) (smem + (c & 1) * L::BUF + L::CST + L::XST)[lane] = v;
             }
-            if (pub >= 0) publish(pub);
         };
-        take(0, -1);
+        take(0);
         lds_barrier(); // chunk 0 is in buffer 0
-        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: write chunk k-1 back, fetch the west values of chunk k+1
-            if (k >= 1) store_out(k - 1);
-            take(k + 1, k >= 1 ? k - 1 : -1);
+        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: the west values of chunk k+1
+            take(k + 1);
             lds_barrier();
         }
-        store_out(NC - 1);
-        publish(NC - 1);
         return;
     }
 
@@ -307,23 +342,6 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
                     const float v = ModelPde8::update(xo[xq], w, xe[xq + 2], prev, xo[xq + 1], nw, xe[xq + 1], sw, xe[xq + 3], kk, omega, om1);
                     prev = active ? v : xo[xq]; // a cell that is not relaxed hands its value on: border rows feed the taps of rows 1 / nrows-2
                     if (xq == 0) res.x = prev; else if (xq == 1) res.y = prev; else if (xq == 2) res.z = prev; else res.w = prev;
-                    if (!INTERIOR && active) { // border ring after this sweep: nearest-interior replicate (pdeSolvers.c:249-262)
-                        const unsigned uv = __float_as_uint(v);
-                        auto put = [&](int idx) { __builtin_amdgcn_raw_buffer_store_b32(uv, rs_ring_w, (unsigned)idx * 4u, 0, 16); };
-                        const int top = 0, bot = ncols, left = 2 * ncols, right = 2 * ncols + nrows;
-                        if (i == 1) {
-                            put(top + j);
-                            if (j == 1) { put(top); put(left); }
-                            if (j == ncols - 2) { put(top + ncols - 1); put(right); }
-                        }
-                        if (i == nrows - 2) {
-                            put(bot + j);
-                            if (j == 1) { put(bot); put(left + nrows - 1); }
-                            if (j == ncols - 2) { put(bot + ncols - 1); put(right + nrows - 1); }
-                        }
-                        if (j == 1) put(left + i);
-                        if (j == ncols - 2) put(right + i);
-                    }
                     nw = w;
                     w = sw;
                 }
@@ -334,10 +352,7 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
             const int lo_row = row0(k) - 126, hi_row = row0(k) + EX_CH - 1;
             const bool interior = (lo_row >= 2) && (hi_row <= nrows - 3) && (jbase >= 2) && (jbase + 63 <= ncols - 3);
             if (interior) relax_chunk(std::true_type{});
-            else {
-                relax_chunk(std::false_type{});
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the ring stores have left before the storer publishes this chunk
-            }
+            else relax_chunk(std::false_type{});
         }
         if (has_east && lane < 16) {
             // mailbox: lane 63's 16 values of this chunk (rows 16k - 127 .. 16k - 112 of my last column) as ONE 128-byte line of

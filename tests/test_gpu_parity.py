@@ -4,6 +4,8 @@ same seeded inputs.  Bar: bit-exact (float32 arithmetic in the reference's opera
 EXACT_ORDER mode is compared with the oracle's lexicographic (reference) order; RED_BLACK mode
 with the oracle's colour order (same per-pixel arithmetic, red-black / four-colour sweeps).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -123,6 +125,23 @@ def test_pde_sor8(pdeip, oracle, mode, order, shape, F):
         got = pdeip.mex_api.PDEsolver8(*p.values(), np.float32(it), np.float32(1.75), np.float32(1))
         want = oracle.PDEsolver8(*p.values(), it, 1.75, order=order)
         check(got, want, "pde8 %s F=%d it=%d mode=%d" % (shape, F, it, mode))
+
+
+@pytest.mark.parametrize("shape,F,it", [((40, 330), 2, 3), ((300, 140), 1, 9), ((3, 70), 1, 2), ((130, 66), 1, 4), ((17, 129), 3, 6)])
+def test_pde_sor8_exact_one_launch_vs_fronts(pdeip, oracle, shape, F, it):
+    """Reference order, 9-point: the strip walkers (k_pde8_exact_persist, one launch) and the launch-per-front tiles give the
+    oracle's bits -- several strips, a last strip of one column, more sweeps than strips, several frames."""
+    pdeip.mex_api.set_mode(0)
+    p = pb.pde8(67, *shape, nframes=F)
+    want = oracle.PDEsolver8(*p.values(), it, 1.75, order=0)
+    try:
+        for knob in ("1", "0"):
+            os.environ["PDEIP_PDE8_PERSIST"] = knob
+            got = pdeip.mex_api.PDEsolver8(*p.values(), np.float32(it), np.float32(1.75), np.float32(1))
+            check(got, want, "pde8 %s F=%d it=%d persist=%s" % (shape, F, it, knob))
+    finally:
+        os.environ.pop("PDEIP_PDE8_PERSIST", None)
+    assert pdeip.capi.load().pdeip_persist_error() == 0
 
 
 @pytest.mark.parametrize("shape,F", [((32, 48), 1), ((97, 131), 3), ((3, 3), 2), ((260, 7), 1), ((388, 584), 1)])
