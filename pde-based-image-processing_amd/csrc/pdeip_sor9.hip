@@ -153,3 +153,12 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
     return PDEIP_OK;
 }
 
+
+#ifdef PDEIP_P8_STAMPS
+extern "C" int pdeip_debug_read_p8_stamps(unsigned long long *out)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p8_stamps), 4096 * sizeof(unsigned long long)));
+    return PDEIP_OK;
+}
+#endif

@@ -29,6 +29,25 @@
 
 namespace pdeip {
 
+#ifdef PDEIP_P8_STAMPS // diagnostic build only (tools/p8_stamps.py): how long each wave of a walker works per interval; never in the product
+__device__ unsigned long long g_p8_stamps[4096];
+#define P8S_DECL unsigned long long s_busy_ = 0, s_i0_ = 0; const unsigned long long s_t0_ = __builtin_amdgcn_s_memtime(), s_r0_ = __builtin_amdgcn_s_memrealtime()
+#define P8S_BEGIN s_i0_ = __builtin_amdgcn_s_memtime()
+#define P8S_END s_busy_ += __builtin_amdgcn_s_memtime() - s_i0_
+#define P8S_WRITE                                                                                                                  \
+    if (lane == 0 && tk < 256) {                                                                                                  \
+        g_p8_stamps[(tk * 4 + role) * 4 + 0] = s_busy_;                                                                            \
+        g_p8_stamps[(tk * 4 + role) * 4 + 1] = __builtin_amdgcn_s_memtime() - s_t0_;                                              \
+        g_p8_stamps[(tk * 4 + role) * 4 + 2] = __builtin_amdgcn_s_memrealtime() - s_r0_;                                          \
+        g_p8_stamps[(tk * 4 + role) * 4 + 3] = (unsigned long long)(b | (t << 16));                                               \
+    }
+#else
+#define P8S_DECL
+#define P8S_BEGIN
+#define P8S_END
+#define P8S_WRITE
+#endif
+
 constexpr int P8P_THREADS = 256; // compute, loader, storer, west-edge poller: one wave per SIMD
 
 inline int pde8_persist_chunks(int nrows) { return (nrows + 127 + EX_CH - 1) / EX_CH; } // lane 63 reaches row nrows-1 (handed on to the east strip)
@@ -154,6 +173,19 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
             else if (lane < 10 && b == 0) put(&wed[4 * (lane - 5)], xpre[5]); // a later strip's west column: the mailbox
         };
         // chunk c is fetched two barriers before it is relaxed and stashed one barrier before (two register sets)
+        // Per interval: look at the dependency poll issued one interval ago, issue the loads of the chunk two ahead, THEN stash
+        // the chunk that was fetched one interval ago (its loads are older than the ones just issued and vmcnt counts in order,
+        // so they have had a whole interval to land; stashing first and fetching second left them only the barrier and showed
+        // their full latency in every interval -- the walk's pace), and issue the next poll.
+        auto poll_issue = [&]() __attribute__((always_inline)) -> unsigned {
+            return (t > 0 && my_ptr != nullptr) ? __hip_atomic_load(my_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+        };
+        auto poll_finish = [&](int c, unsigned seen) __attribute__((always_inline)) {
+            const int need = lane == 1 ? c + 2 : c - 6;
+            const unsigned un = (unsigned)(need < 0 ? 0 : (need < NC ? need : NC));
+            if (__all(my_ptr == nullptr || seen >= un)) return;
+            persist_wait3(my_ptr, un, ctl.abort_flag); // not there yet: the bounded spin
+        };
         wait_deps(0);
         fetch(0, cA, xA);
         stash(cA, xA, 0);
@@ -161,24 +193,33 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
             wait_deps(1);
             fetch(1, cB, xB);
         }
+        unsigned seen = poll_issue();
         lds_barrier(); // chunk 0 is in buffer 0
+        P8S_DECL;
         for (int c = 0; c < NC; c += 2) {
             // ---- while chunk c (buffer 0) is relaxed ----
-            if (c + 1 < NC) stash(cB, xB, 1);
+            P8S_BEGIN;
             if (c + 2 < NC) {
-                wait_deps(c + 2);
+                poll_finish(c + 2, seen);
                 fetch(c + 2, cA, xA);
             }
+            if (c + 1 < NC) stash(cB, xB, 1);
+            seen = poll_issue();
+            P8S_END;
             lds_barrier();
             if (c + 1 >= NC) break;
             // ---- while chunk c+1 (buffer 1) is relaxed ----
-            if (c + 2 < NC) stash(cA, xA, 0);
+            P8S_BEGIN;
             if (c + 3 < NC) {
-                wait_deps(c + 3);
+                poll_finish(c + 3, seen);
                 fetch(c + 3, cB, xB);
             }
+            if (c + 2 < NC) stash(cA, xA, 0);
+            seen = poll_issue();
+            P8S_END;
             lds_barrier();
         }
+        P8S_WRITE;
         return;
     }
 
@@ -241,15 +282,22 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
             if (lane == 0) __hip_atomic_store(prog_mine, (unsigned)(c + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         lds_barrier(); // chunk 0 is in buffer 0
-        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: write chunk k-1 back
-            if (k >= 1) {
-                store_out(k - 1);
-                publish(k - 1);
-            }
+        // While chunk k is relaxed: publish chunk k-2 -- its stores have had a whole interval to drain, the wait costs nothing --
+        // then write chunk k-1 back.  (Publishing k-1 right behind its own stores put a write-through round trip, 2-3 us at 4K,
+        // into every interval of this wave, and that was the pace of the whole walk.  The counter only orders sweep t+1 behind
+        // sweep t: one chunk later there is harmless; the strip to the east does not wait for it at all.)
+        P8S_DECL;
+        for (int k = 0; k < NC; k++) {
+            P8S_BEGIN;
+            if (k >= 2) publish(k - 2);
+            if (k >= 1) store_out(k - 1);
+            P8S_END;
             lds_barrier();
         }
+        if (NC >= 2) publish(NC - 2);
         store_out(NC - 1);
         publish(NC - 1);
+        P8S_WRITE;
         return;
     }
 
@@ -288,10 +336,14 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
         };
         take(0);
         lds_barrier(); // chunk 0 is in buffer 0
+        P8S_DECL;
         for (int k = 0; k < NC; k++) { // while chunk k is relaxed: the west values of chunk k+1
+            P8S_BEGIN;
             take(k + 1);
+            P8S_END;
             lds_barrier();
         }
+        P8S_WRITE;
         return;
     }
 
@@ -305,7 +357,9 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
     const __amdgpu_buffer_rsrc_t rs_mail = __builtin_amdgcn_make_buffer_rsrc(mail_mine, 0, (unsigned)((size_t)NC * EX_CH * 8), 0x00020000);
     lds_barrier(); // chunk 0 is in buffer 0
 
+    P8S_DECL;
     for (int k = 0; k < NC; k++) {
+        P8S_BEGIN;
         const float *cst = smem + (k & 1) * L::BUF, *xst = cst + L::CST, *wed = xst + L::XST;
         float *outb = outb_base + (k & 1) * L::OUTB;
         const int i0 = row0(k) - P8_SKEW * lane; // my row at step 0 of this chunk
@@ -364,8 +418,10 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
             wv.y = 1u;
             __builtin_amdgcn_raw_buffer_store_b64(wv, rs_mail, (unsigned)((EX_CH * k + lane) * 8), 0, 16); // sc1
         }
+        P8S_END;
         lds_barrier();
     }
+    P8S_WRITE;
 }
 
 // One launch + the final border replicate.  Returns the number of launches, or -1 (message set).
