@@ -29,33 +29,39 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
     RC(ws_get(WS_AUX0, nf * sizeof(float), &bt));
     RC(ws_get(WS_AUX1, nf * sizeof(float), &inv));
     if (mode == PDEIP_MODE_EXACT_ORDER) {
-        hipLaunchKernelGGL(k_pde8_divisors, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, bt, inv, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, nrows, ncols, n);
-        g.last_launches++;
         Pde8Planes P{};
         P.x = X;
         const float *cf[ModelPde8::NCF] = {bt, inv, wW, wNW, wN, wNE, wE, wSE, wS, wSW};
         for (int f = 0; f < ModelPde8::NCF; f++) P.cf[f] = cf[f];
         RC(ws_get(WS_PING, pde8_exact_scratch_floats(nrows, ncols, nframes, iter) * sizeof(float), &scratch));
         // One launch per call (progress counters) or one per front?  PDEIP_PDE8_PERSIST = 0 keeps the launch-per-front form.
-        const int B = (ncols - 2 + 63) / 64;
+        const int nstrips = (ncols - 2 + 63) / 64;
         const bool persist = env_int("PDEIP_PDE8_PERSIST", 1) != 0;
-        if (persist && B <= 0xffff && iter <= 0x7fff && n * sizeof(float) < 0xffff0000ull) {
+        const size_t pack_frame_bytes = pde8_pack_floats(nrows, ncols, 1) * sizeof(float);
+        if (persist && nstrips <= 0xffff && iter <= 0x7fff && n * sizeof(float) < 0xffff0000ull && pack_frame_bytes < 0xffff0000ull && ncols <= 65535) {
+            // pre-pass: B_temp / INV_TRACE and the eight weights of a pixel side by side (k_pde8_pack)
+            float *pack = nullptr;
+            RC(ws_get(WS_PACK, pack_frame_bytes * nframes, &pack));
+            const int nbk = pde8_pack_blocks(nrows);
+            hipLaunchKernelGGL(k_pde8_pack, dim3((unsigned)((nbk + 127) / 128), (unsigned)ncols, (unsigned)nframes), dim3(128), 0, s, pack, TRACE, B, wW,
+                               wNW, wN, wNE, wE, wSE, wS, wSW, nrows, ncols, n);
+            g.last_launches++;
             float *ctl_f = nullptr, *order_f = nullptr;
-            const size_t nprog = (size_t)nframes * iter * B;
+            const size_t nprog = (size_t)nframes * iter * nstrips;
             RC(ws_get(WS_CTL, (4 + nprog) * sizeof(unsigned), &ctl_f));
-            RC(ws_get(WS_ORDER, (size_t)B * iter * sizeof(int), &order_f));
+            RC(ws_get(WS_ORDER, (size_t)nstrips * iter * sizeof(int), &order_f));
             DeviceState *dst = cur_dev(); // after the ws_get calls: a regrown WS_ORDER has dropped its cached shape
-            if (dst->order_B != B || dst->order_T != iter) { // (b,t) in an order where every dependency comes earlier (same table as pdeip_sor5.hip)
+            if (dst->order_B != nstrips || dst->order_T != iter) { // (b,t) in an order where every dependency comes earlier (same table as pdeip_sor5.hip)
                 std::vector<int> ord;
-                ord.reserve((size_t)B * iter);
-                for (int key = 0; key <= (B - 1) + 2 * (iter - 1); key++)
+                ord.reserve((size_t)nstrips * iter);
+                for (int key = 0; key <= (nstrips - 1) + 2 * (iter - 1); key++)
                     for (int t = 0; t < iter; t++) {
                         const int b = key - 2 * t;
-                        if (b >= 0 && b < B) ord.push_back(b | (t << 16));
+                        if (b >= 0 && b < nstrips) ord.push_back(b | (t << 16));
                     }
                 HIPCHK(hipMemcpyAsync(order_f, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, s));
                 HIPCHK(hipStreamSynchronize(s)); // `ord` is about to go out of scope
-                dst->order_B = B;
+                dst->order_B = nstrips;
                 dst->order_T = iter;
             }
             // word 0: abort (sticky, cleared by pdeip_persist_error()); word 1: ticket; words 4..: progress counters
@@ -73,13 +79,15 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
             ctl.order = reinterpret_cast<const int *>(order_f);
             dst->persist_used = true;
             SweepTimer timer(s);
-            const int nl = pde8_run_exact_persist(s, P, scratch, ctl, nrows, ncols, nframes, iter, omega);
+            const int nl = pde8_run_exact_persist(s, P, pack, scratch, ctl, nrows, ncols, nframes, iter, omega);
             if (nl < 0) return PDEIP_ERR_DEVICE;
             timer.stop(1);
             g.last_launches += nl;
             HIPCHK(hipGetLastError());
             return PDEIP_OK;
         }
+        hipLaunchKernelGGL(k_pde8_divisors, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, bt, inv, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, nrows, ncols, n);
+        g.last_launches++;
         SweepTimer timer(s);
         const int nl = pde8_run_exact(s, P, scratch, nrows, ncols, nframes, iter, omega);
         if (nl < 0) return PDEIP_ERR_DEVICE; // LDS opt-in refused (message set by ensure_lds)

@@ -50,10 +50,48 @@ __device__ unsigned long long g_p8_stamps[4096];
 
 constexpr int P8P_THREADS = 256; // compute, loader, storer, west-edge poller: one wave per SIMD
 
+// Packed coefficients.  The walk's pace is its loader, and the loader's cost is the number of cache lines its loads touch: ten
+// coefficient planes give a (column, chunk) ten 64-byte pieces in ten places.  The pre-pass that derives B_temp / INV_TRACE
+// (pdeSolvers.c:190-206) therefore writes all ten coefficients of a pixel side by side, in blocks of two rows:
+//   pack[col][pb][f][2]   pb = (row + 1) / 2, element (row + 1) & 1   (rows -1 and nrows.. are padding)
+// so the 16 rows a lane starts at row 16c - 1 - 2l (row + 1 even) are 640 contiguous, 16-byte aligned bytes.
+__host__ __device__ inline int pde8_pack_blocks(int nrows) { return (nrows + 2) / 2; }
+inline size_t pde8_pack_floats(int nrows, int ncols, int nframes) { return (size_t)pde8_pack_blocks(nrows) * ncols * 2 * ModelPde8::NCF * nframes; }
+
+static __global__ void k_pde8_pack(float *pack, const float *TRACE, const float *B, const float *wW, const float *wNW, const float *wN,
+                                   const float *wNE, const float *wE, const float *wSE, const float *wS, const float *wSW, int nrows,
+                                   int ncols, size_t frame_stride)
+{
+    constexpr int NCF = ModelPde8::NCF;
+    const int nb = pde8_pack_blocks(nrows);
+    const int pb = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (pb >= nb) return;
+    const size_t fo = (size_t)blockIdx.z * frame_stride;
+    float v[NCF][2];
+#pragma unroll
+    for (int r2 = 0; r2 < 2; r2++) {
+        const int row = 2 * pb + r2 - 1;
+        const bool in = row >= 0 && row < nrows;
+        const size_t p = fo + (size_t)col * nrows + (in ? row : 0);
+        const float tr = TRACE[p];
+        float t = wE[p] + wW[p];
+        t += wS[p] + wN[p];
+        t += wSW[p] + wNW[p];
+        t += wSE[p] + wNE[p];
+        const bool ok = !is_nan(tr);
+        const float c[NCF] = {ok ? B[p] : 0.0f, ok ? 1.0f / tr : 1.0f / t, wW[p], wNW[p], wN[p], wNE[p], wE[p], wSE[p], wS[p], wSW[p]};
+#pragma unroll
+        for (int f = 0; f < NCF; f++) v[f][r2] = in ? c[f] : 0.0f;
+    }
+    float4 *dst = reinterpret_cast<float4 *>(pack + (((size_t)blockIdx.z * ncols + col) * nb + pb) * (2 * NCF));
+#pragma unroll
+    for (int q = 0; q < NCF / 2; q++) dst[q] = make_float4(v[2 * q][0], v[2 * q][1], v[2 * q + 1][0], v[2 * q + 1][1]);
+}
+
 inline int pde8_persist_chunks(int nrows) { return (nrows + 127 + EX_CH - 1) / EX_CH; } // lane 63 reaches row nrows-1 (handed on to the east strip)
 
 __global__ void __launch_bounds__(P8P_THREADS)
-k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int ncols, int B, int T, int NC, int nframes, float omega,
+k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ctl, int nrows, int ncols, int B, int T, int NC, int nframes, float omega,
                      size_t frame_stride)
 {
     using L = Pde8Layout;
@@ -78,9 +116,10 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
     // every plane through a range-checked buffer descriptor (an access outside the plane reads 0 / writes nothing)
     const unsigned plane_bytes = (unsigned)((size_t)nrows * ncols * sizeof(float));
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(P.x + fo, 0, plane_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_cf[NCF];
-#pragma unroll
-    for (int f = 0; f < NCF; f++) rs_cf[f] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.cf[f]) + fo, 0, plane_bytes, 0x00020000);
+    const int nb = pde8_pack_blocks(nrows);
+    const unsigned pack_bytes = (unsigned)((size_t)ncols * nb * 2 * NCF * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rs_pack =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pack) + (size_t)frame * ncols * nb * 2 * NCF, 0, pack_bytes, 0x00020000);
     // border ring after sweep t-1 (read) and after sweep t (written): top[ncols] bot[ncols] left[nrows] right[nrows]
     const size_t sstride = pde8_side_stride(nrows, ncols);
     float *ring_w = side + ((size_t)frame * T + t) * sstride;
@@ -101,6 +140,12 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
     if (role == 1) {
         // ================================ loader wave ==========================================
         f4u cA[NCF][4], cB[NCF][4], xA[6], xB[6];
+        int soff[NCF]; // LDS float offset of float4 k of a column's run (column 0): plane f0, rows 2 blk, 2 blk + 1
+#pragma unroll
+        for (int k = 0; k < NCF; k++) {
+            const int e0 = 16 * k + 4 * lrq;
+            soff[k] = (((e0 % 20) >> 1) * 64) * EX_STR + 2 * (e0 / 20);
+        }
         const unsigned *my_ptr = lane == 1 ? prog_prev : (lane == 2 ? prog_east : nullptr); // the west strip: by mailbox (storer)
         auto wait_deps = [&](int c) __attribute__((always_inline)) {
             const int need = lane == 1 ? c + 2 : c - 6;
@@ -135,8 +180,10 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
                 const int col = 16 * g + lcol;
                 const int jj = ccol(jbase + col);
                 const int row = r0 - P8_SKEW * col + 4 * lrq;
+                // coefficients: the four lanes of a column read 64 contiguous bytes of its 640-byte run per instruction
+                const unsigned run = (unsigned)((((long)jj * nb + ((row - 4 * lrq + 1) >> 1)) * (2 * NCF)) * 4) + 16u * (unsigned)lrq;
 #pragma unroll
-                for (int f = 0; f < NCF; f++) as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_cf[f], boff(jj, row), 0, 0), cpre[f][g]);
+                for (int k = 0; k < NCF; k++) as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_pack, run + 64u * k, 0, 0), cpre[k][g]);
                 as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_x, boff(jj, row), 0, 16), xpre[g]);
             }
             const int row4 = r0 - P8_SKEW * lane + 16; // fifth quad (rows +16..+19) of every own column: lane -> column
@@ -164,8 +211,13 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const int col = 16 * g + lcol;
+                // float4 k of the run holds elements 16k + 4 lrq .. + 3 = coefficients f0, f0 + 1 of the two rows of block blk
 #pragma unroll
-                for (int f = 0; f < NCF; f++) put(&cst[(f * 64 + col) * EX_STR + 4 * lrq], cpre[f][g]);
+                for (int k = 0; k < NCF; k++) {
+                    float *d = &cst[soff[k] + col * EX_STR];
+                    *reinterpret_cast<float2 *>(d) = make_float2(cpre[k][g].v[0], cpre[k][g].v[1]);
+                    *reinterpret_cast<float2 *>(d + 64 * EX_STR) = make_float2(cpre[k][g].v[2], cpre[k][g].v[3]);
+                }
                 put(&xst[col * EX_STR + 4 * lrq], xpre[g]);
             }
             put(&xst[lane * EX_STR + 16], xpre[4]);
@@ -425,7 +477,7 @@ k_pde8_exact_persist(Pde8Planes P, float *side, PersistCtl ctl, int nrows, int n
 }
 
 // One launch + the final border replicate.  Returns the number of launches, or -1 (message set).
-inline int pde8_run_exact_persist(hipStream_t s, Pde8Planes P, float *side, PersistCtl ctl, int nrows, int ncols, int nframes, int iter,
+inline int pde8_run_exact_persist(hipStream_t s, Pde8Planes P, const float *pack, float *side, PersistCtl ctl, int nrows, int ncols, int nframes, int iter,
                                   float omega)
 {
     const size_t n = (size_t)nrows * ncols;
@@ -433,7 +485,7 @@ inline int pde8_run_exact_persist(hipStream_t s, Pde8Planes P, float *side, Pers
     const int NC = pde8_persist_chunks(nrows);
     constexpr size_t lds = Pde8Layout::LDS_BYTES + 16;
     if (ensure_lds(reinterpret_cast<const void *>(&k_pde8_exact_persist), lds) != PDEIP_OK) return -1;
-    hipLaunchKernelGGL(k_pde8_exact_persist, dim3((unsigned)(B * iter * nframes)), dim3(P8P_THREADS), lds, s, P, side, ctl, nrows, ncols, B, iter,
+    hipLaunchKernelGGL(k_pde8_exact_persist, dim3((unsigned)(B * iter * nframes)), dim3(P8P_THREADS), lds, s, P, pack, side, ctl, nrows, ncols, B, iter,
                        NC, nframes, omega, n);
     const int nb = 2 * ncols + 2 * (nrows - 2);
     hipLaunchKernelGGL(k_fill_borders, dim3((nb + 255) / 256, nframes, 1), dim3(256), 0, s, P.x, P.x, 1, nrows, ncols, n);
