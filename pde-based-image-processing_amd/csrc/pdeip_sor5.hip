@@ -114,10 +114,8 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     RC(ws_get(WS_AUX1, n * nframes * sizeof(float), &aux1));
 
     if (mode == PDEIP_MODE_EXACT_ORDER) {
-        hipLaunchKernelGGL(k_derive<Mdl>, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, P, aux0, aux1, nrows, ncols, n);
-        g.last_launches++;
-        P.cf[Mdl::D0] = aux0;
-        P.cf[Mdl::D1] = aux1;
+        const float *raw_cf[Mdl::NCF];
+        for (int f = 0; f < Mdl::NCF; f++) raw_cf[f] = P.cf[f];
         const int A = (nrows - 2 + 63 + EX_R - 1) / EX_R;
         const int B = (ncols - 2 + 63) / 64;
         const int last_m = (A - 1) + 2 * (B - 1) + 3 * (iter - 1);
@@ -127,7 +125,13 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         // way --, 1.4x at iter=20, 1.3x at 1080p, 2.4x at 34x60: no per-front launch, sweeps overlap more tightly).
         // PDEIP_EXACT_PERSIST = 0 falls back to one launch per front.
         const bool persist = env_int("PDEIP_EXACT_PERSIST", 1) != 0;
-        if (persist && B <= 0xffff && iter <= 0x7fff && n * sizeof(float) < 0xffffffffull) {
+        if (persist && B <= 0xffff && iter <= 0x7fff && n * Mdl::NCF * sizeof(float) < 0xffff0000ull && ncols <= 65535) {
+            // pre-pass of the persistent form: the derived planes AND the raw ones, packed per pixel (k_pack_coefficients)
+            float *pack = nullptr;
+            for (int f = 0; f < Mdl::NCF; f++) P.cf[f] = raw_cf[f];
+            RC(ws_get(WS_PACK, n * nframes * Mdl::NCF * sizeof(float), &pack));
+            hipLaunchKernelGGL(k_pack_coefficients<Mdl>, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, P, pack, nrows, ncols, n);
+            g.last_launches++;
             // ---- persistent form: one launch, progress counters instead of one launch per front ----
             const int NC = (nrows - 2 + 63 + EX_CH - 1) / EX_CH;
             float *ctl_f = nullptr, *order_f = nullptr;
@@ -166,7 +170,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_exact_persist<Mdl>), plds));
             dst->persist_used = true;
             SweepTimer timer(s);
-            hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(B * iter * nframes)), dim3(exp_threads<Mdl>()), plds, s, P, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
+            hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(B * iter * nframes)), dim3(exp_threads<Mdl>()), plds, s, P, pack, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
             timer.stop(1);
             g.last_launches++;
             const int nb = 2 * ncols + 2 * (nrows - 2);
@@ -176,6 +180,10 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             HIPCHK(hipGetLastError());
             return PDEIP_OK;
         }
+        hipLaunchKernelGGL(k_derive<Mdl>, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, P, aux0, aux1, nrows, ncols, n);
+        g.last_launches++;
+        P.cf[Mdl::D0] = aux0;
+        P.cf[Mdl::D1] = aux1;
         const dim3 grid((unsigned)(B * iter), (unsigned)nframes);
         constexpr size_t lds = ExactLayout<Mdl>::LDS_BYTES;
         RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_exact<Mdl>), lds)); // > 64 KiB of dynamic LDS needs an explicit opt-in

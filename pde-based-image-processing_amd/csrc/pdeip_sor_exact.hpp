@@ -422,6 +422,36 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
 // every dependency has a smaller ticket, so whatever the dispatch order a running workgroup only ever
 // waits for workgroups that are running or finished.  Every spin is bounded; a timeout raises the
 // abort word, after which all waits fall through and the grid drains (the host reports the error).
+// Packed coefficients (persistent form).  The walk's pace is its loader, and the loader's cost is the cache lines its loads
+// touch: NCF coefficient planes give a (column, chunk) NCF 64-byte pieces in NCF places.  The pre-pass that
+// derives the divisor planes (k_derive's job) therefore writes all NCF coefficients of a pixel side by side,
+//   pack[col][row][NCF],
+// so the 16 rows of a column's chunk are NCF*64 contiguous bytes (4-byte aligned: the lanes are skewed by one row).  The chunk's
+// LDS image is that run as it lies in memory, one run per column: 16-byte granule q of column c at granule
+// c * CS + (q ^ ((c >> 2) & 3)), CS = 4 NCF rounded up to an odd multiple of 4 -- the loader's four lanes of a column write 64
+// contiguous bytes, the compute lanes (one column each) read granule q of 16 columns from 16 different bank groups.
+template <class Mdl> struct PackLayout {
+    static constexpr int NCF = Mdl::NCF;
+    static constexpr int RUN = 4 * NCF;                            // granules per column and chunk
+    static constexpr int CS = (RUN % 8 == 4) ? RUN : RUN + 4;      // column stride in granules: 4 x odd
+    static_assert(64 * CS * 4 <= NCF * 64 * EX_STR, "the packed image fits the coefficient planes' LDS region");
+};
+template <class Mdl>
+__global__ void k_pack_coefficients(SweepPlanes<Mdl> P, float *pack, int nrows, int ncols, size_t frame_stride)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i >= nrows) return;
+    const size_t pos = (size_t)j * nrows + i;
+    const size_t q = pos + (size_t)blockIdx.z * frame_stride;
+    float k[Mdl::NCF];
+#pragma unroll
+    for (int f = 0; f < Mdl::NCF; f++) k[f] = P.cf[f][q];
+    Mdl::derive(k);
+    float *dst = pack + q * Mdl::NCF;
+#pragma unroll
+    for (int f = 0; f < Mdl::NCF; f++) dst[f] = k[f];
+}
+
 struct PersistCtl {
     unsigned *ticket;    // [1]
     unsigned *abort_flag; // [1]
@@ -458,7 +488,7 @@ template <class Mdl> constexpr int exp_threads() { return Mdl::NIT == 2 ? 256 : 
 
 template <class Mdl>
 __global__ void __launch_bounds__((exp_threads<Mdl>()))
-k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, int B, int T, int NC, int nframes,
+k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int ncols, int B, int T, int NC, int nframes,
                     float omega, size_t frame_stride)
 {
     using L = ExactLayout<Mdl>;
@@ -498,8 +528,10 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
     for (int f = 0; f < NIT; f++) rs[f] = __builtin_amdgcn_make_buffer_rsrc(P.it_out[f] + fo, 0, plane_bytes, 0x00020000);
 #pragma unroll
     for (int f = 0; f < NRO; f++) rs[NIT + f] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.ro[f]) + fo, 0, plane_bytes, 0x00020000);
-#pragma unroll
-    for (int f = 0; f < NCF; f++) rs[NF + f] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.cf[f]) + fo, 0, plane_bytes, 0x00020000);
+    // the coefficients: packed per pixel (see PackLayout); rs[NF..] stay unused here
+    using PL = PackLayout<Mdl>;
+    const __amdgpu_buffer_rsrc_t rs_pack =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pack) + fo * NCF, 0, (unsigned)((size_t)nrows * ncols * NCF * sizeof(float)), 0x00020000);
 
     const int jbase = 1 + 64 * b;
     auto crow = [&](int i) { return i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i); };
@@ -523,17 +555,27 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
         auto fetch = [&](int c, f4u (&pre)[NP][4], f4u (&epre)[NF]) __attribute__((always_inline)) {
             const int i00 = 1 + EX_CH * c;
 #pragma unroll
-            for (int p = 0; p < NP; p++) {
+            for (int p = 0; p < NF; p++) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int col = 16 * g + lcol;
                     int jj = jbase + col;
                     jj = jj < ncols - 1 ? jj : ncols - 1;
-                    const int row = i00 - col + (p < NF ? 1 : 0) + 4 * lrq;
+                    const int row = i00 - col + 1 + 4 * lrq;
                     const v4u_t v = (p < NIT) ? __builtin_amdgcn_raw_buffer_load_b128(rs[p], boff(jj, row), 0, 16)
                                               : __builtin_amdgcn_raw_buffer_load_b128(rs[p], boff(jj, row), 0, 0);
                     as_f4u(v, pre[p][g]);
                 }
+            }
+            // coefficients: the column's run of 16 rows x NCF floats, the four lanes of a column 64 contiguous bytes per instruction
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = 16 * g + lcol;
+                int jj = jbase + col;
+                jj = jj < ncols - 1 ? jj : ncols - 1;
+                const unsigned run = (unsigned)((((long)jj * nrows + (i00 - col)) * NCF) * 4) + 16u * (unsigned)lrq;
+#pragma unroll
+                for (int k = 0; k < NCF; k++) as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_pack, run + 64u * k, 0, 0), pre[NF + k][g]);
             }
             // edge columns: east (old values) of every field; west of the read-only fields, and of the iterate fields only for
             // the first strip (the frame's border column) -- a later strip's west iterate column is the mailbox's (role 4)
@@ -552,13 +594,24 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
         auto stash = [&](const f4u (&pre)[NP][4], const f4u (&epre)[NF], int buf) __attribute__((always_inline)) {
             float *stage = smem + buf * L::BUF, *edge = stage + L::STAGE;
 #pragma unroll
-            for (int p = 0; p < NP; p++)
+            for (int p = 0; p < NF; p++)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const int col = 16 * g + lcol;
                     *reinterpret_cast<float4 *>(&stage[(p * 64 + col) * EX_STR + 4 * lrq]) =
                         make_float4(pre[p][g].v[0], pre[p][g].v[1], pre[p][g].v[2], pre[p][g].v[3]);
                 }
+            {
+                float4 *cimg = reinterpret_cast<float4 *>(stage + NF * 64 * EX_STR); // the packed image (PackLayout)
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int col = 16 * g + lcol;
+#pragma unroll
+                    for (int k = 0; k < NCF; k++)
+                        cimg[col * PL::CS + ((4 * k + lrq) ^ ((col >> 2) & 3))] =
+                            make_float4(pre[NF + k][g].v[0], pre[NF + k][g].v[1], pre[NF + k][g].v[2], pre[NF + k][g].v[3]);
+                }
+            }
             if (lane < 8) {
                 const int which = (lane >> 2) & 1;
 #pragma unroll
@@ -750,9 +803,16 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
         constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
         for (int mq = 0; mq < EX_CH / 4; mq++) {
-            float4 ck[NCF], s4[NF], e4[NF], res[NIT];
+            float4 s4[NF], e4[NF], res[NIT];
+            float cflat[4 * NCF]; // coefficients of the four rows of this group, [row][f]: granules NCF mq .. NCF mq + NCF - 1 of my run
+            {
+                const float4 *cimg = reinterpret_cast<const float4 *>(stage + NF * 64 * EX_STR) + lane * PL::CS;
 #pragma unroll
-            for (int f = 0; f < NCF; f++) ck[f] = *reinterpret_cast<const float4 *>(&stage[((NF + f) * 64 + lane) * EX_STR + 4 * mq]);
+                for (int jq = 0; jq < NCF; jq++) {
+                    const float4 v = cimg[(NCF * mq + jq) ^ ((lane >> 2) & 3)];
+                    cflat[4 * jq] = v.x; cflat[4 * jq + 1] = v.y; cflat[4 * jq + 2] = v.z; cflat[4 * jq + 3] = v.w;
+                }
+            }
 #pragma unroll
             for (int f = 0; f < NF; f++) {
                 s4[f] = *reinterpret_cast<const float4 *>(&stage[(f * 64 + lane) * EX_STR + 4 * mq]);
@@ -797,7 +857,7 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, PersistCtl ctl, int nrows, int ncols, in
                     }
                 }
 #pragma unroll
-                for (int f = 0; f < NCF; f++) kk[f] = el(ck[f]);
+                for (int f = 0; f < NCF; f++) kk[f] = cflat[NCF * x + f];
                 Mdl::update(c, w, e, n, s, rcen, rwest, reast, rnorth, rsouth, kk, omega, om1);
 #pragma unroll
                 for (int f = F0; f < F0 + NFW; f++) {
