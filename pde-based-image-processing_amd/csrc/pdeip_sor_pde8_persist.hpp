@@ -137,9 +137,14 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
         o.v[0] = __uint_as_float(v.x); o.v[1] = __uint_as_float(v.y); o.v[2] = __uint_as_float(v.z); o.v[3] = __uint_as_float(v.w);
     };
 
-    if (role == 1) {
-        // ================================ loader wave ==========================================
-        f4u cA[NCF][4], cB[NCF][4], xA[6], xB[6];
+    if (role == 1 || role == 3) {
+        // ============================ loader wave, west-edge wave ==============================
+        // The loader's pace is the walk's pace, so the wave that only polls the mailbox takes half of the coefficient loads: the
+        // loader stages columns 0-31 of the packed coefficients and everything of the iterate, the west-edge wave columns 32-63
+        // (its mailbox polls queue behind its loads -- vmcnt counts in order -- which costs the hand-off less than it saves).
+        const int gc0 = (role == 1) ? 0 : 2;
+        const bool xs = (role == 1);
+        f4u cA[NCF][2], cB[NCF][2], xA[6], xB[6];
         int soff[NCF]; // LDS float offset of float4 k of a column's run (column 0): plane f0, rows 2 blk, 2 blk + 1
 #pragma unroll
         for (int k = 0; k < NCF; k++) {
@@ -170,8 +175,18 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
                 if (ii >= 0 && ii <= nrows - 1 && (colb || ii == 0 || ii == nrows - 1)) v.v[e] = ring_cell(ii, jj);
             }
         };
-        auto fetch = [&](int c, f4u (&cpre)[NCF][4], f4u (&xpre)[6]) __attribute__((always_inline)) {
+        auto fetch = [&](int c, f4u (&cpre)[NCF][2], f4u (&xpre)[6]) __attribute__((always_inline)) {
             const int r0 = row0(c);
+#pragma unroll
+            for (int gg = 0; gg < 2; gg++) {
+                const int col = 16 * (gc0 + gg) + lcol;
+                const int jj = ccol(jbase + col);
+                // coefficients: the four lanes of a column read 64 contiguous bytes of its 640-byte run per instruction
+                const unsigned run = (unsigned)((((long)jj * nb + ((r0 - P8_SKEW * col + 1) >> 1)) * (2 * NCF)) * 4) + 16u * (unsigned)lrq;
+#pragma unroll
+                for (int k = 0; k < NCF; k++) as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_pack, run + 64u * k, 0, 0), cpre[k][gg]);
+            }
+            if (!xs) return;
             // does a staged window hold border cells of sweep t-1's ring?  rows r0-128 .. r0+19, columns jbase-1 .. jbase+64
             const bool ringed = (t > 0) && ((r0 - 128 <= 0 && r0 + 19 >= 0) || (r0 - 128 <= nrows - 1 && r0 + 19 >= nrows - 1) ||
                                             jbase - 1 == 0 || jbase + 64 >= ncols - 1);
@@ -180,10 +195,6 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
                 const int col = 16 * g + lcol;
                 const int jj = ccol(jbase + col);
                 const int row = r0 - P8_SKEW * col + 4 * lrq;
-                // coefficients: the four lanes of a column read 64 contiguous bytes of its 640-byte run per instruction
-                const unsigned run = (unsigned)((((long)jj * nb + ((row - 4 * lrq + 1) >> 1)) * (2 * NCF)) * 4) + 16u * (unsigned)lrq;
-#pragma unroll
-                for (int k = 0; k < NCF; k++) as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_pack, run + 64u * k, 0, 0), cpre[k][g]);
                 as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_x, boff(jj, row), 0, 16), xpre[g]);
             }
             const int row4 = r0 - P8_SKEW * lane + 16; // fifth quad (rows +16..+19) of every own column: lane -> column
@@ -205,21 +216,23 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
                 patch(xpre[5], erow, ej);
             }
         };
-        auto stash = [&](const f4u (&cpre)[NCF][4], const f4u (&xpre)[6], int buf) __attribute__((always_inline)) {
+        auto stash = [&](const f4u (&cpre)[NCF][2], const f4u (&xpre)[6], int buf) __attribute__((always_inline)) {
             float *cst = smem + buf * L::BUF, *xst = cst + L::CST, *wed = xst + L::XST;
             auto put = [&](float *dst, const f4u &v) { *reinterpret_cast<float4 *>(dst) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]); };
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int col = 16 * g + lcol;
+            for (int gg = 0; gg < 2; gg++) {
+                const int col = 16 * (gc0 + gg) + lcol;
                 // float4 k of the run holds elements 16k + 4 lrq .. + 3 = coefficients f0, f0 + 1 of the two rows of block blk
 #pragma unroll
                 for (int k = 0; k < NCF; k++) {
                     float *d = &cst[soff[k] + col * EX_STR];
-                    *reinterpret_cast<float2 *>(d) = make_float2(cpre[k][g].v[0], cpre[k][g].v[1]);
-                    *reinterpret_cast<float2 *>(d + 64 * EX_STR) = make_float2(cpre[k][g].v[2], cpre[k][g].v[3]);
+                    *reinterpret_cast<float2 *>(d) = make_float2(cpre[k][gg].v[0], cpre[k][gg].v[1]);
+                    *reinterpret_cast<float2 *>(d + 64 * EX_STR) = make_float2(cpre[k][gg].v[2], cpre[k][gg].v[3]);
                 }
-                put(&xst[col * EX_STR + 4 * lrq], xpre[g]);
             }
+            if (!xs) return;
+#pragma unroll
+            for (int g = 0; g < 4; g++) put(&xst[(16 * g + lcol) * EX_STR + 4 * lrq], xpre[g]);
             put(&xst[lane * EX_STR + 16], xpre[4]);
             if (lane < 5) put(&xst[64 * EX_STR + 4 * lane], xpre[5]);
             else if (lane < 10 && b == 0) put(&wed[4 * (lane - 5)], xpre[5]); // a later strip's west column: the mailbox
@@ -238,6 +251,37 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
             if (__all(my_ptr == nullptr || seen >= un)) return;
             persist_wait3(my_ptr, un, ctl.abort_flag); // not there yet: the bounded spin
         };
+        // West edge of chunk c: lane r polls the west strip's mailbox word of row 16c - 2 + r (r < 18) until its tag is set and puts
+        // the value into the chunk's LDS edge slot.  Not the storer's job: behind its write-through stores a poll would wait for
+        // their drain first, a round trip in every interval.
+        const size_t mpitch = (size_t)NC * EX_CH;
+        const unsigned long long *mail_w = ctl.mail + (((size_t)frame * T + t) * B + (b > 0 ? b - 1 : 0)) * mpitch;
+        auto take = [&](int c) __attribute__((always_inline)) {
+            if (b > 0 && c < NC) {
+                const int row = row0(c) - 1 + lane;
+                const bool want = lane < 18 && row >= 0 && row <= nrows - 1;
+                float v = 0.0f;
+                bool ok = !want;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+                for (;;) {
+                    if (!ok) {
+                        const unsigned long long wd = __hip_atomic_load(mail_w + row + 127, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(wd >> 32) != 0u) {
+                            v = __uint_as_float((unsigned)wd);
+                            ok = true;
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if (__hip_atomic_load(ctl.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) { // 0.5 s: drain the grid, the host reports it
+                        __hip_atomic_store(ctl.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (lane < 18) (smem + (c & 1) * L::BUF + L::CST + L::XST)[lane] = v;
+            }
+        };
         wait_deps(0);
         fetch(0, cA, xA);
         stash(cA, xA, 0);
@@ -245,6 +289,7 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
             wait_deps(1);
             fetch(1, cB, xB);
         }
+        if (!xs) take(0);
         unsigned seen = poll_issue();
         lds_barrier(); // chunk 0 is in buffer 0
         P8S_DECL;
@@ -256,6 +301,7 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
                 fetch(c + 2, cA, xA);
             }
             if (c + 1 < NC) stash(cB, xB, 1);
+            if (!xs) take(c + 1);
             seen = poll_issue();
             P8S_END;
             lds_barrier();
@@ -267,6 +313,7 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
                 fetch(c + 3, cB, xB);
             }
             if (c + 2 < NC) stash(cA, xA, 0);
+            if (!xs) take(c + 2);
             seen = poll_issue();
             P8S_END;
             lds_barrier();
@@ -349,52 +396,6 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
         if (NC >= 2) publish(NC - 2);
         store_out(NC - 1);
         publish(NC - 1);
-        P8S_WRITE;
-        return;
-    }
-
-    if (role == 3) {
-        // ================================ west-edge wave =======================================
-        // West edge of chunk c: lane r polls the west strip's mailbox word of row 16c - 2 + r (r < 18) until its tag is set and
-        // puts the value into the chunk's LDS edge slot.  A wave of its own: behind the storer's write-through stores a poll
-        // would wait for their drain first (vmcnt counts in order), and that round trip would be every chunk's.
-        const size_t mpitch = (size_t)NC * EX_CH;
-        const unsigned long long *mail_w = ctl.mail + (((size_t)frame * T + t) * B + (b > 0 ? b - 1 : 0)) * mpitch;
-        auto take = [&](int c) __attribute__((always_inline)) {
-            if (b > 0 && c < NC) {
-                const int row = row0(c) - 1 + lane;
-                const bool want = lane < 18 && row >= 0 && row <= nrows - 1;
-                float v = 0.0f;
-                bool ok = !want;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
-                for (;;) {
-                    if (!ok) {
-                        const unsigned long long wd = __hip_atomic_load(mail_w + row + 127, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((unsigned)(wd >> 32) != 0u) {
-                            v = __uint_as_float((unsigned)wd);
-                            ok = true;
-                        }
-                    }
-                    if (__all(ok)) break;
-                    if (__hip_atomic_load(ctl.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) { // 0.5 s: drain the grid, the host reports it
-                        __hip_atomic_store(ctl.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (lane < 18) (smem + (c & 1) * L::BUF + L::CST + L::XST)[lane] = v;
-            }
-        };
-        take(0);
-        lds_barrier(); // chunk 0 is in buffer 0
-        P8S_DECL;
-        for (int k = 0; k < NC; k++) { // while chunk k is relaxed: the west values of chunk k+1
-            P8S_BEGIN;
-            take(k + 1);
-            P8S_END;
-            lds_barrier();
-        }
         P8S_WRITE;
         return;
     }
