@@ -88,6 +88,12 @@ static __global__ void k_pde8_pack(float *pack, const float *TRACE, const float 
     for (int q = 0; q < NCF / 2; q++) dst[q] = make_float4(v[2 * q][0], v[2 * q][1], v[2 * q + 1][0], v[2 * q + 1][1]);
 }
 
+// LDS image of a chunk's coefficients: the packed run of every column as it lies in memory, 40 granules of 16 bytes; granule q of
+// column c at granule c * P8_CS + (q ^ ((c >> 2) & 3)) (pdeip_sor_exact.hpp, PackLayout: 16 compute lanes read granule q of 16
+// columns from 16 different bank groups).
+constexpr int P8_RUN = 40, P8_CS = 44;
+static_assert(64 * P8_CS * 4 <= Pde8Layout::CST, "the packed image fits the coefficient region");
+
 inline int pde8_persist_chunks(int nrows) { return (nrows + 127 + EX_CH - 1) / EX_CH; } // lane 63 reaches row nrows-1 (handed on to the east strip)
 
 __global__ void __launch_bounds__(P8P_THREADS)
@@ -144,13 +150,8 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
         // (its mailbox polls queue behind its loads -- vmcnt counts in order -- which costs the hand-off less than it saves).
         const int gc0 = (role == 1) ? 0 : 2;
         const bool xs = (role == 1);
-        f4u cA[NCF][2], cB[NCF][2], xA[6], xB[6];
-        int soff[NCF]; // LDS float offset of float4 k of a column's run (column 0): plane f0, rows 2 blk, 2 blk + 1
-#pragma unroll
-        for (int k = 0; k < NCF; k++) {
-            const int e0 = 16 * k + 4 * lrq;
-            soff[k] = (((e0 % 20) >> 1) * 64) * EX_STR + 2 * (e0 / 20);
-        }
+        f4u cA[5][4], cB[5][4], xA[6], xB[6];
+        const int l8 = lane >> 3, part = lane & 7; // coefficient loads: eight lanes to a column, 128 contiguous bytes per instruction
         const unsigned *my_ptr = lane == 1 ? prog_prev : (lane == 2 ? prog_east : nullptr); // the west strip: by mailbox (storer)
         auto wait_deps = [&](int c) __attribute__((always_inline)) {
             const int need = lane == 1 ? c + 2 : c - 6;
@@ -175,16 +176,16 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
                 if (ii >= 0 && ii <= nrows - 1 && (colb || ii == 0 || ii == nrows - 1)) v.v[e] = ring_cell(ii, jj);
             }
         };
-        auto fetch = [&](int c, f4u (&cpre)[NCF][2], f4u (&xpre)[6]) __attribute__((always_inline)) {
+        auto fetch = [&](int c, f4u (&cpre)[5][4], f4u (&xpre)[6]) __attribute__((always_inline)) {
             const int r0 = row0(c);
 #pragma unroll
-            for (int gg = 0; gg < 2; gg++) {
-                const int col = 16 * (gc0 + gg) + lcol;
+            for (int gg = 0; gg < 4; gg++) {
+                const int col = 8 * (2 * gc0 + gg) + l8;
                 const int jj = ccol(jbase + col);
-                // coefficients: the four lanes of a column read 64 contiguous bytes of its 640-byte run per instruction
-                const unsigned run = (unsigned)((((long)jj * nb + ((r0 - P8_SKEW * col + 1) >> 1)) * (2 * NCF)) * 4) + 16u * (unsigned)lrq;
+                // coefficients: the eight lanes of a column read 128 contiguous bytes of its 640-byte run per instruction
+                const unsigned run = (unsigned)((((long)jj * nb + ((r0 - P8_SKEW * col + 1) >> 1)) * (2 * NCF)) * 4) + 16u * (unsigned)part;
 #pragma unroll
-                for (int k = 0; k < NCF; k++) as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_pack, run + 64u * k, 0, 0), cpre[k][gg]);
+                for (int k = 0; k < 5; k++) as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_pack, run + 128u * k, 0, 0), cpre[k][gg]);
             }
             if (!xs) return;
             // does a staged window hold border cells of sweep t-1's ring?  rows r0-128 .. r0+19, columns jbase-1 .. jbase+64
@@ -216,19 +217,17 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
                 patch(xpre[5], erow, ej);
             }
         };
-        auto stash = [&](const f4u (&cpre)[NCF][2], const f4u (&xpre)[6], int buf) __attribute__((always_inline)) {
+        auto stash = [&](const f4u (&cpre)[5][4], const f4u (&xpre)[6], int buf) __attribute__((always_inline)) {
             float *cst = smem + buf * L::BUF, *xst = cst + L::CST, *wed = xst + L::XST;
             auto put = [&](float *dst, const f4u &v) { *reinterpret_cast<float4 *>(dst) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]); };
+            float4 *cimg = reinterpret_cast<float4 *>(cst);
 #pragma unroll
-            for (int gg = 0; gg < 2; gg++) {
-                const int col = 16 * (gc0 + gg) + lcol;
-                // float4 k of the run holds elements 16k + 4 lrq .. + 3 = coefficients f0, f0 + 1 of the two rows of block blk
+            for (int gg = 0; gg < 4; gg++) {
+                const int col = 8 * (2 * gc0 + gg) + l8;
 #pragma unroll
-                for (int k = 0; k < NCF; k++) {
-                    float *d = &cst[soff[k] + col * EX_STR];
-                    *reinterpret_cast<float2 *>(d) = make_float2(cpre[k][gg].v[0], cpre[k][gg].v[1]);
-                    *reinterpret_cast<float2 *>(d + 64 * EX_STR) = make_float2(cpre[k][gg].v[2], cpre[k][gg].v[3]);
-                }
+                for (int k = 0; k < 5; k++)
+                    cimg[col * P8_CS + ((8 * k + part) ^ ((col >> 2) & 3))] =
+                        make_float4(cpre[k][gg].v[0], cpre[k][gg].v[1], cpre[k][gg].v[2], cpre[k][gg].v[3]);
             }
             if (!xs) return;
 #pragma unroll
@@ -420,10 +419,18 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
             constexpr bool INTERIOR = decltype(interior_tag)::value;
 #pragma unroll
             for (int mq = 0; mq < EX_CH / 4; mq++) {
-                float4 ck[NCF], res;
+                float4 res;
                 float xo[8], xe[8], we[8];
+                // granules 10 mq .. 10 mq + 9 of my run: two blocks of two rows, granule jq = coefficients 2 (jq % 5), + 1 of block jq / 5
+                float cflat[40];
+                {
+                    const float4 *cimg = reinterpret_cast<const float4 *>(cst) + lane * P8_CS;
 #pragma unroll
-                for (int f = 0; f < NCF; f++) ck[f] = *reinterpret_cast<const float4 *>(&cst[(f * 64 + lane) * EX_STR + 4 * mq]);
+                    for (int jq = 0; jq < 10; jq++) {
+                        const float4 v = cimg[(10 * mq + jq) ^ ((lane >> 2) & 3)];
+                        cflat[4 * jq] = v.x; cflat[4 * jq + 1] = v.y; cflat[4 * jq + 2] = v.z; cflat[4 * jq + 3] = v.w;
+                    }
+                }
                 {
                     const float4 a0 = *reinterpret_cast<const float4 *>(&xst[lane * EX_STR + 4 * mq]);
                     const float4 a1 = *reinterpret_cast<const float4 *>(&xst[lane * EX_STR + 4 * mq + 4]);
@@ -439,12 +446,11 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
                 for (int xq = 0; xq < 4; xq++) {
                     const int i = i0 + 4 * mq + xq;
                     const bool active = INTERIOR || (col_ok && (i >= 1) && (i <= nrows - 2));
-                    auto el = [&](const float4 &v) { return xq == 0 ? v.x : (xq == 1 ? v.y : (xq == 2 ? v.z : v.w)); };
                     // south-west (new): lane l-1 relaxed (i+1, j-1) one step ago; lane 0 reads the west edge column
                     const float sw = dpp_from_lower_lane(prev, we[xq + 2]);
                     float kk[NCF];
 #pragma unroll
-                    for (int f = 0; f < NCF; f++) kk[f] = el(ck[f]);
+                    for (int f = 0; f < NCF; f++) kk[f] = cflat[(5 * (xq >> 1) + (f >> 1)) * 4 + 2 * (f & 1) + (xq & 1)];
                     // update(xc, xW, xE, xN, xS, xNW, xNE, xSW, xSE)
                     const float v = ModelPde8::update(xo[xq], w, xe[xq + 2], prev, xo[xq + 1], nw, xe[xq + 1], sw, xe[xq + 3], kk, omega, om1);
                     prev = active ? v : xo[xq]; // a cell that is not relaxed hands its value on: border rows feed the taps of rows 1 / nrows-2
