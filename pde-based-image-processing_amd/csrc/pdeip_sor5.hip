@@ -364,6 +364,14 @@ extern "C" int pdeip_debug_read_rbp_stamps(unsigned long long *out)
     return PDEIP_OK;
 }
 #endif
+#ifdef PDEIP_P8_STAMPS
+extern "C" int pdeip_debug_read_walk_stamps(unsigned long long *out)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p8_stamps), 4096 * sizeof(unsigned long long)));
+    return PDEIP_OK;
+}
+#endif
 #ifdef PDEIP_EXACT_STAMPS
 extern "C" int pdeip_debug_read_stamps(unsigned long long *out)
 {

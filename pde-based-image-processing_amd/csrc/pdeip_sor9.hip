@@ -161,7 +161,6 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
     return PDEIP_OK;
 }
 
-
 #ifdef PDEIP_P8_STAMPS
 extern "C" int pdeip_debug_read_p8_stamps(unsigned long long *out)
 {

@@ -422,6 +422,25 @@ k_sor_exact(SweepPlanes<Mdl> P, int nrows, int ncols, int A, int B, int T, int m
 // every dependency has a smaller ticket, so whatever the dispatch order a running workgroup only ever
 // waits for workgroups that are running or finished.  Every spin is bounded; a timeout raises the
 // abort word, after which all waits fall through and the grid drains (the host reports the error).
+#ifdef PDEIP_P8_STAMPS // diagnostic build only (tools/p8_stamps.py, tools/walk_stamps.py): how long each wave of a walker works per interval; never in the product
+static __device__ unsigned long long g_p8_stamps[4096]; // one copy per translation unit (5-point / 9-point), each with its reader
+#define P8S_DECL unsigned long long s_busy_ = 0, s_i0_ = 0; const unsigned long long s_t0_ = __builtin_amdgcn_s_memtime(), s_r0_ = __builtin_amdgcn_s_memrealtime()
+#define P8S_BEGIN s_i0_ = __builtin_amdgcn_s_memtime()
+#define P8S_END s_busy_ += __builtin_amdgcn_s_memtime() - s_i0_
+#define P8S_WRITE                                                                                                                  \
+    if (lane == 0 && tk < 256) {                                                                                                  \
+        g_p8_stamps[(tk * 4 + role) * 4 + 0] = s_busy_;                                                                            \
+        g_p8_stamps[(tk * 4 + role) * 4 + 1] = __builtin_amdgcn_s_memtime() - s_t0_;                                              \
+        g_p8_stamps[(tk * 4 + role) * 4 + 2] = __builtin_amdgcn_s_memrealtime() - s_r0_;                                          \
+        g_p8_stamps[(tk * 4 + role) * 4 + 3] = (unsigned long long)(b | (t << 16));                                               \
+    }
+#else
+#define P8S_DECL
+#define P8S_BEGIN
+#define P8S_END
+#define P8S_WRITE
+#endif
+
 // Packed coefficients (persistent form).  The walk's pace is its loader, and the loader's cost is the cache lines its loads
 // touch: NCF coefficient planes give a (column, chunk) NCF 64-byte pieces in NCF places.  The pre-pass that
 // derives the divisor planes (k_derive's job) therefore writes all NCF coefficients of a pixel side by side,
@@ -516,7 +535,6 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
     const int b = packed & 0xffff, t = packed >> 16;
     const size_t fo = (size_t)frame * frame_stride;
     unsigned *prog_mine = ctl.progress + ((size_t)frame * T + t) * B + b;
-    const unsigned *prog_west = (b > 0) ? prog_mine - 1 : nullptr;
     const unsigned *prog_prev = (t > 0) ? prog_mine - B : nullptr;
     const unsigned *prog_east = (t > 0 && b + 1 < B) ? prog_mine - B + 1 : nullptr;
 
@@ -645,8 +663,10 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
             else fetch(1, preA, epreA);
         }
         lds_barrier(); // chunk 0 is in buffer 0
+        P8S_DECL;
         for (int c = 0; c < NC; c += 2) {
             // ---- while chunk c (buffer 0) is relaxed ----
+            P8S_BEGIN;
             {
                 const bool pf = c + 2 < NC;
                 const unsigned seen = pf ? poll_issue() : 0u;
@@ -656,9 +676,11 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
                 }
                 if (pf) { poll_finish(c + 2, seen); fetch(c + 2, preA, epreA); }
             }
+            P8S_END;
             lds_barrier();
             if (c + 1 >= NC) break;
             // ---- while chunk c+1 (buffer 1) is relaxed ----
+            P8S_BEGIN;
             {
                 const bool pf = c + 3 < NC;
                 const unsigned seen = pf ? poll_issue() : 0u;
@@ -669,8 +691,10 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
                     else fetch(c + 3, preA, epreA);
                 }
             }
+            P8S_END;
             lds_barrier();
         }
+        P8S_WRITE;
         return;
     }
 
@@ -749,13 +773,17 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
         };
         take(0, -1);
         lds_barrier(); // chunk 0 is in buffer 0
+        P8S_DECL;
         for (int k = 0; k < NC; k++) { // while chunk k is relaxed: write chunk k-1 back, fetch the west values of chunk k+1
+            P8S_BEGIN;
             if (k >= 1) store_out(k - 1);
             take(k + 1, k >= 1 ? k - 1 : -1);
+            P8S_END;
             lds_barrier();
         }
         store_out(NC - 1);
         publish(NC - 1);
+        P8S_WRITE;
         return;
     }
 
@@ -795,7 +823,9 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
         rnorth[f] = (NRO > 0) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs[(NRO > 0 ? NIT + f : 0)], boff(jc, crow(i0 - 1)), 0, 0)) : 0.0f;
     }
 
+    P8S_DECL;
     for (int k = 0; k < NC; k++) {
+        P8S_BEGIN;
         const float *stage = smem + (k & 1) * L::BUF, *edge = stage + L::STAGE;
         float *outb = outb_base + (k & 1) * L::OUTB;
         const int i00 = 1 + EX_CH * k;
@@ -899,8 +929,11 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
                 }
             }
         }
+        P8S_END;
         lds_barrier();
-    }    };
+    }
+    P8S_WRITE;
+    };
     if constexpr (NIT == 2) {
         if (role == 0) compute_wave(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
         else compute_wave(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});

@@ -29,25 +29,6 @@
 
 namespace pdeip {
 
-#ifdef PDEIP_P8_STAMPS // diagnostic build only (tools/p8_stamps.py): how long each wave of a walker works per interval; never in the product
-__device__ unsigned long long g_p8_stamps[4096];
-#define P8S_DECL unsigned long long s_busy_ = 0, s_i0_ = 0; const unsigned long long s_t0_ = __builtin_amdgcn_s_memtime(), s_r0_ = __builtin_amdgcn_s_memrealtime()
-#define P8S_BEGIN s_i0_ = __builtin_amdgcn_s_memtime()
-#define P8S_END s_busy_ += __builtin_amdgcn_s_memtime() - s_i0_
-#define P8S_WRITE                                                                                                                  \
-    if (lane == 0 && tk < 256) {                                                                                                  \
-        g_p8_stamps[(tk * 4 + role) * 4 + 0] = s_busy_;                                                                            \
-        g_p8_stamps[(tk * 4 + role) * 4 + 1] = __builtin_amdgcn_s_memtime() - s_t0_;                                              \
-        g_p8_stamps[(tk * 4 + role) * 4 + 2] = __builtin_amdgcn_s_memrealtime() - s_r0_;                                          \
-        g_p8_stamps[(tk * 4 + role) * 4 + 3] = (unsigned long long)(b | (t << 16));                                               \
-    }
-#else
-#define P8S_DECL
-#define P8S_BEGIN
-#define P8S_END
-#define P8S_WRITE
-#endif
-
 constexpr int P8P_THREADS = 256; // compute, loader, storer, west-edge poller: one wave per SIMD
 
 // Packed coefficients.  The walk's pace is its loader, and the loader's cost is the number of cache lines its loads touch: ten

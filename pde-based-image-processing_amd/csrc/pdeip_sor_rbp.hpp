@@ -179,7 +179,7 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
                                                float omega, int col0, size_t fo)
 {
     using L = RbpLayout<Mdl, S>;
-    constexpr int NIT = L::NIT, NRO = L::NRO, NRO1 = at_least_one<NRO>::value, NCF = L::NCF, NRING = L::NRING, COL = L::COL;
+    constexpr int NIT = L::NIT, NRO = L::NRO, NRO1 = at_least_one<NRO>::value, NCF = L::NCF, COL = L::COL;
     const float om1 = 1.0f - omega;
     const bool store_lane = (lane >= 2) && (lane <= 61);
     auto inner = [&](int col) { return col >= 1 && col <= ncols - 2; };
@@ -395,7 +395,7 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
           int col0, size_t frame_stride)
 {
     using L = RbpLayout<Mdl, S>;
-    constexpr int NIT = L::NIT, NRO = L::NRO, NCF = L::NCF, NRING = L::NRING, COL = L::COL, NW = L::NW;
+    constexpr int NIT = L::NIT, NRO = L::NRO, NCF = L::NCF, COL = L::COL, NW = L::NW;
     extern __shared__ __attribute__((aligned(16))) float rbp_lds[];
     float *const Kring = rbp_lds;
     float *const Qring = Kring + L::K_FLOATS;
