@@ -307,7 +307,7 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
         auto store_out = [&](int c) __attribute__((always_inline)) {
             const float *outb = outb_base + (c & 1) * L::OUTB;
             const int r0 = row0(c);
-            const bool all_valid = (r0 - 126 >= 1) && (r0 + EX_CH - 1 <= nrows - 2) && (jbase + 63 <= ncols - 2);
+            const bool all_valid = (r0 - 126 >= 1) && (r0 + EX_CH - 1 <= nrows - 2); // every row an inner row: whole vectors for the inner columns
             // does the chunk relax a pixel next to the image border?
             const bool ringed = (r0 - 126 <= 1 && r0 + EX_CH - 1 >= 1) || (r0 - 126 <= nrows - 2 && r0 + EX_CH - 1 >= nrows - 2) ||
                                 jbase == 1 || jbase + 63 >= ncols - 2;
@@ -318,9 +318,11 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
                 const int row = r0 - P8_SKEW * col + 4 * lrq;
                 const float4 v = *reinterpret_cast<const float4 *>(&outb[col * EX_STR + 4 * lrq]);
                 if (all_valid) {
-                    v4u_t u;
-                    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-                    __builtin_amdgcn_raw_buffer_store_b128(u, rs_x, boff(jj, row), 0, 16);
+                    if (jj <= ncols - 2) {
+                        v4u_t u;
+                        u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+                        __builtin_amdgcn_raw_buffer_store_b128(u, rs_x, boff(jj, row), 0, 16);
+                    }
                 } else if (jj <= ncols - 2) {
                     const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
