@@ -832,7 +832,10 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
         float *outb = outb_base + (k & 1) * L::OUTB;
         const int i00 = 1 + EX_CH * k;
         auto relax_chunk = [&](auto interior_tag) __attribute__((always_inline)) {
-        constexpr bool INTERIOR = decltype(interior_tag)::value;
+        // 2: every lane relaxes an inner pixel at every step and no tap is a border cell; 1: the same for the rows, but the strip
+        // holds column 1 or ncols-2 or is partial (the first strip heads the whole walk, the last one ends it: they should not
+        // pay for row tests they never need); 0: anything
+        constexpr bool INTERIOR = decltype(interior_tag)::value == 2, ROWS_IN = decltype(interior_tag)::value >= 1;
 #pragma unroll
         for (int mq = 0; mq < EX_CH / 4; mq++) {
             float4 s4[NF], e4[NF], res[NIT];
@@ -854,7 +857,7 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
             for (int x = 0; x < 4; x++) {
                 const int q = EX_CH * k + 4 * mq + x;
                 const int i = i0 + q;
-                const bool row_ok = INTERIOR || ((i >= 1) && (i <= nrows - 2));
+                const bool row_ok = ROWS_IN || ((i >= 1) && (i <= nrows - 2));
                 const bool active = INTERIOR || (col_ok && row_ok);
                 auto el = [&](const float4 &v) { return x == 0 ? v.x : (x == 1 ? v.y : (x == 2 ? v.z : v.w)); };
                 float c[NIT], w[NIT], e[NIT], n[NIT], s[NIT], kk[NCF];
@@ -868,9 +871,9 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
                         float wnew = dpp_from_lower_lane(prev[f], el(e4[f]));
                         if (q == 0 && lane != 0) wnew = west0[f];
                         float nv = (q == 0) ? north0[f] : prev[f];
-                        if (!INTERIOR && i == 1) nv = first_sweep ? topb[f] : cen[f];
+                        if (!ROWS_IN && i == 1) nv = first_sweep ? topb[f] : cen[f];
                         n[f] = nv;
-                        s[f] = (!INTERIOR && i + 1 == nrows - 1 && !first_sweep) ? cen[f] : sraw;
+                        s[f] = (!ROWS_IN && i + 1 == nrows - 1 && !first_sweep) ? cen[f] : sraw;
                         e[f] = (!INTERIOR && j + 1 == ncols - 1 && !first_sweep) ? cen[f] : eraw;
                         w[f] = (!INTERIOR && j - 1 == 0 && !first_sweep) ? cen[f] : wnew;
                     } else {
@@ -909,9 +912,10 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
         };
         {
             const int lo_row = i00 - 63, hi_row = i00 + EX_CH - 1;
-            const bool interior = (lo_row >= 2) && (hi_row <= nrows - 3) && (jbase >= 2) && (jbase + 63 <= ncols - 3);
-            if (interior) relax_chunk(std::true_type{});
-            else relax_chunk(std::false_type{});
+            const bool rows_in = (lo_row >= 2) && (hi_row <= nrows - 3), cols_in = (jbase >= 2) && (jbase + 63 <= ncols - 3);
+            if (rows_in && cols_in) relax_chunk(std::integral_constant<int, 2>{});
+            else if (rows_in) relax_chunk(std::integral_constant<int, 1>{});
+            else relax_chunk(std::integral_constant<int, 0>{});
         }
         if (has_east) {
             // Mailbox: lane 63's 16 results of this chunk (rows i0 + 16k .. + 15 of my last column) go out as ONE 128-byte line of
