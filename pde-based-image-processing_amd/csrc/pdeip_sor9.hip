@@ -48,7 +48,11 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
             g.last_launches++;
             float *ctl_f = nullptr, *order_f = nullptr;
             const size_t nprog = (size_t)nframes * iter * nstrips;
-            RC(ws_get(WS_CTL, (4 + nprog) * sizeof(unsigned), &ctl_f));
+            // control words and the west-edge mailbox in ONE block, cleared by one memset per call (a second one cost every small call
+            // a stream operation): [abort, ticket, 2 spare, progress counters ... | 128-byte aligned | mailbox words]
+            const size_t ctl_bytes = ((4 + nprog) * sizeof(unsigned) + 127) / 128 * 128;
+            const size_t mail_bytes = nprog * (size_t)pde8_persist_chunks(nrows) * EX_CH * sizeof(unsigned long long);
+            RC(ws_get(WS_CTL, ctl_bytes + mail_bytes, &ctl_f));
             RC(ws_get(WS_ORDER, (size_t)nstrips * iter * sizeof(int), &order_f));
             DeviceState *dst = cur_dev(); // after the ws_get calls: a regrown WS_ORDER has dropped its cached shape
             if (dst->order_B != nstrips || dst->order_T != iter) { // (b,t) in an order where every dependency comes earlier (same table as pdeip_sor5.hip)
@@ -65,12 +69,9 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
                 dst->order_T = iter;
             }
             // word 0: abort (sticky, cleared by pdeip_persist_error()); word 1: ticket; words 4..: progress counters
-            HIPCHK(hipMemsetAsync(reinterpret_cast<unsigned *>(ctl_f) + 1, 0, (3 + nprog) * sizeof(unsigned), s));
-            // west-edge mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, step of the walk), tags clear at the start of a call
-            float *mail_f = nullptr;
-            const size_t mail_bytes = nprog * (size_t)pde8_persist_chunks(nrows) * EX_CH * sizeof(unsigned long long);
-            RC(ws_get(WS_MAIL, mail_bytes, &mail_f));
-            HIPCHK(hipMemsetAsync(mail_f, 0, mail_bytes, s));
+            HIPCHK(hipMemsetAsync(reinterpret_cast<unsigned *>(ctl_f) + 1, 0, ctl_bytes - sizeof(unsigned) + mail_bytes, s));
+            // mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, [field,] row / step of the walk), tags clear at the start of a call
+            float *mail_f = reinterpret_cast<float *>(reinterpret_cast<char *>(ctl_f) + ctl_bytes);
             PersistCtl ctl{};
             ctl.mail = reinterpret_cast<unsigned long long *>(mail_f);
             ctl.abort_flag = reinterpret_cast<unsigned *>(ctl_f);
