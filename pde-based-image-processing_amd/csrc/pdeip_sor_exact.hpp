@@ -600,14 +600,23 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
             const int which = (lane >> 2) & 1;
             const int ecol = which ? (jbase + 64 < ncols - 1 ? jbase + 64 : ncols - 1) : jbase - 1;
             const int erow = (which ? i00 - 63 : i00) + 4 * (lane & 3);
+            if (i00 - 63 >= 0 && i00 + EX_CH - 1 <= nrows - 1) { // every edge row lies in the plane: one vector per field (no clamping)
 #pragma unroll
-            for (int f = 0; f < NF; f++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const unsigned u = (f < NIT) ? __builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(ecol, crow(erow + e)), 0, 16)
-                                                 : __builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(ecol, crow(erow + e)), 0, 0);
-                    epre[f].v[e] = __uint_as_float(u);
+                for (int f = 0; f < NF; f++) {
+                    const v4u_t v = (f < NIT) ? __builtin_amdgcn_raw_buffer_load_b128(rs[f], boff(ecol, erow), 0, 16)
+                                              : __builtin_amdgcn_raw_buffer_load_b128(rs[f], boff(ecol, erow), 0, 0);
+                    as_f4u(v, epre[f]);
                 }
+            } else {
+#pragma unroll
+                for (int f = 0; f < NF; f++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const unsigned u = (f < NIT) ? __builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(ecol, crow(erow + e)), 0, 16)
+                                                     : __builtin_amdgcn_raw_buffer_load_b32(rs[f], boff(ecol, crow(erow + e)), 0, 0);
+                        epre[f].v[e] = __uint_as_float(u);
+                    }
+            }
         };
         auto stash = [&](const f4u (&pre)[NP][4], const f4u (&epre)[NF], int buf) __attribute__((always_inline)) {
             float *stage = smem + buf * L::BUF, *edge = stage + L::STAGE;
