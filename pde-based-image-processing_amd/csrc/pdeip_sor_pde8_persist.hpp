@@ -188,9 +188,13 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
             const int erow = west ? r0 - 1 + 4 * (w - 5) : r0 - P8_SKEW * 64 + 4 * w;
             // row by row, clamped: the first strip's west column is column 0, where a negative row is a negative offset (the whole
             // vector would read as out of range, valid rows included)
+            if (r0 - 128 >= 0 && r0 + 18 <= nrows - 1) { // every edge row lies in the plane: one vector
+                as_f4u(__builtin_amdgcn_raw_buffer_load_b128(rs_x, boff(ccol(ej), erow), 0, 16), xpre[5]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                xpre[5].v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, boff(ccol(ej), crow(erow + e)), 0, 16));
+                for (int e = 0; e < 4; e++)
+                    xpre[5].v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, boff(ccol(ej), crow(erow + e)), 0, 16));
+            }
             if (ringed) {
 #pragma unroll
                 for (int g = 0; g < 4; g++) patch(xpre[g], r0 - P8_SKEW * (16 * g + lcol) + 4 * lrq, jbase + 16 * g + lcol);
