@@ -458,7 +458,10 @@ template <class Mdl> struct PackLayout {
 template <class Mdl>
 __global__ void k_pack_coefficients(SweepPlanes<Mdl> P, float *pack, int nrows, int ncols, size_t frame_stride)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    // last column first: the walkers start at column 1 right after this kernel, and what was written last is what the
+    // Infinity Cache still holds when the packed planes (299 MB at 4K) are larger than it (measured: +4 % for the 9-point walk
+    // at 4K, nothing either way for the 5-point ones)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = ncols - 1 - (int)blockIdx.y;
     if (i >= nrows) return;
     const size_t pos = (size_t)j * nrows + i;
     const size_t q = pos + (size_t)blockIdx.z * frame_stride;

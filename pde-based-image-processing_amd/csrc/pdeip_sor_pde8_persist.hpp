@@ -45,7 +45,8 @@ static __global__ void k_pde8_pack(float *pack, const float *TRACE, const float 
 {
     constexpr int NCF = ModelPde8::NCF;
     const int nb = pde8_pack_blocks(nrows);
-    const int pb = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    // last column first: see k_pack_coefficients
+    const int pb = blockIdx.x * blockDim.x + threadIdx.x, col = ncols - 1 - (int)blockIdx.y;
     if (pb >= nb) return;
     const size_t fo = (size_t)blockIdx.z * frame_stride;
     float v[NCF][2];
