@@ -29,7 +29,8 @@ struct DeviceState {
     int device = -1;
     void *ws[WS_NSLOT] = {};
     size_t ws_bytes[WS_NSLOT] = {};
-    int order_B = 0, order_T = 0; // shape of the schedule table cached in ws[WS_ORDER]
+    int order_B = 0, order_T = 0, order_affine = -1; // shape (and kind) of the schedule table cached in ws[WS_ORDER]
+    int num_cus = 0;                                 // compute units of this device (0: not asked yet)
     bool persist_used = false;    // a persistent launch happened since the last pdeip_persist_error()
     bool abort_latched = false;   // a persistent kernel's abort word was seen set before its buffer went away
     std::map<const void *, size_t> lds_opt_in; // kernel -> dynamic LDS bytes opted into (hipFuncSetAttribute is per device)
@@ -42,6 +43,7 @@ struct DeviceState {
     void reset_caches()
     {
         order_B = order_T = 0;
+        order_affine = -1;
         persist_used = false;
     }
 };

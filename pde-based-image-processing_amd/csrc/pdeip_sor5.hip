@@ -7,6 +7,7 @@
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
 #include "pdeip_sor_exact.hpp"
+#include "pdeip_persist_host.hpp"
 #include "pdeip_sor_rb.hpp"
 #include "pdeip_sor_rbp.hpp"
 #include "pdeip_sor_small.hpp"
@@ -134,42 +135,11 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             g.last_launches++;
             // ---- persistent form: one launch, progress counters instead of one launch per front ----
             const int NC = (nrows - 2 + 63 + EX_CH - 1) / EX_CH;
-            float *ctl_f = nullptr, *order_f = nullptr;
-            const size_t nprog = (size_t)nframes * iter * B;
-            // control words and the west-edge mailbox in ONE block, cleared by one memset per call (a second one cost every small call
-            // a stream operation): [abort, ticket, 2 spare, progress counters ... | 128-byte aligned | mailbox words]
-            const size_t ctl_bytes = ((4 + nprog) * sizeof(unsigned) + 127) / 128 * 128;
-            const size_t mail_bytes = nprog * NIT * (size_t)NC * EX_CH * sizeof(unsigned long long);
-            RC(ws_get(WS_CTL, ctl_bytes + mail_bytes, &ctl_f));
-            RC(ws_get(WS_ORDER, (size_t)B * iter * sizeof(int), &order_f));
-            DeviceState *dst = cur_dev(); // after the ws_get calls: a regrown WS_ORDER has dropped its cached shape
-            if (dst->order_B != B || dst->order_T != iter) { // (b,t) in an order where every dependency comes earlier
-                std::vector<int> ord;
-                ord.reserve((size_t)B * iter);
-                for (int key = 0; key <= (B - 1) + 2 * (iter - 1); key++)
-                    for (int t = 0; t < iter; t++) {
-                        const int b = key - 2 * t;
-                        if (b >= 0 && b < B) ord.push_back(b | (t << 16));
-                    }
-                HIPCHK(hipMemcpyAsync(order_f, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, s));
-                HIPCHK(hipStreamSynchronize(s)); // `ord` is about to go out of scope
-                dst->order_B = B;
-                dst->order_T = iter;
-            }
-            // word 0: abort (sticky: cleared only by pdeip_persist_error(), so a timed-out wait cannot be lost under the next
-            // call's reset); word 1: ticket; words 4..: progress counters
-            HIPCHK(hipMemsetAsync(reinterpret_cast<unsigned *>(ctl_f) + 1, 0, ctl_bytes - sizeof(unsigned) + mail_bytes, s));
-            // mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, [field,] row / step of the walk), tags clear at the start of a call
-            float *mail_f = reinterpret_cast<float *>(reinterpret_cast<char *>(ctl_f) + ctl_bytes);
-            PersistCtl ctl;
-            ctl.mail = reinterpret_cast<unsigned long long *>(mail_f);
-            ctl.abort_flag = reinterpret_cast<unsigned *>(ctl_f);
-            ctl.ticket = ctl.abort_flag + 1;
-            ctl.progress = ctl.abort_flag + 4;
-            ctl.order = reinterpret_cast<const int *>(order_f);
+            // schedule table, control block, mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, field, row)
+            PersistCtl ctl{};
+            RC(persist_prepare(s, B, iter, nframes, (size_t)nframes * iter * B * NIT * (size_t)NC * EX_CH * sizeof(unsigned long long), &ctl));
             constexpr size_t plds = ExactLayout<Mdl>::LDS_BYTES + 16;
             RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_exact_persist<Mdl>), plds));
-            dst->persist_used = true;
             SweepTimer timer(s);
             hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(B * iter * nframes)), dim3(exp_threads<Mdl>()), plds, s, P, pack, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
             timer.stop(1);

@@ -8,6 +8,7 @@
 #include "pdeip_pointwise.hpp"
 #include "pdeip_sor_pde8.hpp"
 #include "pdeip_sor_pde8_persist.hpp"
+#include "pdeip_persist_host.hpp"
 #include <vector>
 #include "pdeip_sor_rb.hpp"
 
@@ -46,39 +47,9 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
             hipLaunchKernelGGL(k_pde8_pack, dim3((unsigned)((nbk + 127) / 128), (unsigned)ncols, (unsigned)nframes), dim3(128), 0, s, pack, TRACE, B, wW,
                                wNW, wN, wNE, wE, wSE, wS, wSW, nrows, ncols, n);
             g.last_launches++;
-            float *ctl_f = nullptr, *order_f = nullptr;
-            const size_t nprog = (size_t)nframes * iter * nstrips;
-            // control words and the west-edge mailbox in ONE block, cleared by one memset per call (a second one cost every small call
-            // a stream operation): [abort, ticket, 2 spare, progress counters ... | 128-byte aligned | mailbox words]
-            const size_t ctl_bytes = ((4 + nprog) * sizeof(unsigned) + 127) / 128 * 128;
-            const size_t mail_bytes = nprog * (size_t)pde8_persist_chunks(nrows) * EX_CH * sizeof(unsigned long long);
-            RC(ws_get(WS_CTL, ctl_bytes + mail_bytes, &ctl_f));
-            RC(ws_get(WS_ORDER, (size_t)nstrips * iter * sizeof(int), &order_f));
-            DeviceState *dst = cur_dev(); // after the ws_get calls: a regrown WS_ORDER has dropped its cached shape
-            if (dst->order_B != nstrips || dst->order_T != iter) { // (b,t) in an order where every dependency comes earlier (same table as pdeip_sor5.hip)
-                std::vector<int> ord;
-                ord.reserve((size_t)nstrips * iter);
-                for (int key = 0; key <= (nstrips - 1) + 2 * (iter - 1); key++)
-                    for (int t = 0; t < iter; t++) {
-                        const int b = key - 2 * t;
-                        if (b >= 0 && b < nstrips) ord.push_back(b | (t << 16));
-                    }
-                HIPCHK(hipMemcpyAsync(order_f, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, s));
-                HIPCHK(hipStreamSynchronize(s)); // `ord` is about to go out of scope
-                dst->order_B = nstrips;
-                dst->order_T = iter;
-            }
-            // word 0: abort (sticky, cleared by pdeip_persist_error()); word 1: ticket; words 4..: progress counters
-            HIPCHK(hipMemsetAsync(reinterpret_cast<unsigned *>(ctl_f) + 1, 0, ctl_bytes - sizeof(unsigned) + mail_bytes, s));
-            // mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, [field,] row / step of the walk), tags clear at the start of a call
-            float *mail_f = reinterpret_cast<float *>(reinterpret_cast<char *>(ctl_f) + ctl_bytes);
+            // schedule table, control block, mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, step of the walk)
             PersistCtl ctl{};
-            ctl.mail = reinterpret_cast<unsigned long long *>(mail_f);
-            ctl.abort_flag = reinterpret_cast<unsigned *>(ctl_f);
-            ctl.ticket = ctl.abort_flag + 1;
-            ctl.progress = ctl.abort_flag + 4;
-            ctl.order = reinterpret_cast<const int *>(order_f);
-            dst->persist_used = true;
+            RC(persist_prepare(s, nstrips, iter, nframes, (size_t)nframes * iter * nstrips * (size_t)pde8_persist_chunks(nrows) * EX_CH * sizeof(unsigned long long), &ctl));
             SweepTimer timer(s);
             const int nl = pde8_run_exact_persist(s, P, pack, scratch, ctl, nrows, ncols, nframes, iter, omega);
             if (nl < 0) return PDEIP_ERR_DEVICE;

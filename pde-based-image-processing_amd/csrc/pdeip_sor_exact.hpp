@@ -430,7 +430,7 @@ static __device__ unsigned long long g_p8_stamps[4096]; // one copy per translat
 #define P8S_WRITE                                                                                                                  \
     if (lane == 0 && tk < 256) {                                                                                                  \
         g_p8_stamps[(tk * 4 + role) * 4 + 0] = s_busy_;                                                                            \
-        g_p8_stamps[(tk * 4 + role) * 4 + 1] = __builtin_amdgcn_s_memtime() - s_t0_;                                              \
+        g_p8_stamps[(tk * 4 + role) * 4 + 1] = (role == 1) ? s_r0_ : __builtin_amdgcn_s_memtime() - s_t0_; /* loader: when the walk began, 100 MHz */ \
         g_p8_stamps[(tk * 4 + role) * 4 + 2] = __builtin_amdgcn_s_memrealtime() - s_r0_;                                          \
         g_p8_stamps[(tk * 4 + role) * 4 + 3] = (unsigned long long)(b | (t << 16));                                               \
     }
@@ -475,12 +475,31 @@ __global__ void k_pack_coefficients(SweepPlanes<Mdl> P, float *pack, int nrows, 
 }
 
 struct PersistCtl {
-    unsigned *ticket;    // [1]
+    unsigned *ticket;    // [8] one per XCD list
     unsigned *abort_flag; // [1]
     unsigned *progress;  // [nframes][T][B] chunks completed and visible
-    const int *order;    // [B*T] packed b | (t << 16), dependency-respecting order
+    const int *order;    // schedule table: [0..8] list offsets, [16..] items b | (t << 16) (pdeip_persist_host.hpp)
     unsigned long long *mail; // [nframes][T][B][NIT][nrows] east-column results of a strip, {value, tag}: see "West edge" below
 };
+
+// One item per workgroup (thread 0): the next one of the list of the XCD this workgroup runs on, or of the next list that still has
+// one (pdeip_persist_host.hpp).  Returns the item's index in the table and the frame, or false (cannot happen: one item per workgroup).
+__device__ __forceinline__ bool persist_take_item(const PersistCtl &ctl, int nframes, unsigned *item, unsigned *frame)
+{
+    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; // HW_REG_XCC_ID, bits 3:0
+    for (unsigned a = 0; a < 8; a++) {
+        const unsigned x = (xcc + a) & 7u;
+        const unsigned first = (unsigned)ctl.order[x], len = ((unsigned)ctl.order[x + 1] - first) * (unsigned)nframes;
+        if (len == 0) continue;
+        const unsigned idx = atomicAdd(ctl.ticket + x, 1u);
+        if (idx < len) {
+            *item = first + idx / (unsigned)nframes;
+            *frame = idx % (unsigned)nframes;
+            return true;
+        }
+    }
+    return false;
+}
 
 // Wave-wide wait: lane k polls counter ptrs[k] (k < 3) until it reaches need[k]; the three polls are ONE
 // load instruction per round (one write-through latency instead of three).  Bounded: a timeout raises
@@ -530,11 +549,18 @@ k_sor_exact_persist(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int n
     // relaxed by two COMPUTE waves that never exchange anything: half the instructions per step each.
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 compute (field 0 / all), 1 loader, 2 storer + west edge, 3 compute (field 1)
     const bool mover = role == 1;
-    if (threadIdx.x == 0) *s_ticket = atomicAdd(ctl.ticket, 1u);
+    if (threadIdx.x == 0) {
+        unsigned item = 0, fr = 0;
+        s_ticket[2] = persist_take_item(ctl, nframes, &item, &fr) ? 1u : 0u;
+        s_ticket[0] = item;
+        s_ticket[1] = fr;
+    }
     __syncthreads();
-    const unsigned tk = *s_ticket;
-    const int frame = (int)(tk % (unsigned)nframes);
-    const int packed = ctl.order[tk / (unsigned)nframes];
+    if (s_ticket[2] == 0u) return;
+    const int frame = (int)s_ticket[1];
+    const unsigned tk = s_ticket[0] * (unsigned)nframes + s_ticket[1]; // dense id of (item, frame): diagnostics only
+    (void)tk;
+    const int packed = ctl.order[16 + s_ticket[0]];
     const int b = packed & 0xffff, t = packed >> 16;
     const size_t fo = (size_t)frame * frame_stride;
     unsigned *prog_mine = ctl.progress + ((size_t)frame * T + t) * B + b;

@@ -90,11 +90,18 @@ k_pde8_exact_persist(Pde8Planes P, const float *pack, float *side, PersistCtl ct
 
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 compute, 1 loader, 2 storer, 3 west edge
-    if (threadIdx.x == 0) *s_ticket = atomicAdd(ctl.ticket, 1u);
+    if (threadIdx.x == 0) {
+        unsigned item = 0, fr = 0;
+        s_ticket[2] = persist_take_item(ctl, nframes, &item, &fr) ? 1u : 0u;
+        s_ticket[0] = item;
+        s_ticket[1] = fr;
+    }
     __syncthreads();
-    const unsigned tk = *s_ticket;
-    const int frame = (int)(tk % (unsigned)nframes);
-    const int packed = ctl.order[tk / (unsigned)nframes];
+    if (s_ticket[2] == 0u) return;
+    const int frame = (int)s_ticket[1];
+    const unsigned tk = s_ticket[0] * (unsigned)nframes + s_ticket[1]; // dense id of (item, frame): diagnostics only
+    (void)tk;
+    const int packed = ctl.order[16 + s_ticket[0]];
     const int b = packed & 0xffff, t = packed >> 16;
     const size_t fo = (size_t)frame * frame_stride;
     unsigned *prog_mine = ctl.progress + ((size_t)frame * T + t) * B + b;

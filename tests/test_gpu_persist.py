@@ -144,3 +144,32 @@ def test_set_device_keeps_working(pdeip, oracle):
     for g, w in zip(got, want):
         assert pb.bit_equal(g, w)
     api.set_mode(0)
+
+
+@pytest.mark.parametrize("knob", ["0", "1"])
+def test_schedule_kinds_give_the_same_bits(pdeip, oracle, knob):
+    """The walkers take their (strip, sweep) from per-XCD lists when every workgroup of the call is resident (PDEIP_PERSIST_XCD=1,
+    the default) and from one list in key order otherwise (more workgroups than compute units, or the knob at 0): placement changes
+    speed only.  5-point and 9-point walkers, a grid below the CU count (affine unless the knob says no) and one far above it
+    (iter = 40 x 6 strips x 2 frames: one list whatever the knob)."""
+    os.environ.pop("PDEIP_EXACT_PERSIST", None)
+    old = os.environ.get("PDEIP_PERSIST_XCD")
+    os.environ["PDEIP_PERSIST_XCD"] = knob
+    try:
+        api = pdeip.mex_api
+        api.set_mode(0)
+        for it in (3, 40):
+            p = pb.elin4(831, 150, 330, nan_frac=0.01)
+            got = api.Oflow_sor_elin4_2d(*p.values(), np.float32(it), np.float32(1.9), np.float32(1))
+            want = oracle.Oflow_sor_elin4_2d(*p.values(), it, 1.9)
+            for g, w in zip(got, want):
+                assert pb.bit_equal(g, w), "elin4 it=%d knob=%s: %s" % (it, knob, pb.describe_mismatch(g, w))
+            e = pb.pde8(832, 90, 330, nframes=2)
+            assert pb.bit_equal(api.PDEsolver8(*e.values(), np.float32(it), np.float32(1.75), np.float32(1)), oracle.PDEsolver8(*e.values(), it, 1.75, order=0)), \
+                "pde8 it=%d knob=%s" % (it, knob)
+            _ok(pdeip)
+    finally:
+        if old is None:
+            os.environ.pop("PDEIP_PERSIST_XCD", None)
+        else:
+            os.environ["PDEIP_PERSIST_XCD"] = old

@@ -36,6 +36,7 @@ for tk in range(256):
     cells = []
     for r in range(4):
         busy, total, real = rows[r][0], rows[r][1], rows[r][2]
+        total, real = rows[0][1], rows[0][2]
         ns_per_tick = real * 10.0 / max(total, 1)
         cells.append("%s %5.0f" % (names[r], busy * ns_per_tick / NC))
     print("  b=%2d t=%d  walk %6.0f ns/chunk   %s" % (b, t, rows[0][2] * 10.0 / NC, "   ".join(cells)))

@@ -26,6 +26,24 @@ buf = (ctypes.c_ulonglong * 4096)()
 assert lib.pdeip_debug_read_walk_stamps(buf) == 0
 NC = (nr - 2 + 63 + 15) // 16
 names = ["compute0", "loader", "storer", "compute1"]
+starts = {}
+for tk in range(256):
+    if buf[(tk * 4 + 0) * 4 + 1]:
+        bt = buf[(tk * 4 + 0) * 4 + 3]
+        starts[(bt & 0xffff, bt >> 16)] = (buf[(tk * 4 + 1) * 4 + 1] * 10.0, buf[(tk * 4 + 1) * 4 + 2] * 10.0)  # start ns, duration ns (loader wave)
+if starts:
+    t00 = starts[(0, 0)][0]
+    for t in range(it):
+        print("sweep %d  strip: start us (lag to the west strip) | end us (lag)" % t)
+        prev = None
+        for b in range(0, 64):
+            if (b, t) not in starts:
+                continue
+            st, du = starts[(b, t)]
+            cur = ((st - t00) / 1e3, (st + du - t00) / 1e3)
+            if b % 12 == 0 or b >= 58:
+                print("  b=%2d  start %8.1f (%5.1f)   end %8.1f (%5.1f)   walk %6.1f" % (b, cur[0], cur[0] - prev[0] if prev else 0.0, cur[1], cur[1] - prev[1] if prev else 0.0, du / 1e3))
+            prev = cur
 print("%d x %d, iter %d, %d chunks; per chunk: busy ns (of the walk's ns per chunk)" % (nr, nc, it, NC))
 for tk in range(256):
     rows = [[buf[(tk * 4 + r) * 4 + k] for k in range(4)] for r in range(4)]
@@ -36,6 +54,6 @@ for tk in range(256):
         continue
     cells = []
     for r in range(4):
-        busy, total, real = rows[r][0], rows[r][1], rows[r][2]
+        busy, total, real = rows[r][0], rows[0][1], rows[0][2]  # cycles -> ns by the first compute wave's clock pair
         cells.append("%s %5.0f" % (names[r], busy * (real * 10.0 / max(total, 1)) / NC))
     print("  b=%2d t=%d  walk %6.0f ns/chunk   %s" % (b, t, rows[0][2] * 10.0 / NC, "   ".join(cells)))
