@@ -67,10 +67,11 @@ int pdeip_get_mode(void);
 /* Select the HIP device used by the host-pointer entry points (default 0) = pdeip_set_devices(1, &device_id). */
 int pdeip_set_device(int device_id);
 /* Device group of the host-pointer entry points.  With n > 1, red-black (PDEIP_MODE_RED_BLACK) point-SOR solver calls
- * are cut into n slabs of consecutive MATLAB columns, one per device, each slab relaxed by its device with a wide column
- * halo that is exchanged device-to-device between sweep pairs (csrc/pdeip_multi.hip); results are bit-identical to the
- * single-device red-black call.  Exact-order calls and line relaxation do not decompose (their dependency front crosses
- * the frame) and run on ids[0].  Workspace is cached per device. */
+ * are cut into n slabs of consecutive MATLAB columns, one per device.  Every device uploads its slab plus a halo of
+ * 2 x iter columns per cut side straight from the caller's host planes and relaxes it for the whole call: nothing is
+ * exchanged between devices (for a host-pointer call the upload is the halo refresh; csrc/pdeip_multi.hip).  Results are
+ * bit-identical to the single-device red-black call.  Exact-order calls and line relaxation do not decompose (their
+ * dependency front crosses the frame) and run on ids[0].  Workspace is cached per device. */
 int pdeip_set_devices(int n, const int *ids);
 /* Writes up to `capacity` ids of the current group to ids (may be NULL) and returns the group size. */
 int pdeip_get_devices(int *ids, int capacity);
@@ -90,6 +91,10 @@ int pdeip_workspace_generation(void);
 /* Waits for the device and reports PDEIP_ERR_DEVICE if a bounded dependency wait of the persistent
  * exact-order kernel (PDEIP_EXACT_PERSIST=1) timed out during the preceding calls. */
 int pdeip_persist_error(void);
+/* Diagnostic: the schedule table the exact-order walkers would use for B strips x T sweeps (affine: the XCD-affine lists of
+ * PDEIP_PERSIST_XCD=1), built on the device as a call builds it and copied to `table` (16 + B*T ints: list offsets 0..8, items
+ * b | t << 16 from int 16 on). */
+int pdeip_debug_persist_order(int B, int T, int affine, int *table);
 /* Sweep-kernel timing for bench.py's roofline figure.  While enabled, every *_dev solver call
  * brackets its back-to-back sweep launches (not its prologue) with a pair of HIP events on the
  * call's stream.  pdeip_profile_read() waits for the recorded events, returns the summed elapsed

@@ -5,19 +5,22 @@
 namespace pdeip {
 
 Context g;
+thread_local ThreadState tls;
 
 int set_err(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g.err, sizeof g.err, fmt, ap);
+    vsnprintf(tls.err, sizeof tls.err, fmt, ap);
     va_end(ap);
     return code;
 }
 
 SweepTimer::SweepTimer(hipStream_t stream) : s(stream)
 {
-    if (!g.profile || g.n_ev >= Context::MAX_EV) return;
+    if (!g.profile) return;
+    std::lock_guard<std::mutex> lock(g.ev_mutex);
+    if (g.n_ev >= Context::MAX_EV) return;
     if (g.n_ev == g.n_ev_created) {
         if (hipEventCreate(&g.ev[g.n_ev][0]) != hipSuccess || hipEventCreate(&g.ev[g.n_ev][1]) != hipSuccess) return;
         g.n_ev_created++;
@@ -45,6 +48,7 @@ static void latch_abort(DeviceState *d)
 
 DeviceState *cur_dev()
 {
+    if (tls.dev_slot >= 0 && tls.dev_slot < MAX_DEVICES) return &g.devs[tls.dev_slot]; // its `device` was set by whoever chose the slot
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
     g.devs[dev].device = dev;
@@ -216,9 +220,6 @@ static void release_device(DeviceState *d)
         d->ws[s] = nullptr;
         d->ws_bytes[s] = 0;
     }
-    if (d->pinned) (void)hipHostFree(d->pinned);
-    d->pinned = nullptr;
-    d->pinned_bytes = 0;
     d->reset_caches();
 }
 
@@ -230,7 +231,7 @@ using namespace pdeip;
 // library state
 // ------------------------------------------------------------------------------------------------
 extern "C" const char *pdeip_version(void) { return "pdeip-mi355x 0.2 (gfx950)"; }
-extern "C" const char *pdeip_last_error(void) { return g.err; }
+extern "C" const char *pdeip_last_error(void) { return tls.err; }
 extern "C" int pdeip_set_mode(int mode)
 {
     RC(check_mode("pdeip_set_mode", mode));
@@ -275,7 +276,7 @@ extern "C" int pdeip_release(void)
     if (have_cur) (void)hipSetDevice(cur);
     return PDEIP_OK;
 }
-extern "C" int pdeip_last_launch_count(void) { return g.last_launches; }
+extern "C" int pdeip_last_launch_count(void) { return tls.last_launches; }
 extern "C" int pdeip_workspace_generation(void) { return g.ws_generation; }
 extern "C" int pdeip_persist_error(void)
 { // waits for the device(s), then reports whether a bounded spin of the persistent kernel timed out

@@ -9,11 +9,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <vector>
 
 namespace pdeip {
@@ -35,11 +37,6 @@ struct DeviceState {
     bool abort_latched = false;   // a persistent kernel's abort word was seen set before its buffer went away
     std::map<const void *, size_t> lds_opt_in; // kernel -> dynamic LDS bytes opted into (hipFuncSetAttribute is per device)
     std::map<const void *, int> resident_waves; // kernel -> waves the device holds at once (occupancy query)
-    hipStream_t stream = nullptr; // this device's stream of a multi-device call (pdeip_multi.hip)
-    hipEvent_t ev_halo = nullptr, ev_done = nullptr;
-    void *pinned = nullptr;       // pinned staging buffer of the host entry points
-    size_t pinned_bytes = 0;
-    hipStream_t copy_stream[2] = {nullptr, nullptr};
     void reset_caches()
     {
         order_B = order_T = 0;
@@ -48,11 +45,19 @@ struct DeviceState {
     }
 };
 
+// What a thread of the library keeps to itself.  The host entry points are called from one thread at a time, but a device
+// group runs one worker thread per device through the ordinary *_dev entry points (pdeip_multi.hip): the error text, the
+// launch counter and the device-state slot are per thread, so workers neither tear each other's messages nor lose counts.
+struct ThreadState {
+    char err[512] = "";
+    int last_launches = 0;
+    int dev_slot = -1; // >= 0: cur_dev() returns this slot of Context::devs instead of the current HIP device's (virtual-thread test mode)
+};
+extern thread_local ThreadState tls;
+
 struct Context {
     int mode = PDEIP_MODE_EXACT_ORDER;
-    int last_launches = 0;
-    int ws_generation = 0; // bumped whenever a workspace buffer is freed or regrown: captured HIP graphs hold its pointers
-    char err[512] = "";
+    std::atomic<int> ws_generation{0}; // bumped whenever a workspace buffer is freed or regrown: captured HIP graphs hold its pointers
     int rb_tj = 0;        // columns per red-black unit (0 = default)
     bool env_read = false; // PDEIP_MODE / PDEIP_DEVICE / PDEIP_DEVICES consulted
     // device group of the host entry points: group[0] is "the" device of single-device calls
@@ -65,6 +70,7 @@ struct Context {
     hipEvent_t ev[MAX_EV][2];
     int ev_launches[MAX_EV];
     int n_ev = 0, n_ev_created = 0;
+    std::mutex ev_mutex; // event slots are handed out to whichever thread asks
 };
 extern Context g;
 

@@ -35,7 +35,7 @@ static int zebra3_launch(hipStream_t s, const typename Mdl::Ctx &q, float *x, fl
     const int count = (lastc - first) / lstep + 1;
     hipLaunchKernelGGL((k_alr_zebra3<Mdl, VERT, MODE>), dim3((unsigned)((count + ZB_LW - 1) / ZB_LW), (unsigned)nframes), dim3(ZB_THREADS),
                        Z3_LDS_BYTES, s, q, x, cp, dv, dp, nrows, ncols, (size_t)nrows * ncols, first, lastc, lstep, omega);
-    g.last_launches++;
+    tls.last_launches++;
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }
@@ -65,7 +65,7 @@ static int alr_factor(hipStream_t s, const typename Mdl::Ctx *q, const typename 
             else
                 hipLaunchKernelGGL((k_alr_factor_pair<Mdl, false>), grid, dim3(ZB_THREADS), Z3_LDS_BYTES, s, qt[0], qt[1], f->cp[0][1], f->dv[0][1],
                                    f->cp[1][1], f->dv[1][1], nrows, ncols, fs, lo, hi);
-            g.last_launches++;
+            tls.last_launches++;
         }
         HIPCHK(hipGetLastError());
         return PDEIP_OK;
@@ -98,7 +98,7 @@ static int alr_lex_pass(hipStream_t s, const typename Mdl::Ctx *q, float *const 
             RC(ensure_lds(vertical ? reinterpret_cast<const void *>(&k_alr_lex<Mdl, 2, true>) : reinterpret_cast<const void *>(&k_alr_lex<Mdl, 2, false>), 2 * line_bytes));
         if (vertical) hipLaunchKernelGGL((k_alr_lex<Mdl, 2, true>), dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), 2 * line_bytes, s, ch, nrows, ncols, fs, lo, hi, omega);
         else hipLaunchKernelGGL((k_alr_lex<Mdl, 2, false>), dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), 2 * line_bytes, s, ch, nrows, ncols, fs, lo, hi, omega);
-        g.last_launches++;
+        tls.last_launches++;
     } else {
         if (line_bytes > 64 * 1024)
             RC(ensure_lds(vertical ? reinterpret_cast<const void *>(&k_alr_lex<Mdl, 1, true>) : reinterpret_cast<const void *>(&k_alr_lex<Mdl, 1, false>), line_bytes));
@@ -107,7 +107,7 @@ static int alr_lex_pass(hipStream_t s, const typename Mdl::Ctx *q, float *const 
             ch.c[0] = AlrChain<Mdl>{q[order[c]], x[order[c]], f.cp[order[c]][d], f.dv[order[c]][d]};
             if (vertical) hipLaunchKernelGGL((k_alr_lex<Mdl, 1, true>), dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), line_bytes, s, ch, nrows, ncols, fs, lo, hi, omega);
             else hipLaunchKernelGGL((k_alr_lex<Mdl, 1, false>), dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), line_bytes, s, ch, nrows, ncols, fs, lo, hi, omega);
-            g.last_launches++;
+            tls.last_launches++;
         }
     }
     HIPCHK(hipGetLastError());
@@ -141,7 +141,7 @@ static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, c
         const dim3 grid((unsigned)((count + 63) / 64), (unsigned)nframes);
         if (vertical) hipLaunchKernelGGL((k_alr_zebra<Mdl, true>), grid, dim3(64), 0, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
         else hipLaunchKernelGGL((k_alr_zebra<Mdl, false>), grid, dim3(64), 0, s, q, x, cp, dp, nrows, ncols, fs, lo, hi, colour, omega);
-        g.last_launches++;
+        tls.last_launches++;
     }
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
@@ -166,7 +166,7 @@ struct AlrTwin {
 static int alr_transpose(hipStream_t s, float *out, const float *in, int na, int nb, int nframes)
 {
     hipLaunchKernelGGL(k_alr_transpose, dim3((unsigned)((na + 31) / 32), (unsigned)((nb + 31) / 32), (unsigned)nframes), dim3(256), 0, s, out, in, na, nb);
-    g.last_launches++;
+    tls.last_launches++;
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }
@@ -183,7 +183,7 @@ static int alr_transpose_many(hipStream_t s, float *const *out, const float *con
         }
         hipLaunchKernelGGL(k_alr_transpose_batch, dim3((unsigned)((na + 31) / 32), (unsigned)((nb + 31) / 32), (unsigned)(m * nframes)), dim3(256), 0,
                            s, B, na, nb, nframes);
-        g.last_launches++;
+        tls.last_launches++;
     }
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
@@ -247,7 +247,7 @@ static int run_alr(const char *who, hipStream_t s, const typename Mdl::Ctx *q, f
     RC(check_dims(who, nrows, ncols, nframes));
     RC(check_mode(who, mode));
     RC(check_alr_line(who, mode, nrows, ncols));
-    g.last_launches = 0;
+    tls.last_launches = 0;
     if (iter <= 0) return PDEIP_OK;
     const int fwd[2] = {0, 1}, rev[2] = {1, 0};
     typename Mdl::Ctx qt[2];
@@ -289,7 +289,7 @@ static int run_alr(const char *who, hipStream_t s, const typename Mdl::Ctx *q, f
                 SweepTimer timer(s);
                 hipLaunchKernelGGL(k_alr_small<Mdl>, dim3((unsigned)nframes), dim3(ALR_SMALL_THREADS), lds, s, A);
                 timer.stop(iter);
-                g.last_launches++;
+                tls.last_launches++;
                 HIPCHK(hipGetLastError());
                 return PDEIP_OK;
             }

@@ -12,7 +12,9 @@
 // planes over the link, and every device has its own link.
 //
 // One host thread per device (pageable-memory copies block the calling thread, so the devices would otherwise take turns);
-// several slabs on one device (PDEIP_VIRTUAL_SLABS, a test knob) run one after the other in that device's thread.
+// several slabs on one device (PDEIP_VIRTUAL_SLABS, a test knob) run one after the other in that device's thread.  The
+// workers call the ordinary *_dev entry points concurrently: what those touch besides their device's state is per thread
+// (ThreadState: error text, launch counter) or atomic / locked (workspace generation, profiling event slots).
 // Exact-order calls and line relaxation do not decompose (their dependency front crosses the frame): they run on the first
 // device of the group.  No slab narrower than its halo: the group is cut down until every slab is at least H + 1 wide.
 #include "pdeip_ctx.hpp"
@@ -130,15 +132,33 @@ int multi_sor(const MultiCall &mc, int *handled)
     SlabPlan plan;
     if (multi_plan(mc.ncols, 2 * mc.iter, &plan) <= 1) return PDEIP_OK;
     *handled = 1;
-    // one thread per distinct device; each walks its slabs in order
-    int rc[MAX_DEVICES] = {};
+    // one thread per distinct device; each walks its slabs in order.  PDEIP_VIRTUAL_THREADS=n (testing, one-device group
+    // only): the slabs are dealt over n worker threads on that device instead, each with a device-state slot of its own
+    // (workspace, caches) -- the threaded path with everything it shares, on a one-GPU box.
+    int rc[MAX_DEVICES] = {}, launches[MAX_DEVICES] = {};
     char errs[MAX_DEVICES][256] = {};
     std::thread th[MAX_DEVICES];
-    int nth = 0, devs[MAX_DEVICES];
-    for (int k = 0; k < plan.nslabs; k++) {
-        bool seen = false;
-        for (int j = 0; j < nth; j++) seen = seen || devs[j] == plan.dev[k];
-        if (!seen) devs[nth++] = plan.dev[k];
+    int nth = 0, devs[MAX_DEVICES], slot[MAX_DEVICES], owner[MAX_DEVICES];
+    int vthreads = g.ngroup == 1 ? env_int("PDEIP_VIRTUAL_THREADS", 0) : 0;
+    if (vthreads > plan.nslabs) vthreads = plan.nslabs;
+    if (vthreads > MAX_DEVICES / 2) vthreads = MAX_DEVICES / 2;
+    if (vthreads > 1) {
+        nth = vthreads;
+        for (int ti = 0; ti < nth; ti++) {
+            devs[ti] = g.group[0];
+            slot[ti] = ti == 0 ? -1 : MAX_DEVICES - ti; // the first worker keeps the device's own state
+        }
+        for (int k = 0; k < plan.nslabs; k++) owner[k] = k % nth;
+    } else {
+        for (int k = 0; k < plan.nslabs; k++) {
+            int j = 0;
+            while (j < nth && devs[j] != plan.dev[k]) j++;
+            if (j == nth) {
+                devs[nth] = plan.dev[k];
+                slot[nth++] = -1;
+            }
+            owner[k] = j;
+        }
     }
     auto work = [&](int ti) {
         if (hipSetDevice(devs[ti]) != hipSuccess) {
@@ -146,22 +166,28 @@ int multi_sor(const MultiCall &mc, int *handled)
             snprintf(errs[ti], sizeof errs[ti], "multi-device call: hipSetDevice(%d) failed", devs[ti]);
             return;
         }
-        g.devs[devs[ti]].device = devs[ti];
+        const int keep_slot = tls.dev_slot;
+        tls.dev_slot = slot[ti];
+        cur_dev()->device = devs[ti];
         for (int k = 0; k < plan.nslabs && rc[ti] == PDEIP_OK; k++)
-            if (plan.dev[k] == devs[ti]) {
+            if (owner[k] == ti) {
                 rc[ti] = slab_run(mc, plan, k);
-                if (rc[ti] != PDEIP_OK) snprintf(errs[ti], sizeof errs[ti], "%s", g.err);
+                launches[ti] += tls.last_launches;
+                if (rc[ti] != PDEIP_OK) snprintf(errs[ti], sizeof errs[ti], "%s", tls.err); // this thread's own text
             }
         if (rc[ti] == PDEIP_OK && hipDeviceSynchronize() != hipSuccess) rc[ti] = PDEIP_ERR_DEVICE;
+        tls.dev_slot = keep_slot;
     };
     if (nth == 1) work(0); // virtual slabs on one device: no thread needed
     else {
         for (int ti = 0; ti < nth; ti++) th[ti] = std::thread(work, ti);
         for (int ti = 0; ti < nth; ti++) th[ti].join();
     }
+    (void)hipSetDevice(g.group[0]);
+    tls.last_launches = 0;
+    for (int ti = 0; ti < nth; ti++) tls.last_launches += launches[ti];
     for (int ti = 0; ti < nth; ti++)
         if (rc[ti] != PDEIP_OK) return set_err(rc[ti], "%s", errs[ti][0] ? errs[ti] : "multi-device call failed");
-    (void)hipSetDevice(g.group[0]);
     return PDEIP_OK;
 }
 

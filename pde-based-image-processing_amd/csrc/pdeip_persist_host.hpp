@@ -9,22 +9,49 @@
 // Schedule table (ws[WS_ORDER], cached by shape): ints 0..8 = offsets of eight lists into the items, items from int 16 on, an item
 // = b | (t << 16).  Every list is sorted by key = b + 2t, in which every dependency of an item -- (b-1,t), (b,t-1), (b+1,t-1) --
 // has a smaller key.
-//   XCD-affine (all workgroups of the call resident at once: grid <= compute units): list x holds the strips b = x (mod 8),
+//   XCD-affine (opt-in, PDEIP_PERSIST_XCD=1, and only when grid <= compute units): list x holds the strips b = x (mod 8),
 //   all their sweeps; a workgroup takes the next item of the list of the XCD it runs on (HW_REG_XCC_ID) and only steals
 //   from the other lists when its own is used up.  The sweeps of a strip then follow each other through ONE L2: sweep t+1 reads
 //   the packed coefficients sweep t fetched 10-15 us earlier.  With every workgroup resident and exactly one item per
 //   workgroup every item is taken by a running workgroup, whatever the placement: placement changes speed only.
-//   Otherwise (more workgroups than compute units): one list in key order, as before -- a running workgroup then only ever
-//   waits for items with smaller tickets, which are running or finished.
+//   Default (and always with more workgroups than compute units): one list in key order -- a running workgroup then only ever
+//   waits for items with smaller tickets, which are running or finished: live for any grid, any dispatch order and whatever
+//   other kernels hold compute units.
 #pragma once
-#include <vector>
-
 #include "pdeip_ctx.hpp"
 #include "pdeip_sor_exact.hpp"
 
 namespace pdeip {
 
 constexpr int PERSIST_HDR_WORDS = 16, PERSIST_TABLE_HDR = 16;
+
+// Schedule table on the device.  Thread (b, t) writes its item at its rank in its list: the number of items of the list that
+// come before it in (key, t) order, key = b + 2t.  Items (b', t') of list x: 0 <= b' < B, b' = x (mod 8) when affine.
+static __device__ __forceinline__ int persist_count_below(int lim, int B, int affine, int x)
+{ // #{b' in [0, min(lim, B)) : affine ? b' % 8 == x : true}
+    int n = lim < B ? lim : B;
+    if (n <= 0) return 0;
+    return affine ? (n - x + 7) / 8 : n;
+}
+static __global__ void k_persist_order(int *table, int B, int T, int affine)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < PERSIST_TABLE_HDR) { // list offsets: list x starts behind the items of the lists before it
+        int off = 0;
+        for (int x = 0; x < idx && x < 8; x++) off += (affine ? (B - x + 7) / 8 : (x == 0 ? B : 0)) * T;
+        table[idx] = idx <= 8 ? (idx == 8 ? B * T : off) : 0;
+    }
+    if (idx >= B * T) return;
+    const int b = idx % B, t = idx / B, key = b + 2 * t, x = affine ? (b & 7) : 0;
+    int rank = 0;
+    for (int tt = 0; tt < T; tt++) {
+        // items of sweep tt with a smaller key, or the same key and a smaller sweep: b' < key - 2 tt (+1 when tt < t)
+        rank += persist_count_below(key - 2 * tt + (tt < t ? 1 : 0), B, affine, x);
+    }
+    int first = 0;
+    for (int xx = 0; xx < x; xx++) first += ((B - xx + 7) / 8) * T;
+    table[PERSIST_TABLE_HDR + first + rank] = b | (t << 16);
+}
 
 inline int persist_prepare(hipStream_t s, int B, int iter, int nframes, size_t mail_bytes, PersistCtl *ctl)
 {
@@ -38,23 +65,15 @@ inline int persist_prepare(hipStream_t s, int B, int iter, int nframes, size_t m
         hipDeviceProp_t prop;
         dst->num_cus = (hipGetDeviceProperties(&prop, dst->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
     }
-    const int affine = (env_int("PDEIP_PERSIST_XCD", 1) != 0 && nprog <= (size_t)dst->num_cus) ? 1 : 0;
+    // Default: the single key-ordered list -- a running workgroup only ever waits for smaller tickets, which are running or
+    // finished, whatever else holds compute units.  The XCD-affine lists (3-5 % faster at 4K) are live only while every
+    // workgroup of the grid is resident, which a library inside somebody else's process cannot know: opt-in, PDEIP_PERSIST_XCD=1.
+    const int affine = (env_int("PDEIP_PERSIST_XCD", 0) != 0 && nprog <= (size_t)dst->num_cus) ? 1 : 0;
     if (dst->order_B != B || dst->order_T != iter || dst->order_affine != affine) {
-        std::vector<int> table(PERSIST_TABLE_HDR, 0), items;
-        items.reserve((size_t)B * iter);
-        for (int x = 0; x < 8; x++) {
-            table[x] = (int)items.size();
-            if (!affine && x > 0) continue;
-            for (int key = 0; key <= (B - 1) + 2 * (iter - 1); key++)
-                for (int t = 0; t < iter; t++) {
-                    const int b = key - 2 * t;
-                    if (b >= 0 && b < B && (!affine || (b & 7) == x)) items.push_back(b | (t << 16));
-                }
-        }
-        table[8] = (int)items.size();
-        table.insert(table.end(), items.begin(), items.end());
-        HIPCHK(hipMemcpyAsync(order_f, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s)); // `table` is about to go out of scope
+        // built on the call's stream by a kernel: no host table, no synchronisation, capturable into a HIP graph
+        const int nitems = B * iter;
+        hipLaunchKernelGGL(k_persist_order, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, s, reinterpret_cast<int *>(order_f), B, iter, affine);
+        HIPCHK(hipGetLastError());
         dst->order_B = B;
         dst->order_T = iter;
         dst->order_affine = affine;

@@ -92,7 +92,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
 {
     constexpr int NIT = Mdl::NIT;
     const size_t n = (size_t)nrows * ncols;
-    g.last_launches = 0;
+    tls.last_launches = 0;
     if (dst != nullptr) {
         bool same = true;
         for (int f = 0; f < NIT; f++) same = same && dst[f] == P.it_out[f];
@@ -132,7 +132,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             for (int f = 0; f < Mdl::NCF; f++) P.cf[f] = raw_cf[f];
             RC(ws_get(WS_PACK, n * nframes * Mdl::NCF * sizeof(float), &pack));
             hipLaunchKernelGGL(k_pack_coefficients<Mdl>, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, P, pack, nrows, ncols, n);
-            g.last_launches++;
+            tls.last_launches++;
             // ---- persistent form: one launch, progress counters instead of one launch per front ----
             const int NC = (nrows - 2 + 63 + EX_CH - 1) / EX_CH;
             // schedule table, control block, mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, field, row)
@@ -143,16 +143,16 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             SweepTimer timer(s);
             hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(B * iter * nframes)), dim3(exp_threads<Mdl>()), plds, s, P, pack, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
             timer.stop(1);
-            g.last_launches++;
+            tls.last_launches++;
             const int nb = 2 * ncols + 2 * (nrows - 2);
             hipLaunchKernelGGL(k_fill_borders, dim3((nb + 255) / 256, nframes, NIT), dim3(256), 0, s,
                                P.it_out[0], P.it_out[NIT - 1], NIT, nrows, ncols, n);
-            g.last_launches++;
+            tls.last_launches++;
             HIPCHK(hipGetLastError());
             return PDEIP_OK;
         }
         hipLaunchKernelGGL(k_derive<Mdl>, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, P, aux0, aux1, nrows, ncols, n);
-        g.last_launches++;
+        tls.last_launches++;
         P.cf[Mdl::D0] = aux0;
         P.cf[Mdl::D1] = aux1;
         const dim3 grid((unsigned)(B * iter), (unsigned)nframes);
@@ -161,13 +161,13 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         SweepTimer timer(s);
         for (int m = 0; m <= last_m; m++) {
             hipLaunchKernelGGL(k_sor_exact<Mdl>, grid, dim3(128), lds, s, P, nrows, ncols, A, B, iter, m, omega, n);
-            g.last_launches++;
+            tls.last_launches++;
         }
         timer.stop(last_m + 1);
         const int nb = 2 * ncols + 2 * (nrows - 2);
         hipLaunchKernelGGL(k_fill_borders, dim3((nb + 255) / 256, nframes, NIT), dim3(256), 0, s,
                            P.it_out[0], P.it_out[NIT - 1], NIT, nrows, ncols, n);
-        g.last_launches++;
+        tls.last_launches++;
         HIPCHK(hipGetLastError());
         return PDEIP_OK;
     }
@@ -183,8 +183,16 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             sp = SL::plan(nrows, ncols, SMALL_MAX_SWEEPS, qpref < 1 ? 1 : qpref);
             per_launch = SMALL_MAX_SWEEPS;
         }
-        // a cut frame relaxed in place needs every workgroup resident at once (the load counter below)
-        if (sp.ok && sp.nslabs > 1 && (long)sp.nslabs * nframes > 224) sp.ok = false;
+        // a cut frame relaxed in place needs every workgroup resident at once (the load counter below): at most one workgroup
+        // per compute unit, with an eighth of the device left for whatever else is running
+        if (sp.ok && sp.nslabs > 1) {
+            DeviceState *d = cur_dev();
+            if (d->num_cus == 0) {
+                hipDeviceProp_t prop;
+                d->num_cus = (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
+            }
+            if ((long)sp.nslabs * nframes > (long)d->num_cus - d->num_cus / 8) sp.ok = false;
+        }
         if (sp.ok) {
             RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_small<Mdl>), sp.lds));
             unsigned *counter = nullptr, *abort_word = nullptr;
@@ -211,7 +219,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
                 for (int f = 0; f < NIT; f++) P.it_in[f] = P.it_out[f]; // later launches of the call: in place on the result
             }
             timer.stop(nl);
-            g.last_launches += nl;
+            tls.last_launches += nl;
             HIPCHK(hipGetLastError());
             return PDEIP_OK;
         }
@@ -286,7 +294,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             it += PS;
             flips++;
             nlaunch++;
-            g.last_launches++;
+            tls.last_launches++;
             continue;
         }
         const bool two = fuse && it + 2 <= iter;
@@ -315,7 +323,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
         it += two ? 2 : 1;
         flips++;
         nlaunch++;
-        g.last_launches++;
+        tls.last_launches++;
     }
     timer.stop(nlaunch);
     if (!dst && (flips & 1)) // in place and the last launch wrote the scratch copy
@@ -326,6 +334,20 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
 }
 
 } // namespace
+
+extern "C" int pdeip_debug_persist_order(int B, int T, int affine, int *table)
+{
+    if (B < 1 || T < 1 || table == nullptr) return set_err(PDEIP_ERR_ARG, "pdeip_debug_persist_order: bad arguments");
+    RC(use_device());
+    int *dev = nullptr;
+    const size_t n = PERSIST_TABLE_HDR + (size_t)B * T;
+    HIPCHK(hipMalloc(&dev, n * sizeof(int)));
+    hipLaunchKernelGGL(k_persist_order, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, nullptr, dev, B, T, affine ? 1 : 0);
+    const hipError_t e = hipMemcpy(table, dev, n * sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return set_err(PDEIP_ERR_DEVICE, "pdeip_debug_persist_order: %s", hipGetErrorString(e));
+    return PDEIP_OK;
+}
 
 #ifdef PDEIP_RBP_STAMPS
 extern "C" int pdeip_debug_read_rbp_stamps(unsigned long long *out)
@@ -465,9 +487,9 @@ extern "C" int pdeip_disp_sor_llin_sym4_dev(void *stream, const float *U0, float
             for (int f = 0; f < 6; f++) P.cf[f] = cf[k][f];
             RC(run_sweeps<ModelDispSym4>(s, P, nrows, ncols, 1, iter, omega, mode, col0));
         }
-        launches += g.last_launches;
+        launches += tls.last_launches;
     }
-    g.last_launches = launches;
+    tls.last_launches = launches;
     return PDEIP_OK;
 }
 

@@ -23,7 +23,7 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
     RC(check_dims(who, nrows, ncols, nframes));
     RC(check_mode(who, mode));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    g.last_launches = 0;
+    tls.last_launches = 0;
     if (iter <= 0) return PDEIP_OK;
     const size_t n = (size_t)nrows * ncols, nf = n * (size_t)nframes;
     float *bt, *inv, *scratch = nullptr;
@@ -46,7 +46,7 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
             const int nbk = pde8_pack_blocks(nrows);
             hipLaunchKernelGGL(k_pde8_pack, dim3((unsigned)((nbk + 127) / 128), (unsigned)ncols, (unsigned)nframes), dim3(128), 0, s, pack, TRACE, B, wW,
                                wNW, wN, wNE, wE, wSE, wS, wSW, nrows, ncols, n);
-            g.last_launches++;
+            tls.last_launches++;
             // schedule table, control block, mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, step of the walk)
             PersistCtl ctl{};
             RC(persist_prepare(s, nstrips, iter, nframes, (size_t)nframes * iter * nstrips * (size_t)pde8_persist_chunks(nrows) * EX_CH * sizeof(unsigned long long), &ctl));
@@ -54,17 +54,17 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
             const int nl = pde8_run_exact_persist(s, P, pack, scratch, ctl, nrows, ncols, nframes, iter, omega);
             if (nl < 0) return PDEIP_ERR_DEVICE;
             timer.stop(1);
-            g.last_launches += nl;
+            tls.last_launches += nl;
             HIPCHK(hipGetLastError());
             return PDEIP_OK;
         }
         hipLaunchKernelGGL(k_pde8_divisors, pixel_grid(nrows, ncols, nframes), dim3(256), 0, s, bt, inv, TRACE, B, wW, wNW, wN, wNE, wE, wSE, wS, wSW, nrows, ncols, n);
-        g.last_launches++;
+        tls.last_launches++;
         SweepTimer timer(s);
         const int nl = pde8_run_exact(s, P, scratch, nrows, ncols, nframes, iter, omega);
         if (nl < 0) return PDEIP_ERR_DEVICE; // LDS opt-in refused (message set by ensure_lds)
         timer.stop(nl);
-        g.last_launches += nl;
+        tls.last_launches += nl;
         HIPCHK(hipGetLastError());
         return PDEIP_OK;
     }
@@ -125,7 +125,7 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
         it += two ? 2 : 1;
         flips++;
         nlaunch++;
-        g.last_launches++;
+        tls.last_launches++;
     }
     timer.stop(nlaunch);
     if (flips & 1) HIPCHK(hipMemcpyAsync(X, scratch, nf * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -180,8 +180,14 @@ class SlabSolver:
         self.spent = None
 
     def _room(self, iterate):
-        """Sweeps the budget still covers; refreshes the halo when it covers none."""
+        """Sweeps the budget still covers; refreshes the halo when it covers none.  A single slab has no cut and so no
+        budget to keep: any number of sweeps runs at once."""
+        if self.dom.world == 1:
+            self.spent = 0
+            return 1 << 30
         cap = self.dom.halo
+        if cap < 2:
+            raise ValueError("a halo of %d columns covers no sweep" % cap)
         if self.spent is None or cap - self.spent < 2:
             self.dom.exchange(iterate)
             self.spent = 0

@@ -77,3 +77,35 @@ def test_set_devices_on_a_one_gpu_box(pdeip):
         capi.set_devices([0, 0])
     with pytest.raises(capi.PdeipError):
         capi.set_devices([0, 63])
+
+
+@pytest.mark.parametrize("nthreads", [2, 3])
+def test_virtual_slabs_on_worker_threads(pdeip, oracle, slabs, nthreads):
+    """PDEIP_VIRTUAL_THREADS: the slabs of a one-device group are dealt over n worker threads, each with a device-state slot of
+    its own -- the std::thread branch a real device group takes, with everything the workers share (error text and launch
+    counter per thread, atomic workspace generation, locked profiling slots).  Same bits as the single domain, the launch
+    counter is the sum over the workers, and a worker's failure reaches the caller with its own message."""
+    api, lib = pdeip.mex_api, pdeip.capi.load()
+    api.set_mode(1)
+    os.environ["PDEIP_VIRTUAL_THREADS"] = str(nthreads)
+    try:
+        f = lambda v: np.float32(v)
+        for name, p, omega in [("Oflow_sor_elin4_2d", pb.elin4(961, 128, 300, nan_frac=0.01), 1.9),
+                               ("Disp_sor_llin4_2d", pb.disp4(962, 96, 260, nan_frac=0.01), 1.9),
+                               ("PDEsolver8", pb.pde8(963, 64, 240, nframes=2), 1.75)]:
+            for rep in range(3):  # repeated: the workers' slots keep their workspace between calls
+                slabs(0)
+                single = getattr(api, name)(*p.values(), f(4), f(omega), f(1))
+                slabs(5)
+                lib.pdeip_profile_enable(1)
+                split = getattr(api, name)(*p.values(), f(4), f(omega), f(1))
+                lib.pdeip_profile_enable(0)
+                assert lib.pdeip_last_launch_count() >= 5, "five slabs, at least one launch each"
+                single, split = [x if isinstance(x, tuple) else (x,) for x in (single, split)]
+                for a, b in zip(single, split):
+                    assert pb.bit_equal(b, a), "%s threads=%d: %s" % (name, nthreads, pb.describe_mismatch(b, a))
+    finally:
+        os.environ.pop("PDEIP_VIRTUAL_THREADS", None)
+        slabs(0)
+        api.set_mode(0)
+        lib.pdeip_release()

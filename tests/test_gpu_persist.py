@@ -173,3 +173,33 @@ def test_schedule_kinds_give_the_same_bits(pdeip, oracle, knob):
             os.environ.pop("PDEIP_PERSIST_XCD", None)
         else:
             os.environ["PDEIP_PERSIST_XCD"] = old
+
+
+def _host_order(B, T, affine):
+    """The schedule table as round 2 built it on the host: eight lists, each in (key = b + 2t, t) order."""
+    table, items = [0] * 16, []
+    for x in range(8):
+        table[x] = len(items)
+        if not affine and x > 0:
+            continue
+        for key in range((B - 1) + 2 * (T - 1) + 1):
+            for t in range(T):
+                b = key - 2 * t
+                if 0 <= b < B and (not affine or (b & 7) == x):
+                    items.append(b | (t << 16))
+    table[8] = len(items)
+    return table[:9], items
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 7), (5, 3), (8, 4), (9, 4), (60, 4), (60, 20), (23, 40), (200, 2)])
+def test_schedule_table_built_on_the_device(pdeip, B, T):
+    """k_persist_order writes each item at its rank; the table equals the host-built one (both list kinds), so every dependency
+    of an item -- (b-1,t), (b,t-1), (b+1,t-1) -- comes before it in its list order's key."""
+    import ctypes
+    lib = pdeip.capi.load()
+    for affine in (0, 1):
+        buf = (ctypes.c_int * (16 + B * T))()
+        assert lib.pdeip_debug_persist_order(B, T, affine, buf) == 0, pdeip.capi.last_error()
+        hdr, items = _host_order(B, T, affine)
+        assert list(buf[:9]) == hdr, (B, T, affine, list(buf[:9]), hdr)
+        assert list(buf[16:]) == items, (B, T, affine)
