@@ -467,7 +467,7 @@ __global__ void k_pack_coefficients(SweepPlanes<Mdl> P, float *pack, int nrows, 
     const size_t q = pos + (size_t)blockIdx.z * frame_stride;
     float k[Mdl::NCF];
 #pragma unroll
-    for (int f = 0; f < Mdl::NCF; f++) k[f] = P.cf[f][q];
+    for (int f = 0; f < Mdl::NCF; f++) k[f] = __builtin_nontemporal_load(P.cf[f] + q); // read once: leave the Infinity Cache to the packed copy
     Mdl::derive(k);
     float *dst = pack + q * Mdl::NCF;
 #pragma unroll

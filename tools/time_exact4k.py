@@ -1,0 +1,21 @@
+"""Exact-order elin4 at 2160 x 3840 (and 1080p): us per call for iter in argv (default 1 4), 20 calls each; environment knobs as set."""
+import importlib, sys, time
+import torch
+sys.path.insert(0, ".")
+dev = importlib.import_module("pde-based-image-processing_amd.device")
+iters = [int(a) for a in sys.argv[1:]] or [1, 4]
+for nr, nc in ((2160, 3840), (1080, 1920)):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    P = lambda lo, hi: torch.empty((nc, nr), device="cuda").uniform_(lo, hi, generator=g)
+    U, V = P(-1, 1), P(-1, 1)
+    coef = [P(-0.5, 0.5) for _ in range(3)] + [P(0.1, 1), P(0.1, 1)] + [P(0.5, 5) for _ in range(4)]
+    for it in iters:
+        fn = lambda: dev.oflow_sor_elin4(U, V, *coef, it, 1.0, 0)
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20): fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 20
+        print("%dx%d iter %2d  %8.1f us  %7.0f sweeps/s" % (nr, nc, it, dt * 1e6, it / dt), flush=True)
+dev.sync_check()
