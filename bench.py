@@ -120,7 +120,7 @@ def cpu_red_black_all_cores(U, V, coef, calls):
     return calls * ITER / (time.perf_counter() - t0), int(used)
 
 
-def host_call(capi, U, V, coef, mode, reps=3):
+def host_call(capi, U, V, coef, mode, reps=7):
     """Median wall time of pdeip_oflow_sor_elin4 (host pointers in, host pointers out) for one iter=4 call at 4K."""
     lib = capi.load()
     hu, hv = U.cpu().numpy().copy(), V.cpu().numpy().copy()
@@ -232,56 +232,105 @@ def main():
         def step_rb():  # the slab form of the same thing: the solver returns the plane set that holds the iterate now
             state[0] = solver.solve_pingpong(state[0], coef, ITER, OMEGA)
 
-    # Untimed setup before the W warm-up steps: bring the device to its steady clocks.  With only the driver's W = 5 the timed steps run
-    # on a part still ramping up (measured on the same box, K = 50: W = 5 26.9 k, W = 50 29.2 k, W = 200 32.9 k sweeps/s); the metric
-    # is a steady-state throughput, so the ramp is taken out here -- 300 calls, ~40 ms, reported as config.prewarm_steps.
+    # The driver's own warm-up (W steps) and K timed steps first, on a device that has just been handed over: `value_cold`.
+    # Then an untimed pre-warm brings the device to its steady clocks (measured on one box, K = 50: W = 5 26.9 k, W = 50 29.2 k,
+    # W = 200 32.9 k sweeps/s): the metric is a steady-state throughput, so `value` is W more warm-up steps + K timed steps AFTER
+    # PREWARM untimed calls (reported as config.prewarm_steps), and the same K-step loop is repeated REPEATS - 1 more times: `value_repeats`
+    # holds min / median / max of all of them (the timed region is a few ms: single runs move by 2-4 %).
+    calls_done = [0]
+    inner_step = step_rb
+
+    def step_counted():
+        inner_step()
+        calls_done[0] += 1
+
+    step_rb = step_counted
+    cold_dt, _, _ = timed(step_rb, args.steps, args.warmup)
+    value_cold = args.steps * ITER / cold_dt
     PREWARM = env_int_py("PDEIP_BENCH_PREWARM", 300)
     for _ in range(PREWARM):
         step_rb()
     barrier()
     dt, ms, nl = timed(step_rb, args.steps, args.warmup)
     value = args.steps * ITER / dt
+    REPEATS = max(1, env_int_py("PDEIP_BENCH_REPEATS", 5))
+    rates = [value]
+    for _ in range(REPEATS - 1):
+        rdt, _, _ = timed(step_rb, args.steps, 0)
+        rates.append(args.steps * ITER / rdt)
     if world == 1:
         U, V = sets[cur[0]]
     else:
         U, V = state[0]
     if not (bool(torch.isfinite(U).all()) and bool(torch.isfinite(V).all())):
         raise SystemExit("bench.py: the iterate is not finite after the timed loop (the workload must converge)")
+    # N > 1: what the slabs hold must be, bit for bit, what ONE domain holds after the same number of red-black sweeps.  Rank 0
+    # gathers the owned columns and relaxes the whole frame by the same number of solver calls (outside every timed region).
+    parity_slabs = None
+    if world > 1:
+        gU, gV = dom.gather_owned(U), dom.gather_owned(V)
+        if rank == 0:
+            a, b2 = (U0.clone(), V0.clone()), (torch.empty_like(U0), torch.empty_like(V0))
+            for _ in range(calls_done[0]):
+                dev.oflow_sor_elin4(a[0], a[1], *coef_full, ITER, OMEGA, capi.MODE_RED_BLACK, out=b2)
+                a, b2 = b2, a
+            torch.cuda.synchronize()
+            du, dv = (gU - a[0]).abs().max().item(), (gV - a[1]).abs().max().item()
+            parity_slabs = {"max_abs": float(max(du, dv)), "bit_identical": bool(torch.equal(gU, a[0]) and torch.equal(gV, a[1])),
+                            "sweeps": calls_done[0] * ITER,
+                            "what": "owned columns of all ranks gathered on rank 0 vs the single-domain red-black solver after the same %d calls" % calls_done[0]}
+            del a, b2
+        del gU, gV
     # per launch: this rank's pixels (owned + halo columns are all relaxed by the launch; count owned only)
     own_px = (dom.c1 - dom.c0) * NROWS
     launch_s = ms * 1e-3 / max(nl, 1)
-    # the library fuses two sweeps into one launch where it can: algorithmic bytes per launch follow
+    # the library fuses up to four sweeps into one launch (k_sor_rbp): a launch of k sweeps has to move every plane ONCE --
+    # 9 coefficient planes + the iterate in + the iterate out = 13 planes -- whatever k is.  That is the byte count the launch
+    # is priced with (`achieved`, `frac`); SURVEY 8(d)'s per-sweep figure (52 B x pixels x sweeps in the launch) is the
+    # EFFECTIVE rate beside it, which exceeds the HBM peak by construction once sweeps are fused.
     sweeps_per_launch = args.steps * ITER / max(nl, 1)
-    bytes_per_launch = BYTES_PER_PIXEL_SWEEP * own_px * sweeps_per_launch
-    achieved = bytes_per_launch / launch_s / 1e9
+    fused_min_bytes = (9 + 2 + 2) * 4.0 * own_px
+    effective_bytes = BYTES_PER_PIXEL_SWEEP * own_px * sweeps_per_launch
+    achieved = fused_min_bytes / launch_s / 1e9
+    effective = effective_bytes / launch_s / 1e9
+    k_fused = int(round(sweeps_per_launch))
+    kernel_name = ("k_sor_rbp<ModelElin4, %d sweeps per launch>" % k_fused) if k_fused >= 4 else ("k_sor_rb<ModelElin4, sweeps per launch = %d>" % k_fused)
 
     out = {
         "metric": "SOR iterations/sec (3840x2160 flow)", "value": round(value, 2), "unit": "iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value_cold": round(value_cold, 2),
+        "value_repeats": {"n": len(rates), "min": round(min(rates), 2), "median": round(sorted(rates)[len(rates) // 2], 2), "max": round(max(rates), 2)},
         "config": {"workload": "Oflow_sor_elin4_2d point SOR, 2160x3840 f32 frame, iter=4/call, omega=1.9, resident in HBM",
                    "ordering": "red_black", "prewarm_steps": PREWARM, "decomposition": "column slabs, %d-column halo, 1 RCCL exchange per %d sweeps" % (2 * k_ex, k_ex)
-                   if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": "k_sor_rb<ModelElin4, sweeps per launch = %d>" % round(sweeps_per_launch),
+                   if world > 1 else "single GPU",
+                   "knobs": {k: os.environ[k] for k in sorted(os.environ) if k.startswith("PDEIP_")}},
+        "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "launch_us": round(launch_s * 1e6, 2), "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "launch_us": round(launch_s * 1e6, 2), "bytes_per_launch": fused_min_bytes,
                      "sweeps_per_launch": round(sweeps_per_launch, 3),
-                     "note": "achieved/frac = ALGORITHMIC bytes (52 B x pixels x sweeps in the launch) / launch time: an effective rate -- a "
-                             "launch that fuses k sweeps reads the nine coefficient planes once for all k, so it can exceed what HBM "
-                             "delivers; frac_hbm = measured traffic / time / peak is the HBM utilisation"},
+                     "effective_achieved": round(effective, 1), "effective_frac": round(effective / HBM_PEAK_GBS, 4),
+                     "effective_bytes_per_launch": effective_bytes,
+                     "limiter": "instruction issue and the barrier per column of the wave pipeline, not HBM (SQ_WAIT_ANY 46 % of wave cycles: "
+                                "profiles/README.md, DESIGN.md kernel table)",
+                     "note": "achieved/frac = the bytes a launch of k fused sweeps must move (13 planes x 4 B x pixels) / launch time / peak; "
+                             "effective_* = SURVEY 8(d)'s per-sweep figure (52 B x pixels x k sweeps) / launch time -- an effective rate that can "
+                             "exceed what HBM delivers; frac_hbm = measured traffic / time / peak is the HBM utilisation, overfetch = traffic / bytes_per_launch"},
     }
+    if parity_slabs is not None:
+        out["parity_slabs"] = parity_slabs
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if world == 1 and os.path.exists(tr):
         try:
             table = json.load(open(tr))
-            k_fused = int(round(sweeps_per_launch))
             key = "k_sor_rb%s_elin4_2160x3840_bytes_per_launch" % ("" if k_fused == 1 else k_fused)
             traffic = table.get(key)
             out["roofline"]["traffic"] = traffic
             if traffic:
                 # what the memory system actually moved for this launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes)
-                fused_min = (9 + 2 + 2) * 4.0 * own_px   # a perfectly fused launch: every plane once, whatever the sweep count
+                fused_min = fused_min_bytes
                 out["roofline"]["hbm_gbs_from_traffic"] = round(traffic / launch_s / 1e9, 1)
                 out["roofline"]["frac_hbm"] = round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4)
                 out["roofline"]["overfetch"] = round(traffic / fused_min, 3)
@@ -296,8 +345,8 @@ def main():
         def step_exact():
             dev.oflow_sor_elin4(Ue, Ve, *coef_full, ITER, OMEGA, capi.MODE_EXACT_ORDER)
 
-        e_steps = max(5, args.steps // 10)
-        edt, ems, enl = timed(step_exact, e_steps, max(2, args.warmup // 10))
+        e_steps = max(20, args.steps // 10)   # every reported leg times at least 20 calls
+        edt, ems, enl = timed(step_exact, e_steps, max(3, args.warmup // 10))
         e_launch_s = ems * 1e-3 / max(enl, 1)
         e_bytes = BYTES_PER_PIXEL_SWEEP * N * ITER * e_steps / max(enl, 1)  # tiles of one front per launch
         out["exact_order"] = {
@@ -311,8 +360,8 @@ def main():
         def step_exact20():
             dev.oflow_sor_elin4(Ue, Ve, *coef_full, 20, OMEGA, capi.MODE_EXACT_ORDER)
 
-        l_steps = max(3, args.steps // 40)
-        ldt, _, _ = timed(step_exact20, l_steps, 1)
+        l_steps = max(20, args.steps // 40)
+        ldt, _, _ = timed(step_exact20, l_steps, 2)
         out["exact_order"]["iter20_per_call"] = {"value": round(l_steps * 20 / ldt, 2), "unit": "iterations/s",
                                                  "ms_per_call": round(ldt / l_steps * 1e3, 4), "kernel": "k_sor_exact_persist<ModelElin4>"}
         capi.call("pdeip_persist_error")
@@ -370,7 +419,7 @@ def main():
                 if mode == capi.MODE_EXACT_ORDER:
                     hc["exact_order_max_abs_vs_cpu"] = float(max(np.abs(ou.astype(np.float64) - first[0]).max(), np.abs(ov.astype(np.float64) - first[1]).max()))
             hc["bytes_over_pcie"] = (13 + 2) * 4 * N
-            hc["workload"] = "pdeip_oflow_sor_elin4, host pointers, 2160x3840, iter=4, median of 3 calls"
+            hc["workload"] = "pdeip_oflow_sor_elin4, host pointers, 2160x3840, iter=4, median of 7 calls"
             out["host_call"] = hc
             del Ur, Vr, Ux, Vx
             # ---- solver 2 (alternating line relaxation, the MATLAB drivers' default), same frame ----------
@@ -417,13 +466,13 @@ def main():
                 lv = fl.FlowLlinLevel(prm, mode=mode)
                 gU, gV = lv.run(dG0, dG1, dZ, dZ, dI0, dI1)
                 torch.cuda.synchronize()
-                laps = []  # median of five runs: one run in ~20 catches an allocator stall of tens of ms (seen twice in a mean of three)
-                for _ in range(5):
+                laps = []  # median of 21 runs: one run in ~20 catches an allocator stall of tens of ms (seen twice in a mean of three)
+                for _ in range(21):
                     t0 = time.perf_counter()
                     gU, gV = lv.run(dG0, dG1, dZ, dZ, dI0, dI1)
                     torch.cuda.synchronize()
                     laps.append(time.perf_counter() - t0)
-                level[name + "_ms"] = round(sorted(laps)[2] * 1e3, 3)
+                level[name + "_ms"] = round(sorted(laps)[len(laps) // 2] * 1e3, 3)
                 if name == "exact_order":
                     t0 = time.perf_counter()
                     wU, wV = ms.flow_level(sys.modules["oracle_lib"], ms.rgb2grad(I0), ms.rgb2grad(I1), Z, Z, lp, I2t0=I0, I2t1=I1)
@@ -449,10 +498,10 @@ def main():
                                  ("symmetric_", lambda lv=fl.DispSymLevel(prm, mode=mode): lv.run(dL, dR, dZ5, dZ5, 2.0))):
                     run(); torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    for _ in range(3):
+                    for _ in range(20):
                         run()
                     torch.cuda.synchronize()
-                    dl[tag + name] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+                    dl[tag + name] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
             out["disparity_level"] = dl
             del dL, dR, gL, gR, dZ5
             # ---- whole drivers (pyramid + every level resident; host numpy frames in, flow out), as runme.m calls them --------
@@ -463,19 +512,21 @@ def main():
             for name, kw in (("red_black_sor", dict(mode=capi.MODE_RED_BLACK, solver=1, omega=1.5)), ("zebra_alr", dict(mode=capi.MODE_RED_BLACK, omega=1.5))):
                 drivers.FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", **kw)
                 torch.cuda.synchronize()
+                nrep = 20 if name == "red_black_sor" else 5   # the zebra run is 0.2 s a piece
                 t0 = time.perf_counter()
-                drivers.FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", **kw)
+                for _ in range(nrep):
+                    drivers.FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", **kw)
                 torch.cuda.synchronize()
-                dr[name] = round((time.perf_counter() - t0) * 1e3, 1)
+                dr[name] = round((time.perf_counter() - t0) / nrep * 1e3, 1)
                 # graph=True: the resident part replayed from a HIP graph captured on the first call for this frame size
                 ref = drivers.FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", **kw)
                 drivers.FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", graph=True, **kw)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(3):
+                for _ in range(nrep):
                     got = drivers.FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", graph=True, **kw)
                 torch.cuda.synchronize()
-                dr[name + "_graph"] = round((time.perf_counter() - t0) / 3 * 1e3, 1)
+                dr[name + "_graph"] = round((time.perf_counter() - t0) / nrep * 1e3, 1)
                 dr[name + "_graph_same_bits"] = bool(all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got)))
             out["driver_nd_1080p"] = dr
             del Iseq
@@ -489,9 +540,10 @@ def main():
                 lv.run(gI, gI)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                lv.run(gI, gI)
+                for _ in range(20):
+                    lv.run(gI, gI)
                 torch.cuda.synchronize()
-                tv[name + "_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+                tv[name + "_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 2)
             out["tv_level"] = tv
             del gI
             # ---- BASELINE config C4 with its outer structure: the FAS full-multigrid driver at 2160x3840, resident ------
@@ -509,17 +561,19 @@ def main():
                 drv = fas.FasFmgFlow(prm, mode=mode)
                 drv.run(d0, d1)
                 torch.cuda.synchronize()
+                nrep = 20 if name == "red_black_sor" else 5   # zebra: 0.16 s a run, exact order 57 ms
                 t0 = time.perf_counter()
-                drv.run(d0, d1)
+                for _ in range(nrep):
+                    drv.run(d0, d1)
                 torch.cuda.synchronize()
-                fmg[name] = round((time.perf_counter() - t0) * 1e3, 2)
+                fmg[name] = round((time.perf_counter() - t0) / nrep * 1e3, 2)
                 if mode == capi.MODE_RED_BLACK:
                     # the same launches replayed from a captured HIP graph (graphs.py): bit-identical, no per-launch host work;
                     # the eager figure above is bound by the host enqueueing ~1 700 launches
                     ref = [t.clone() for t in drv.run(d0, d1)]
                     drv.run_graph(d0, d1)
                     torch.cuda.synchronize()
-                    reps = 3
+                    reps = 20
                     t0 = time.perf_counter()
                     for _ in range(reps):
                         got = drv.run_graph(d0, d1)
@@ -548,7 +602,7 @@ def main():
             def planes(nr, nc, k, lo=0.5, hi=5.0):
                 return [torch.empty((nc, nr), device=device, dtype=torch.float32).uniform_(lo, hi, generator=gen) for _ in range(k)]
 
-            def rate(fn, it, reps=5):
+            def rate(fn, it, reps=20):
                 fn(); torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(reps):
@@ -566,7 +620,7 @@ def main():
                 cfgs.setdefault("C2_llin4_1080x1920_iter4", {})[tag] = rate(lambda: dev.oflow_sor_llin4(Uc, Vc, dUc, dVc, a * b, -a * c, -b * c, a * a, b * b, *w, 4, OMEGA, mode), 4)
                 nr, nc = 2160, 3840    # C3 TV denoising, 8 neighbours, inner_iter = 4
                 w8 = planes(nr, nc, 8); Xc, Bc = planes(nr, nc, 2, 0, 1); TR = 1 + sum(w8)
-                cfgs.setdefault("C3_pde8_2160x3840_iter4", {})[tag] = rate(lambda: dev.pde_sor8(Xc, TR, Bc, *w8, 4, 1.75, mode), 4, reps=3)
+                cfgs.setdefault("C3_pde8_2160x3840_iter4", {})[tag] = rate(lambda: dev.pde_sor8(Xc, TR, Bc, *w8, 4, 1.75, mode), 4)
                 del w8, TR
                 nr, nc = 1988, 2880    # C5 disparity, iter = 4
                 w = planes(nr, nc, 4); Ud, = planes(nr, nc, 1, -3, 3); dUd, Cud = planes(nr, nc, 2, -0.5, 0.5); Dud, = planes(nr, nc, 1, 0.05, 2)

@@ -469,6 +469,32 @@ int pdeip_median3_dev(void *stream, const float *A, const float *B, int nrows, i
 int pdeip_median3_pair_dev(void *stream, const float *A0, const float *B0, const float *A1, const float *B1, int nrows, int ncols,
                            float *out0, float *out1);
 
+/* ---- whole drivers, resident on the device (csrc/pdeip_drivers.hip) --------------------------------------------------------
+ * What `runme.m` calls first -- FlowEminND_llin_2D_v10 (runme.m:44) and DispEminND_llin_2D (runme.m:20) -- as ONE host-pointer
+ * call each: the frames go up once, the coarse-to-fine loop (pyramid, warps, derivatives, robust assembly, diffusion weights,
+ * solver calls, medians, up-scaling) runs on device planes, the result comes down once.  A MATLAB session reaches them through
+ * the stubs mex/FlowEminND_llin_2D_v10_gpu.c and mex/DispEminND_llin_2D_gpu.c.  The pyramid's IPT calls
+ * (imresize, imfilter, fspecial) are OUR definitions of them (pyramid.py); everything between them is the arithmetic the
+ * per-stage entry points above are tested for. */
+#define PDEIP_TERM_NONE 0
+#define PDEIP_TERM_RGB 1
+#define PDEIP_TERM_GRAD 2     /* first term only: rgb2grad */
+#define PDEIP_TERM_GRADMAG 3  /* second term only: gradient magnitude through SndDerivatives5 */
+/* param struct of both drivers (FlowEminND_llin_2D_v10.m:52-67, DispEminND_llin_2D.m:51-66); a member that is <= 0 (or NaN)
+ * keeps the driver's own default; `scales` limits the number of pyramid scales (param.scales).  NULL: all defaults. */
+typedef struct pdeip_driver_params {
+    double alpha, omega, gammaS, b1, b2, scl_factor;
+    int firstLoop, secondLoop, iter, solver, scales;
+} pdeip_driver_params;
+/* [U V] = FlowEminND_llin_2D_v10(Iin, channels, fstTerm, sndTerm, param): Iin = cat(3, frame0, frame1), single, 0..255,
+ * [nrows x ncols x 2*channels] column-major; fst_term PDEIP_TERM_RGB | _GRAD, snd_term _NONE | _RGB | _GRADMAG; Us, Vs:
+ * param.Us / param.Vs, double [nrows x ncols] or NULL; U, V: [nrows x ncols].  Ordering: pdeip_set_mode / PDEIP_MODE. */
+int pdeip_flow_nd_llin(const float *Iin, int nrows, int ncols, int channels, int fst_term, int snd_term, const pdeip_driver_params *prm,
+                       const double *Us, const double *Vs, float *U, float *V);
+/* U = DispEminND_llin_2D(Il, Ir, fstTerm, sndTerm, param): Il, Ir single 0..255 [nrows x ncols x channels]; Us: param.Us or NULL. */
+int pdeip_disp_nd_llin(const float *Il, const float *Ir, int nrows, int ncols, int channels, int fst_term, int snd_term,
+                       const pdeip_driver_params *prm, const double *Us, float *U);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,12 +19,14 @@ COMMON = ["pdeip_ctx.hpp", PUBLIC]
 # translation unit -> the headers it includes (besides COMMON)
 UNITS = {
     "pdeip_ctx.hip": [],
-    "pdeip_sor5.hip": ["pdeip_models.hpp", "pdeip_pointwise.hpp", "pdeip_sor_exact.hpp", "pdeip_sor_walk.hpp", "pdeip_sor_rb.hpp", "pdeip_sor_rbp.hpp", "pdeip_sor_small.hpp", "pdeip_persist_host.hpp"],
+    "pdeip_sor5.hip": ["pdeip_models.hpp", "pdeip_pointwise.hpp", "pdeip_sor_exact.hpp", "pdeip_walk_host.hpp", "pdeip_sor_rb.hpp", "pdeip_sor_rbp.hpp", "pdeip_sor_small.hpp", "pdeip_persist_host.hpp"],
+    "pdeip_walk5.hip": ["pdeip_models.hpp", "pdeip_sor_exact.hpp", "pdeip_walk_host.hpp", "pdeip_sor_walk.hpp"],
     "pdeip_sor9.hip": ["pdeip_models.hpp", "pdeip_pointwise.hpp", "pdeip_sor_pde8.hpp", "pdeip_sor_pde8_persist.hpp", "pdeip_sor_exact.hpp", "pdeip_sor_rb.hpp", "pdeip_persist_host.hpp"],
     "pdeip_line.hip": ["pdeip_alr.hpp", "pdeip_models.hpp"],
     "pdeip_stages.hip": ["pdeip_models.hpp", "pdeip_pointwise.hpp", "pdeip_flow.hpp", "pdeip_fas.hpp", "pdeip_sym.hpp", "pdeip_pyr.hpp",
                          "pdeip_tv.hpp"],
     "pdeip_host.hip": [],
+    "pdeip_drivers.hip": [],
     "pdeip_multi.hip": [],
 }
 # -ffp-contract=off is part of the parity contract (the reference is FMA-free C).

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpdeip.so")
+LIB_PATH = os.environ.get("PDEIP_LIB") or os.path.join(HERE, "libpdeip.so")  # PDEIP_LIB: a diagnostic build of the same library (tools/)
 
 PDEIP_OK = 0
 PDEIP_ERR_ARG = 1

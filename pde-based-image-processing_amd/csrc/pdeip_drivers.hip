@@ -1,0 +1,501 @@
+// pdeip_drivers.hip -- libpdeip.so: the two drivers runme.m leads with, as host-pointer entry points that keep a whole
+// coarse-to-fine run resident on the device.
+//
+//   [U V] = FlowEminND_llin_2D_v10(Iin, channels, fstTerm, sndTerm, ...)   matlab/optical_flow/FlowEminND_llin_2D_v10.m:52-369
+//   U     = DispEminND_llin_2D(Il, Ir, fstTerm, sndTerm, ...)              matlab/disparity/DispEminND_llin_2D.m:51-316
+//
+// A MATLAB session that only swaps the MEX gateways pays 13-17 planes of PCIe traffic per solver call (7.8 ms per 4K call,
+// INTEGRATION.md); calling these instead moves the frames up once and the flow down once.  The level loop below is host
+// control flow around the library's own device entry points -- the same `_dev` stage kernels, in the same order and with
+// the same arguments, as the Python drivers (drivers.py / flow_level.py / pyramid.py), which the tests compare with bit
+// for bit.  The pyramid's imresize / imfilter / fspecial are the definitions of pyramid.py (csrc/pdeip_pyr.hpp), there
+// being no Image Processing Toolbox to compare with.  Ordering and solver as everywhere: pdeip_set_mode / PDEIP_MODE,
+// param.solver.
+#include "pdeip_ctx.hpp"
+
+#include <cmath>
+#include <utility>
+#include <vector>
+
+using namespace pdeip;
+
+namespace {
+
+__global__ void k_scale(float *out, const float *in, size_t n, float s, int divide)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = divide ? in[i] / s : in[i] * s; // a true division where MATLAB divides (Iin ./ 255)
+}
+
+// One run: a stream, a device arena and a dry mode.  The arena is one cached workspace buffer per device, bump-allocated;
+// a run is played twice -- dry (nothing is launched: the sizes only depend on the frame's dimensions) to learn how much it
+// needs, then for real.
+struct Run {
+    hipStream_t s = nullptr;
+    bool dry = true;
+    int rc = PDEIP_OK, mode = PDEIP_MODE_EXACT_ORDER;
+    char *base = nullptr;
+    size_t used = 0, peak = 0;
+    void *take(size_t bytes)
+    {
+        const size_t at = (used + 255) & ~(size_t)255;
+        used = at + bytes;
+        if (used > peak) peak = used;
+        return base + at; // dry: base is null and nothing dereferences it
+    }
+    float *planes(int nrows, int ncols, int frames = 1) { return static_cast<float *>(take(sizeof(float) * (size_t)nrows * ncols * frames)); }
+    double *dplane(int nrows, int ncols) { return static_cast<double *>(take(sizeof(double) * (size_t)nrows * ncols)); }
+    size_t mark() const { return used; }
+    void release(size_t m) { used = m; }
+};
+#define DO(R, expr)                                                \
+    do {                                                           \
+        if (!(R).dry && (R).rc == PDEIP_OK) (R).rc = (expr);       \
+    } while (0)
+#define DOHIP(R, expr)                                                                                                      \
+    do {                                                                                                                    \
+        if (!(R).dry && (R).rc == PDEIP_OK && (expr) != hipSuccess) (R).rc = set_err(PDEIP_ERR_DEVICE, "%s failed", #expr); \
+    } while (0)
+
+void scale(Run &R, float *out, const float *in, size_t n, float s, bool divide)
+{
+    if (R.dry || R.rc != PDEIP_OK) return;
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, R.s, out, in, n, s, divide ? 1 : 0);
+}
+
+struct Params { // the drivers' parameter structs, defaults filled in
+    double alpha, omega, gammaS, b1, b2, scl_factor;
+    int firstLoop, secondLoop, iter, solver, scales;
+};
+Params merge(const pdeip_driver_params *u, const Params &d)
+{
+    Params p = d;
+    if (u == nullptr) return p;
+    auto D = [](double v, double dflt) { return (v > 0.0) ? v : dflt; }; // <= 0 or NaN: the driver's default
+    auto I = [](int v, int dflt) { return v > 0 ? v : dflt; };
+    p.alpha = D(u->alpha, d.alpha);
+    p.omega = D(u->omega, d.omega);
+    p.gammaS = D(u->gammaS, d.gammaS);
+    p.b1 = D(u->b1, d.b1);
+    p.b2 = D(u->b2, d.b2);
+    p.scl_factor = D(u->scl_factor, d.scl_factor);
+    p.firstLoop = I(u->firstLoop, d.firstLoop);
+    p.secondLoop = I(u->secondLoop, d.secondLoop);
+    p.iter = I(u->iter, d.iter);
+    p.solver = I(u->solver, d.solver);
+    p.scales = I(u->scales, d.scales);
+    return p;
+}
+
+// fspecial('gaussian', [size size], sigma) as pyramid.py states it (row-major doubles), before the division by the sum
+std::vector<double> gaussian(int size, double sigma)
+{
+    const int r = size / 2;
+    std::vector<double> g((size_t)size * size);
+    for (int a = -r; a <= r; a++)
+        for (int b = -r; b <= r; b++) g[(size_t)(a + r) * size + (b + r)] = std::exp(-((double)(a * a) + (double)(b * b)) / (2.0 * sigma * sigma));
+    return g;
+}
+// numpy.ndarray.sum() of a contiguous float64 array of n < 128 elements: eight running sums r[0..7] over i = 0, 8, 16, ... then
+// ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), then the tail added one by one (numpy/core/src/umath/loops_utils.h.src,
+// pairwise_sum).  The Gaussian mask is divided by this sum; pyramid.py (numpy) is the definition the tests compare with.
+double numpy_sum(const std::vector<double> &a)
+{
+    const size_t n = a.size();
+    if (n < 8) {
+        double r = 0.0; // numpy: res = 0.; res += a[i] (with a -0.0 start that does not matter for positive terms)
+        for (size_t i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    size_t i = 8;
+    for (; i + 8 <= n; i += 8)
+        for (int k = 0; k < 8; k++) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+std::vector<double> gaussian_mask(int size, double sigma)
+{
+    std::vector<double> g = gaussian(size, sigma);
+    const double s = numpy_sum(g);
+    for (double &v : g) v /= s;
+    return g;
+}
+
+// imresize(A, [out_rows out_cols], 'bilinear') of a DOUBLE array on the host, as pyramid.resize(..., out_dtype=float64) does it:
+// triangle kernel at MATLAB's pixel-centre convention, stretched by 1/scale when shrinking, taps normalised, rows first, then
+// columns, every sum left to right.  A: column-major [nrows x ncols].  (The a-priori fields only: a few small planes per run.)
+struct Taps {
+    int T = 0;
+    std::vector<int> idx;   // [n_out][T], clamped
+    std::vector<double> w;  // [n_out][T], normalised
+};
+Taps resize_taps(int n_in, int n_out)
+{
+    Taps t;
+    const double scale = (double)n_out / (double)n_in;
+    const double stretch = scale >= 1.0 ? 1.0 : 1.0 / scale;
+    const double width = 1.0 * stretch;
+    t.T = (int)std::ceil(2.0 * width) + 2;
+    t.idx.resize((size_t)n_out * t.T);
+    t.w.resize((size_t)n_out * t.T);
+    for (int o = 0; o < n_out; o++) {
+        const double x = ((double)o + 0.5) / scale - 0.5;
+        const long first = (long)std::floor(x - width);
+        double total = 0.0;
+        for (int k = 0; k < t.T; k++) {
+            const long id = first + k;
+            const double a = std::fabs(((double)id - x) / stretch);
+            const double wk = (1.0 - a) > 0.0 ? (1.0 - a) : 0.0;
+            t.w[(size_t)o * t.T + k] = wk;
+            total = k == 0 ? wk : total + wk;
+            t.idx[(size_t)o * t.T + k] = (int)(id < 0 ? 0 : (id > n_in - 1 ? n_in - 1 : id));
+        }
+        for (int k = 0; k < t.T; k++) t.w[(size_t)o * t.T + k] /= total;
+    }
+    return t;
+}
+std::vector<double> resize_double(const std::vector<double> &A, int nrows, int ncols, int out_rows, int out_cols)
+{
+    const Taps r = resize_taps(nrows, out_rows), c = resize_taps(ncols, out_cols);
+    std::vector<double> T1((size_t)out_rows * ncols), out((size_t)out_rows * out_cols);
+    for (int j = 0; j < ncols; j++)
+        for (int o = 0; o < out_rows; o++) {
+            double acc = r.w[(size_t)o * r.T] * A[(size_t)j * nrows + r.idx[(size_t)o * r.T]];
+            for (int k = 1; k < r.T; k++) acc = acc + r.w[(size_t)o * r.T + k] * A[(size_t)j * nrows + r.idx[(size_t)o * r.T + k]];
+            T1[(size_t)j * out_rows + o] = acc;
+        }
+    for (int o2 = 0; o2 < out_cols; o2++)
+        for (int o = 0; o < out_rows; o++) {
+            double acc = c.w[(size_t)o2 * c.T] * T1[(size_t)c.idx[(size_t)o2 * c.T] * out_rows + o];
+            for (int k = 1; k < c.T; k++) acc = acc + c.w[(size_t)o2 * c.T + k] * T1[(size_t)c.idx[(size_t)o2 * c.T + k] * out_rows + o];
+            out[(size_t)o2 * out_rows + o] = acc;
+        }
+    return out;
+}
+
+struct Level {
+    int nr = 0, nc = 0;
+    float *I0 = nullptr, *I1 = nullptr; // [C] planes each
+    double *Us = nullptr, *Vs = nullptr; // the a-priori fields of the scale on the device (or null)
+};
+
+// The image pyramid of both frames (:100-127 / DispEminND_llin_2D.m:77-104): resize to ceil(size * scl_factor), the level
+// just left is smoothed after it has been resized; downscaling stops at min_size (then the last scale is smoothed too) or at
+// param.scales (then it is not: the loop `for scl=2:param.scales` simply ends).
+std::vector<Level> build_pyramid(Run &R, float *f0, float *f1, int nrows, int ncols, int C, const Params &p, int min_size, const std::vector<double> &G, int gsize)
+{
+    std::vector<Level> L(1);
+    L[0].nr = nrows;
+    L[0].nc = ncols;
+    L[0].I0 = f0;
+    L[0].I1 = f1;
+    while ((int)L.size() < p.scales) {
+        const Level cur = L.back();
+        Level nx;
+        nx.nr = (int)std::ceil(cur.nr * p.scl_factor);
+        nx.nc = (int)std::ceil(cur.nc * p.scl_factor);
+        nx.I0 = R.planes(nx.nr, nx.nc, C);
+        nx.I1 = R.planes(nx.nr, nx.nc, C);
+        DO(R, pdeip_pyr_resize_dev(R.s, cur.I0, cur.nr, cur.nc, C, nx.nr, nx.nc, 0, nx.I0));
+        DO(R, pdeip_pyr_resize_dev(R.s, cur.I1, cur.nr, cur.nc, C, nx.nr, nx.nc, 0, nx.I1));
+        float *s0 = R.planes(cur.nr, cur.nc, C), *s1 = R.planes(cur.nr, cur.nc, C);
+        DO(R, pdeip_pyr_smooth_dev(R.s, cur.I0, cur.nr, cur.nc, C, G.data(), gsize, s0));
+        DO(R, pdeip_pyr_smooth_dev(R.s, cur.I1, cur.nr, cur.nc, C, G.data(), gsize, s1));
+        L.back().I0 = s0;
+        L.back().I1 = s1;
+        L.push_back(nx);
+        if (nx.nr <= min_size || nx.nc <= min_size) {
+            float *t0 = R.planes(nx.nr, nx.nc, C), *t1 = R.planes(nx.nr, nx.nc, C);
+            DO(R, pdeip_pyr_smooth_dev(R.s, nx.I0, nx.nr, nx.nc, C, G.data(), gsize, t0));
+            DO(R, pdeip_pyr_smooth_dev(R.s, nx.I1, nx.nr, nx.nc, C, G.data(), gsize, t1));
+            L.back().I0 = t0;
+            L.back().I1 = t1;
+            break;
+        }
+    }
+    return L;
+}
+
+// param.Us / param.Vs down the pyramid (:162-184): NaN -> 0, USap{scl} = imresize(USap{scl-1} .* scl_factor, scl_factor), doubles;
+// every scale's field goes to the device as a double plane.  The coarsest one also starts the flow (:178, :183) -- MATLAB
+// keeps that double array through the first firstLoop of the coarsest scale (`u_double` below); here, as in drivers.py, `start`
+// receives its float32 rounding.
+void apriori_pyramid(Run &R, const double *Us_host, std::vector<Level> &L, double scl_factor, bool second, float *start)
+{
+    if (Us_host == nullptr) return;
+    std::vector<double> cur;
+    for (size_t s = 0; s < L.size(); s++) {
+        double *d = R.dplane(L[s].nr, L[s].nc);
+        (second ? L[s].Vs : L[s].Us) = d;
+        if (R.dry || R.rc != PDEIP_OK) continue;
+        if (s == 0) {
+            cur.assign(Us_host, Us_host + (size_t)L[0].nr * L[0].nc);
+            for (double &v : cur)
+                if (v != v) v = 0.0;
+        } else {
+            std::vector<double> scaled(cur.size());
+            for (size_t i = 0; i < cur.size(); i++) scaled[i] = cur[i] * scl_factor;
+            cur = resize_double(scaled, L[s - 1].nr, L[s - 1].nc, L[s].nr, L[s].nc);
+        }
+        // `cur` is rewritten for the next scale: the copy must have left it
+        DOHIP(R, hipMemcpyAsync(d, cur.data(), cur.size() * sizeof(double), hipMemcpyHostToDevice, R.s));
+        DOHIP(R, hipStreamSynchronize(R.s));
+    }
+    if (R.dry || R.rc != PDEIP_OK) return;
+    std::vector<float> f(cur.size());
+    for (size_t i = 0; i < cur.size(); i++) f[i] = (float)cur[i];
+    DOHIP(R, hipMemcpyAsync(start, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice, R.s));
+    DOHIP(R, hipStreamSynchronize(R.s));
+}
+
+// One scale of the flow driver: firstLoop x [warp, derivatives, secondLoop x (robust assembly + OPdiffWeights, a-priori terms,
+// Oflow_sor_llin4_2d), median] -- FlowEminND_llin_2D_v10.m:208-356, flow_level.py FlowLlinLevel.run.  The flow enters in
+// (U, V) and leaves in the pair returned through them; (Ua, Va) is the other plane pair of the ping-pong.
+void flow_level(Run &R, const Params &p, const Level &lv, const float *I1t0, const float *I1t1, int C1, const float *I2t0, const float *I2t1, int C2,
+                bool gradmag, float *&U, float *&V, float *&Ua, float *&Va, double as_diff, bool u_double)
+{
+    const int nr = lv.nr, nc = lv.nc;
+    const size_t n = (size_t)nr * nc;
+    const size_t m = R.mark();
+    float *w1 = R.planes(nr, nc, C1), *d1[3], *w2 = nullptr, *d2[5] = {};
+    for (auto &q : d1) q = R.planes(nr, nc, C1);
+    const int nd2 = C2 > 0 ? (gradmag ? 5 : 3) : 0;
+    if (C2 > 0) {
+        w2 = R.planes(nr, nc, C2);
+        for (int k = 0; k < nd2; k++) d2[k] = R.planes(nr, nc, C2);
+    }
+    float *coef[9]; // MGd, CuGd, CvGd, DuGd, DvGd, wW, wN, wE, wS
+    for (auto &q : coef) q = R.planes(nr, nc);
+    float *dUV = R.planes(nr, nc, 2), *dU = dUV, *dV = dUV + n;
+    for (int first = 0; first < p.firstLoop; first++) {
+        DO(R, pdeip_flow_warp_dev(R.s, U, V, I1t1, C1, C2 > 0 ? I2t1 : nullptr, C2, nr, nc, w1, w2));
+        DO(R, pdeip_fst_derivatives5_dev(R.s, I1t0, w1, nr, nc, C1, d1[0], d1[1], d1[2]));
+        if (C2 > 0) {
+            if (gradmag) DO(R, pdeip_snd_derivatives5_dev(R.s, I2t0, w2, nr, nc, C2, d2[0], d2[1], d2[2], d2[3], d2[4]));
+            else DO(R, pdeip_fst_derivatives5_dev(R.s, I2t0, w2, nr, nc, C2, d2[0], d2[1], d2[2]));
+        }
+        DOHIP(R, hipMemsetAsync(dUV, 0, 2 * n * sizeof(float), R.s));
+        for (int k = 0; k < p.secondLoop; k++) {
+            // weights come back in wW wN wS wE order (OPdiffWeights, :389-433)
+            DO(R, pdeip_flow_assemble_weights_dev(R.s, d1[0], d1[1], d1[2], C1, (float)p.b1, d2[0], d2[1], d2[2], d2[3], d2[4], C2, (float)p.b2, U, V, dU, dV,
+                                                  (float)p.alpha, nr, nc, coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[8], coef[7]));
+            if (lv.Us) DO(R, pdeip_flow_apriori_dev(R.s, lv.Us, U, dU, p.gammaS, p.alpha, as_diff, u_double && first == 0, k == 0, nr, nc, coef[1], coef[3]));
+            if (lv.Vs) DO(R, pdeip_flow_apriori_dev(R.s, lv.Vs, V, dV, p.gammaS, p.alpha, as_diff, u_double && first == 0, k == 0, nr, nc, coef[2], coef[4]));
+            if (p.solver == PDEIP_SOLVER_SOR)
+                DO(R, pdeip_oflow_sor_llin4_dev(R.s, U, V, dU, dV, coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[7], coef[8], nr, nc, p.iter,
+                                                (float)p.omega, R.mode, 0));
+            else
+                DO(R, pdeip_oflow_alr_llin4_dev(R.s, U, V, dU, dV, coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6], coef[7], coef[8], nr, nc, p.iter,
+                                                (float)p.omega, R.mode));
+        }
+        DO(R, pdeip_median3_pair_dev(R.s, U, dU, V, dV, nr, nc, Ua, Va));
+        std::swap(U, Ua);
+        std::swap(V, Va);
+    }
+    R.release(m);
+}
+
+// The stereo twin: DispEminND_llin_2D.m:202-316, flow_level.py DispLlinLevel.run
+void disp_level(Run &R, const Params &p, const Level &lv, const float *I1t0, const float *I1t1, int C1, const float *I2t0, const float *I2t1, int C2,
+                bool gradmag, float *&U, float *&Ua, double as_diff, bool u_double)
+{
+    const int nr = lv.nr, nc = lv.nc;
+    const size_t n = (size_t)nr * nc;
+    const size_t m = R.mark();
+    float *w1 = R.planes(nr, nc, C1), *d1[3], *w2 = nullptr, *d2[5] = {};
+    for (auto &q : d1) q = R.planes(nr, nc, C1);
+    if (C2 > 0) {
+        w2 = R.planes(nr, nc, C2);
+        for (int k = 0; k < (gradmag ? 5 : 3); k++) d2[k] = R.planes(nr, nc, C2);
+    }
+    float *CuGd = R.planes(nr, nc), *DuGd = R.planes(nr, nc), *S = R.planes(nr, nc), *w[4], *dU = R.planes(nr, nc);
+    for (auto &q : w) q = R.planes(nr, nc); // wW, wN, wE, wS
+    for (int first = 0; first < p.firstLoop; first++) {
+        DO(R, pdeip_flow_warp_dev(R.s, U, nullptr, I1t1, C1, C2 > 0 ? I2t1 : nullptr, C2, nr, nc, w1, w2)); // along x only
+        DO(R, pdeip_fst_derivatives5_dev(R.s, I1t0, w1, nr, nc, C1, d1[0], d1[1], d1[2]));
+        if (C2 > 0) {
+            if (gradmag) DO(R, pdeip_snd_derivatives5_dev(R.s, I2t0, w2, nr, nc, C2, d2[0], d2[1], d2[2], d2[3], d2[4]));
+            else DO(R, pdeip_fst_derivatives5_dev(R.s, I2t0, w2, nr, nc, C2, d2[0], d2[1], d2[2]));
+        }
+        DOHIP(R, hipMemsetAsync(dU, 0, n * sizeof(float), R.s));
+        for (int k = 0; k < p.secondLoop; k++) {
+            if (C2 > 0 && gradmag) // (Ixt, Iyt, Ixx, Ixy)
+                DO(R, pdeip_disp_assemble_gradmag_dev(R.s, d1[0], d1[1], C1, (float)p.b1, d2[0], d2[1], d2[2], d2[4], C2, (float)p.b2, dU, (float)p.alpha, nr, nc, CuGd, DuGd));
+            else
+                DO(R, pdeip_disp_assemble_dev(R.s, d1[0], d1[1], C1, (float)p.b1, C2 > 0 ? d2[0] : nullptr, C2 > 0 ? d2[1] : nullptr, C2, C2 > 0 ? (float)p.b2 : 0.0f, dU,
+                                              (float)p.alpha, nr, nc, CuGd, DuGd));
+            if (lv.Us) DO(R, pdeip_disp_apriori_dev(R.s, lv.Us, U, dU, p.gammaS, p.alpha, as_diff, u_double && first == 0, k == 0, nr, nc, CuGd, DuGd));
+            DO(R, pdeip_add_dev(R.s, U, dU, nr, nc, S));
+            DO(R, pdeip_diffweights6_dev(R.s, S, nr, nc, 1, 0.00001f, w[0], w[1], w[2], w[3]));
+            if (p.solver == PDEIP_SOLVER_SOR) DO(R, pdeip_disp_sor_llin4_dev(R.s, U, dU, CuGd, DuGd, w[0], w[1], w[2], w[3], nr, nc, p.iter, (float)p.omega, R.mode, 0));
+            else DO(R, pdeip_disp_alr_llin4_dev(R.s, U, dU, CuGd, DuGd, w[0], w[1], w[2], w[3], nr, nc, p.iter, (float)p.omega, R.mode));
+        }
+        DO(R, pdeip_median3_dev(R.s, U, dU, nr, nc, Ua));
+        std::swap(U, Ua);
+    }
+    R.release(m);
+}
+
+// First / second constancy images of a scale (:133-170)
+struct Terms {
+    const float *a0, *a1, *b0, *b1;
+    int C1, C2;
+};
+Terms terms(Run &R, const Level &lv, int C, int fst, int snd)
+{
+    Terms t{lv.I0, lv.I1, nullptr, nullptr, C, 0};
+    if (fst == PDEIP_TERM_GRAD) {
+        float *g0 = R.planes(lv.nr, lv.nc, 2 * C), *g1 = R.planes(lv.nr, lv.nc, 2 * C);
+        DO(R, pdeip_rgb2grad_dev(R.s, lv.I0, lv.nr, lv.nc, C, g0));
+        DO(R, pdeip_rgb2grad_dev(R.s, lv.I1, lv.nr, lv.nc, C, g1));
+        t.a0 = g0;
+        t.a1 = g1;
+        t.C1 = 2 * C;
+    }
+    if (snd != PDEIP_TERM_NONE) {
+        t.b0 = lv.I0;
+        t.b1 = lv.I1;
+        t.C2 = C;
+    }
+    return t;
+}
+
+int check_terms(const char *who, int fst, int snd)
+{
+    if (fst != PDEIP_TERM_RGB && fst != PDEIP_TERM_GRAD) return set_err(PDEIP_ERR_ARG, "%s: No such fstTerm", who);
+    if (snd != PDEIP_TERM_NONE && snd != PDEIP_TERM_RGB && snd != PDEIP_TERM_GRADMAG) return set_err(PDEIP_ERR_ARG, "%s: No such sndTerm", who);
+    return PDEIP_OK;
+}
+
+// the body of pdeip_flow_nd_llin for one Run (dry or real)
+void flow_nd(Run &R, const float *Iin, int nrows, int ncols, int C, int fst, int snd, const Params &p, const double *Us, const double *Vs, float *U_out, float *V_out)
+{
+    const size_t n = (size_t)nrows * ncols;
+    float *up = R.planes(nrows, ncols, 2 * C), *fr = R.planes(nrows, ncols, 2 * C);
+    DOHIP(R, hipMemcpyAsync(up, Iin, 2 * C * n * sizeof(float), hipMemcpyHostToDevice, R.s));
+    scale(R, fr, up, 2 * C * n, 255.0f, true); // Iin = single(Iin) ./ 255
+    const std::vector<double> G = gaussian_mask(5, 1.25);
+    std::vector<Level> L = build_pyramid(R, fr, fr + C * n, nrows, ncols, C, p, 20, G, 5);
+    const Level top = L.back();
+    float *U = R.planes(top.nr, top.nc), *V = R.planes(top.nr, top.nc), *Ua = R.planes(top.nr, top.nc), *Va = R.planes(top.nr, top.nc);
+    DOHIP(R, hipMemsetAsync(U, 0, (size_t)top.nr * top.nc * sizeof(float), R.s)); // "zero flow" unless an a-priori field starts it
+    DOHIP(R, hipMemsetAsync(V, 0, (size_t)top.nr * top.nc * sizeof(float), R.s));
+    apriori_pyramid(R, Us, L, p.scl_factor, false, U);
+    apriori_pyramid(R, Vs, L, p.scl_factor, true, V);
+    const float inv = (float)(1.0 / p.scl_factor);
+    for (int s = (int)L.size() - 1; s >= 0; s--) {
+        const size_t m = R.mark();
+        const Terms t = terms(R, L[s], C, fst, snd);
+        flow_level(R, p, L[s], t.a0, t.a1, t.C1, t.b0, t.b1, t.C2, snd == PDEIP_TERM_GRADMAG, U, V, Ua, Va, 2.0 * std::pow(p.scl_factor, (double)s),
+                   s == (int)L.size() - 1 && (Us != nullptr || Vs != nullptr));
+        if (s > 0) { // U = imresize(U .* (1/scl_factor), size of the finer scale, 'triangle')
+            const Level &f = L[s - 1];
+            scale(R, Ua, U, (size_t)L[s].nr * L[s].nc, inv, false);
+            scale(R, Va, V, (size_t)L[s].nr * L[s].nc, inv, false);
+            R.release(m); // the finer planes may reuse what this scale's terms held; U, V, Ua, Va lie below the mark
+            float *Un = R.planes(f.nr, f.nc), *Vn = R.planes(f.nr, f.nc), *Una = R.planes(f.nr, f.nc), *Vna = R.planes(f.nr, f.nc);
+            DO(R, pdeip_pyr_resize_dev(R.s, Ua, L[s].nr, L[s].nc, 1, f.nr, f.nc, 0, Un));
+            DO(R, pdeip_pyr_resize_dev(R.s, Va, L[s].nr, L[s].nc, 1, f.nr, f.nc, 0, Vn));
+            U = Un;
+            V = Vn;
+            Ua = Una;
+            Va = Vna;
+        }
+    }
+    DOHIP(R, hipMemcpyAsync(U_out, U, n * sizeof(float), hipMemcpyDeviceToHost, R.s));
+    DOHIP(R, hipMemcpyAsync(V_out, V, n * sizeof(float), hipMemcpyDeviceToHost, R.s));
+    DOHIP(R, hipStreamSynchronize(R.s));
+}
+
+void disp_nd(Run &R, const float *Il, const float *Ir, int nrows, int ncols, int C, int fst, int snd, const Params &p, const double *Us, float *U_out)
+{
+    const size_t n = (size_t)nrows * ncols;
+    float *up = R.planes(nrows, ncols, 2 * C), *fr = R.planes(nrows, ncols, 2 * C);
+    DOHIP(R, hipMemcpyAsync(up, Il, C * n * sizeof(float), hipMemcpyHostToDevice, R.s));
+    DOHIP(R, hipMemcpyAsync(up + C * n, Ir, C * n * sizeof(float), hipMemcpyHostToDevice, R.s));
+    scale(R, fr, up, 2 * C * n, 255.0f, true);
+    const std::vector<double> G = gaussian_mask(5, 1.25);
+    std::vector<Level> L = build_pyramid(R, fr, fr + C * n, nrows, ncols, C, p, 10, G, 5);
+    const Level top = L.back();
+    float *U = R.planes(top.nr, top.nc), *Ua = R.planes(top.nr, top.nc);
+    DOHIP(R, hipMemsetAsync(U, 0, (size_t)top.nr * top.nc * sizeof(float), R.s));
+    apriori_pyramid(R, Us, L, p.scl_factor, false, U);
+    const float inv = (float)(1.0 / p.scl_factor);
+    for (int s = (int)L.size() - 1; s >= 0; s--) {
+        const size_t m = R.mark();
+        const Terms t = terms(R, L[s], C, fst, snd);
+        disp_level(R, p, L[s], t.a0, t.a1, t.C1, t.b0, t.b1, t.C2, snd == PDEIP_TERM_GRADMAG, U, Ua, 1.75 * std::pow(p.scl_factor, (double)s),
+                   s == (int)L.size() - 1 && Us != nullptr);
+        if (s > 0) {
+            const Level &f = L[s - 1];
+            scale(R, Ua, U, (size_t)L[s].nr * L[s].nc, inv, false);
+            R.release(m);
+            float *Un = R.planes(f.nr, f.nc), *Una = R.planes(f.nr, f.nc);
+            DO(R, pdeip_pyr_resize_dev(R.s, Ua, L[s].nr, L[s].nc, 1, f.nr, f.nc, 0, Un));
+            U = Un;
+            Ua = Una;
+        }
+    }
+    DOHIP(R, hipMemcpyAsync(U_out, U, n * sizeof(float), hipMemcpyDeviceToHost, R.s));
+    DOHIP(R, hipStreamSynchronize(R.s));
+}
+
+template <class Body> int play(const char *who, Body body)
+{
+    RC(use_device());
+    Run plan;
+    body(plan); // dry: sizes only
+    float *arena = nullptr;
+    RC(ws_get(WS_DRIVER, plan.peak + 256, &arena));
+    Run R;
+    R.dry = false;
+    R.base = reinterpret_cast<char *>(arena);
+    R.mode = g.mode;
+    R.s = nullptr; // the host entry points use the device's default stream
+    body(R);
+    if (R.rc != PDEIP_OK) return R.rc;
+    if (R.used > plan.peak + 256) return set_err(PDEIP_ERR_DEVICE, "%s: the run used more device memory than its plan", who);
+    RC(pdeip_persist_error());
+    return PDEIP_OK;
+}
+
+} // namespace
+
+extern "C" int pdeip_flow_nd_llin(const float *Iin, int nrows, int ncols, int channels, int fst_term, int snd_term, const pdeip_driver_params *prm,
+                                  const double *Us, const double *Vs, float *U, float *V)
+{
+    const char *who = "pdeip_flow_nd_llin";
+    NONNULL(who, Iin);
+    NONNULL(who, U);
+    NONNULL(who, V);
+    RC(check_dims(who, nrows, ncols, channels));
+    RC(check_terms(who, fst_term, snd_term));
+    read_env_once();
+    // FlowEminND_llin_2D_v10.m:52-67
+    const Params dflt{0.042, 1.9, 0.01, 1.4843, 0.2915, 0.75, 4, 4, 4, PDEIP_SOLVER_ALR, 0x7fffffff};
+    const Params p = merge(prm, dflt);
+    RC(check_solver(who, p.solver));
+    if (!(p.scl_factor < 1.0)) return set_err(PDEIP_ERR_ARG, "%s: scl_factor must be below 1", who);
+    return play(who, [&](Run &R) { flow_nd(R, Iin, nrows, ncols, channels, fst_term, snd_term, p, Us, Vs, U, V); });
+}
+
+extern "C" int pdeip_disp_nd_llin(const float *Il, const float *Ir, int nrows, int ncols, int channels, int fst_term, int snd_term,
+                                  const pdeip_driver_params *prm, const double *Us, float *U)
+{
+    const char *who = "pdeip_disp_nd_llin";
+    NONNULL(who, Il);
+    NONNULL(who, Ir);
+    NONNULL(who, U);
+    RC(check_dims(who, nrows, ncols, channels));
+    RC(check_terms(who, fst_term, snd_term));
+    read_env_once();
+    // DispEminND_llin_2D.m:51-63
+    const Params dflt{0.042, 1.9, 0.005, 1.48, 0.29, 0.75, 4, 6, 4, PDEIP_SOLVER_ALR, 0x7fffffff};
+    const Params p = merge(prm, dflt);
+    RC(check_solver(who, p.solver));
+    if (!(p.scl_factor < 1.0)) return set_err(PDEIP_ERR_ARG, "%s: scl_factor must be below 1", who);
+    return play(who, [&](Run &R) { disp_nd(R, Il, Ir, nrows, ncols, channels, fst_term, snd_term, p, Us, U); });
+}

@@ -7,7 +7,7 @@
 #include "pdeip_models.hpp"
 #include "pdeip_pointwise.hpp"
 #include "pdeip_sor_exact.hpp"
-#include "pdeip_sor_walk.hpp"
+#include "pdeip_walk_host.hpp"
 #include "pdeip_persist_host.hpp"
 #include "pdeip_sor_rb.hpp"
 #include "pdeip_sor_rbp.hpp"
@@ -136,26 +136,25 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             tls.last_launches++;
             // ---- persistent form: one launch, progress counters instead of one launch per front ----
             const int NC = (nrows - 2 + 63 + EX_CH - 1) / EX_CH;
+            // Round 3's walker (pdeip_sor_walk.hpp, launched from pdeip_walk5.hip: LDS-DMA loader, three chunk buffers, strips of
+            // W columns) is an opt-in, PDEIP_EXACT_WALK=1: measured against round 2's k_sor_exact_persist in the same runs it is
+            // 15 % faster at 4K with one sweep per call, 2-5 % at iter = 4, and 5-25 % SLOWER on frames below 1080p and for the
+            // single-field models (five waves and a longer prologue per walker) -- the walk is paced by what one compute unit's
+            // memory pipeline takes per chunk and by the strips' start-up chain, not by the loader's instruction count
+            // (exact order; profiles/NOTES.md).
+            const bool walk = env_int("PDEIP_EXACT_WALK", 0) != 0;
+            const int W = walk ? walk_width<Mdl>(nrows, ncols, nframes, iter) : 64;
+            const int BW = (ncols - 2 + W - 1) / W;
             // schedule table, control block, mailbox: one 8-byte {value, tag} word per (frame, sweep, strip, field, row)
             PersistCtl ctl{};
-            RC(persist_prepare(s, B, iter, nframes, (size_t)nframes * iter * B * NIT * (size_t)NC * EX_CH * sizeof(unsigned long long), &ctl));
-            // the walker: LDS-DMA loader with three chunk buffers where they fit (pdeip_sor_walk.hpp); PDEIP_EXACT_WALK=0 keeps
-            // round 2's register-staged loader (k_sor_exact_persist), PDEIP_WALK_NBUF=2 forces two buffers
-            constexpr int WNB = WalkLayout<Mdl, 3>::FITS ? 3 : 2;
-            const bool walk = env_int("PDEIP_EXACT_WALK", 1) != 0;
+            RC(persist_prepare(s, BW, iter, nframes, (size_t)nframes * iter * BW * NIT * (size_t)NC * EX_CH * sizeof(unsigned long long), &ctl));
             SweepTimer timer(s);
-            if (walk && (WNB == 2 || env_int("PDEIP_WALK_NBUF", 3) >= 3)) {
-                using WL = WalkLayout<Mdl, WNB>;
-                RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_walk<Mdl, WNB>), WL::LDS_BYTES));
-                hipLaunchKernelGGL((k_sor_walk<Mdl, WNB>), dim3((unsigned)(B * iter * nframes)), dim3(WL::THREADS), WL::LDS_BYTES, s, P, pack, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
-            } else if (walk) {
-                using WL = WalkLayout<Mdl, 2>;
-                RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_walk<Mdl, 2>), WL::LDS_BYTES));
-                hipLaunchKernelGGL((k_sor_walk<Mdl, 2>), dim3((unsigned)(B * iter * nframes)), dim3(WL::THREADS), WL::LDS_BYTES, s, P, pack, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
+            if (walk) {
+                RC(walk_launch<Mdl>(s, P, pack, ctl, nrows, ncols, BW, iter, NC, nframes, omega, n, W));
             } else {
                 constexpr size_t plds = ExactLayout<Mdl>::LDS_BYTES + 16;
                 RC(ensure_lds(reinterpret_cast<const void *>(&k_sor_exact_persist<Mdl>), plds));
-                hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(B * iter * nframes)), dim3(exp_threads<Mdl>()), plds, s, P, pack, ctl, nrows, ncols, B, iter, NC, nframes, omega, n);
+                hipLaunchKernelGGL(k_sor_exact_persist<Mdl>, dim3((unsigned)(BW * iter * nframes)), dim3(exp_threads<Mdl>()), plds, s, P, pack, ctl, nrows, ncols, BW, iter, NC, nframes, omega, n);
             }
             timer.stop(1);
             tls.last_launches++;
@@ -377,14 +376,6 @@ extern "C" int pdeip_debug_read_walk_stamps(unsigned long long *out)
 {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p8_stamps), 4096 * sizeof(unsigned long long)));
-    return PDEIP_OK;
-}
-#endif
-#ifdef PDEIP_P8_STAMPS
-extern "C" int pdeip_debug_read_walk_trace(unsigned long long *out)
-{
-    HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_trace), 128 * 8 * 16 * sizeof(unsigned long long)));
     return PDEIP_OK;
 }
 #endif

@@ -21,22 +21,24 @@
 
 namespace pdeip {
 
-template <class Mdl, int NBUF_> struct WalkLayout {
+template <class Mdl, int NBUF_, int W_ = 64> struct WalkLayout {
     static constexpr int NIT = Mdl::NIT, NRO = Mdl::NRO, NF = NIT + NRO, NCF = Mdl::NCF, NBUF = NBUF_;
-    static constexpr int FIELD = 64 * EX_CH;                   // floats of one field's chunk image (4 pieces)
+    static constexpr int W = W_;                               // columns of a strip (lanes W .. 63 idle): 64, 48 or 32
+    static constexpr int NFP = W / 16;                         // pieces of one field's chunk image
+    static constexpr int FIELD = W * EX_CH;                    // floats of one field's chunk image
     static constexpr int RUN = PackLayout<Mdl>::RUN, CS = PackLayout<Mdl>::CS;
-    static constexpr int PACK = 64 * CS * 4;                   // floats of the packed image
-    static constexpr int NPK = CS;                             // its pieces (64 CS granules / 64 lanes)
+    static constexpr int PACK = W * CS * 4;                    // floats of the packed image
+    static constexpr int NPK = W * CS / 64;                    // its pieces (W CS granules / 64 lanes)
     static constexpr int EDGE = NF * 32;                       // per field: west 16 | east 16
     static constexpr int BUF = NF * FIELD + PACK + EDGE;       // floats per chunk buffer
     static constexpr int OUTB = NIT * FIELD;
     static constexpr int CTRL = 16 + 2 * NIT * 16;             // words: 0 item, 1 frame, 2 taken, 4 / 5 progress of (b,t-1) / (b+1,t-1) as the poller last saw it; 16..: its mailbox staging
     static constexpr size_t LDS_BYTES = (size_t)(NBUF * BUF + 2 * OUTB + CTRL) * sizeof(float);
-    static constexpr int PIECES = NF * 4 + NPK + NF;           // LDS-DMA instructions per chunk
+    static constexpr int PIECES = NF * NFP + NPK + NF;         // LDS-DMA instructions per chunk
     static constexpr int NCOMP = NIT == 2 ? 2 : 1;             // compute waves (one per field of the coupled models)
     static constexpr int THREADS = 64 * (NCOMP + 3);           // + loader, storer, poller
     static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && (NBUF < 3 || PIECES <= 63);
-    static_assert(BUF % 4 == 0 && FIELD % 256 == 0, "16-byte granules, whole pieces");
+    static_assert(BUF % 4 == 0 && FIELD % 256 == 0 && (W * CS) % 64 == 0 && W % 16 == 0 && W <= 64, "16-byte granules, whole pieces");
 };
 
 #define WALK_LDS(p) ((__attribute__((address_space(3))) void *)(p))
@@ -75,12 +77,18 @@ template <int AUX> __device__ __forceinline__ void walk_dma16(__amdgpu_buffer_rs
 #endif
 }
 
-template <class Mdl, int NBUF>
-__global__ void __launch_bounds__((WalkLayout<Mdl, NBUF>::THREADS))
+template <class Mdl, int NBUF, int W = 64>
+__global__ void __launch_bounds__((WalkLayout<Mdl, NBUF, W>::THREADS))
 k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int ncols, int B, int T, int NC, int nframes, float omega,
-           size_t frame_stride)
+           size_t frame_stride, int tune)
 {
-    using L = WalkLayout<Mdl, NBUF>;
+    // tune (PDEIP_WALK_TUNE, experiments): per role a pause of (nibble) x 64 cycles at the top of every interval --
+    // bits 0-3 loader, 4-7 storer, 8-11 poller, 12-15 compute
+    auto pause = [&](int shift) __attribute__((always_inline)) {
+        for (int n = (tune >> shift) & 15; n > 0; n--) __builtin_amdgcn_s_sleep(1);
+    };
+    using L = WalkLayout<Mdl, NBUF, W>;
+    constexpr int NFP = L::NFP;
     constexpr int NIT = L::NIT, NRO = L::NRO, NRO1 = at_least_one<NRO>::value, NF = L::NF, NCF = L::NCF, CS = L::CS;
     constexpr int D = NBUF - 1; // chunks in flight ahead of the one being relaxed
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -123,7 +131,7 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
     const __amdgpu_buffer_rsrc_t rs_pack =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pack) + fo * NCF, 0, (unsigned)((size_t)nrows * ncols * NCF * sizeof(float)), 0x00020000);
 
-    const int jbase = 1 + 64 * b;
+    const int jbase = 1 + W * b;
     auto crow = [&](int i) { return i < 0 ? 0 : (i > nrows - 1 ? nrows - 1 : i); };
     auto boff = [&](int jj, int row) { return (unsigned)(((long)jj * nrows + row) * 4); };
     const bool west_by_mail = (b > 0);
@@ -133,9 +141,9 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
         // Byte offsets of this lane's 16 bytes in every piece of chunk 0; a chunk further down adds a constant.  Rows above the
         // frame or below it fall into a neighbouring column or outside the plane: valid to fetch (or dropped by the range
         // check), and never used -- those rows belong to steps that relax nothing (pdeip_sor_exact.hpp, "Memory").
-        unsigned vf[4], vp[L::NPK], ve;
+        unsigned vf[NFP], vp[L::NPK], ve;
 #pragma unroll
-        for (int d = 0; d < 4; d++) {
+        for (int d = 0; d < NFP; d++) {
             const int G = 64 * d + lane, c = G >> 2, q = (G & 3) ^ ((c >> 2) & 3);
             int jj = jbase + c;
             jj = jj < ncols - 1 ? jj : ncols - 1;
@@ -150,8 +158,8 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
         }
         {
             const int which = (lane >> 2) & 1; // lanes 0-3: west column, centre rows of lane 0; lanes 4-7: east column, centre rows of lane 63
-            const int ecol = which ? (jbase + 64 < ncols - 1 ? jbase + 64 : ncols - 1) : jbase - 1;
-            ve = boff(ecol, (which ? 1 - 63 : 1) + 4 * (lane & 3));
+            const int ecol = which ? (jbase + W < ncols - 1 ? jbase + W : ncols - 1) : jbase - 1;
+            ve = boff(ecol, (which ? 1 - (W - 1) : 1) + 4 * (lane & 3));
         }
         const bool edge_all = lane < 8, edge_east = lane >= 4 && lane < 8;
         auto issue = [&](int buf) __attribute__((always_inline)) {
@@ -159,7 +167,7 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
 #pragma unroll
             for (int f = 0; f < NF; f++)
 #pragma unroll
-                for (int d = 0; d < 4; d++)
+                for (int d = 0; d < NFP; d++)
                     if (f < NIT) walk_dma16<16>(rs[f], base + f * L::FIELD + d * 256, vf[d]); // sc1
                     else walk_dma16<0>(rs[f], base + f * L::FIELD + d * 256, vf[d]);
 #pragma unroll
@@ -176,7 +184,7 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
                 }
             }
 #pragma unroll
-            for (int d = 0; d < 4; d++) vf[d] += 16u * 4u;
+            for (int d = 0; d < NFP; d++) vf[d] += 16u * 4u;
 #pragma unroll
             for (int d = 0; d < L::NPK; d++) vp[d] += 16u * NCF * 4u;
             ve += 16u * 4u;
@@ -185,7 +193,7 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
         // refreshed by the poller wave through s_ctl[4..5]; only a real shortfall makes this wave poll (and drain) itself
         unsigned known_prev = prog_prev ? 0u : 0xffffffffu, known_east = prog_east ? 0u : 0xffffffffu;
         auto deps = [&](int c) __attribute__((always_inline)) {
-            const int np = c + 2, ne = c - 2;
+            const int np = c + 2, ne = c + 2 - W / 16; // the east strip's lane 0 relaxed the rows my last lane needs W/16 - 1 chunks up
             const unsigned need_prev = (unsigned)(np < NC ? np : NC), need_east = (unsigned)(ne < 0 ? 0 : (ne < NC ? ne : NC));
             if (known_prev >= need_prev && known_east >= need_east) return;
             const unsigned kp = s_ctl[4], ke = s_ctl[5]; // what the poller saw last interval
@@ -220,6 +228,7 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
         int nb = (D - 1) % NBUF; // stepped at the top of an interval: buffer of chunk k + D
         for (int k = 0; k < NC; k++) {
             WKS_BEGIN;
+            pause(0);
             nb = nb + 1 == NBUF ? 0 : nb + 1; // (k + D) % NBUF
             if (k + D < NC) {
                 deps(k + D);
@@ -247,13 +256,13 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
         //       stores for the lanes with a mixed quad, pieces right of it (g > c) hold no inner row; padded to a fixed count;
         //   anything else (the bottom of the frame)           NSD = 20 NIT: every piece in the five-store form.
         // A lane that has nothing to store gets an offset the range check drops.
-        constexpr int NS = NIT * 4, NST = NIT * 8, NSD = NIT * 20;
+        constexpr int NS = NIT * NFP, NST = NIT * (NFP + 4), NSD = NIT * NFP * 5;
         constexpr unsigned DROP = 0xfffffff0u;
         auto store_out = [&](int c) __attribute__((always_inline)) -> int { // returns the number of store instructions
             const float *outb = outb_base + (c & 1) * L::OUTB;
             const int i00 = 1 + EX_CH * c;
-            const bool all_valid = (i00 - 63 >= 1) && (i00 + EX_CH - 1 <= nrows - 2); // every row of the chunk is an inner row
-            const bool top = !all_valid && c < 4 && (i00 + EX_CH - 1 <= nrows - 2);     // only the frame's top is in reach
+            const bool all_valid = (i00 - (W - 1) >= 1) && (i00 + EX_CH - 1 <= nrows - 2); // every row of the chunk is an inner row
+            const bool top = !all_valid && c < NFP && (i00 + EX_CH - 1 <= nrows - 2);     // only the frame's top is in reach
             auto piece = [&](int f, int g, bool five) __attribute__((always_inline)) {
                 const int G = 64 * g + lane, col = G >> 2, q = (G & 3) ^ ((col >> 2) & 3);
                 const int jj = jbase + col;
@@ -279,28 +288,28 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
 #pragma unroll
                 for (int f = 0; f < NIT; f++)
 #pragma unroll
-                    for (int g = 0; g < 4; g++) piece(f, g, false);
+                    for (int g = 0; g < NFP; g++) piece(f, g, false);
                 return NS;
             }
             if (top) {
 #pragma unroll
                 for (int f = 0; f < NIT; f++) {
 #pragma unroll
-                    for (int g = 0; g < 3; g++) { // pieces left of the diagonal, or a dropped store in their place
+                    for (int g = 0; g < NFP - 1; g++) { // pieces left of the diagonal, or a dropped store in their place
                         if (g < c) piece(f, g, false);
                         else __builtin_amdgcn_raw_buffer_store_b32(0u, rs[f], DROP, 0, 16);
                     }
                     if (c == 0) piece(f, 0, true);
-                    else if (c == 1) piece(f, 1, true);
-                    else if (c == 2) piece(f, 2, true);
-                    else piece(f, 3, true);
+                    else if (c == 1 || NFP < 3) piece(f, 1, true);
+                    else if (c == 2 || NFP < 4) piece(f, 2, true);
+                    else piece(f, NFP - 1, true);
                 }
                 return NST;
             }
 #pragma unroll
             for (int f = 0; f < NIT; f++)
 #pragma unroll
-                for (int g = 0; g < 4; g++) piece(f, g, true);
+                for (int g = 0; g < NFP; g++) piece(f, g, true);
             return NSD;
         };
         // progress = c+1 once every store of chunks <= c has left (Guideline 16, R1: drain, then the flag).  A write-through
@@ -335,6 +344,7 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
         P8S_DECL;
         for (int k = 0; k < NC; k++) {
             WKS_BEGIN;
+            pause(4);
             if (k >= 1) {
                 const int n0 = store_out(k - 1);
                 // youngest first: stores(k-1) | counter, stores(k-2) | counter, stores(k-3) | counter, stores(k-4) ...
@@ -436,6 +446,7 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
         P8S_DECL;
         for (int k = 0; k < NC; k++) {
             WKS_BEGIN;
+            pause(8);
             interval(k + 1, k + 2);
             WKS_END(k);
             lds_barrier();
@@ -449,15 +460,17 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
     unsigned long long *const mail_mine = ctl.mail + ((((size_t)frame * T + t) * B + b) * NIT) * ((size_t)NC * EX_CH);
     // ======================================== compute wave(s) ==========================================
     const int j = jbase + lane;
-    const bool col_ok = j <= ncols - 2;
+    const bool lane_in = W == 64 || lane < W; // lanes W .. 63 of a narrower strip relax nothing
+    const bool col_ok = lane_in && j <= ncols - 2;
     const int jc = j < ncols - 1 ? j : ncols - 1;
     const float om1 = 1.0f - omega;
     const bool first_sweep = (t == 0);
     const bool has_east = (b + 1 < B); // my last column is the next strip's west column
-    const int i0w63 = 1 - 63;          // lane 63's row at step 0 of chunk 0
+    const int i0w63 = 1 - (W - 1);     // the last lane's row at step 0 of chunk 0
     const __amdgpu_buffer_rsrc_t rs_mail = __builtin_amdgcn_make_buffer_rsrc(mail_mine, 0, (unsigned)((size_t)NIT * NC * EX_CH * 8), 0x00020000);
     const int i0 = 1 - lane; // row of this lane at step 0 of chunk 0
-    const int sw = (lane >> 2) & 3;
+    const int lw = lane_in ? lane : W - 1; // the lane whose LDS image an idle lane reads (stays inside the buffers)
+    const int sw = (lw >> 2) & 3;
 
     auto compute_wave = [&](auto f0_tag, auto nfw_tag) __attribute__((always_inline)) {
     // this wave relaxes the fields [F0, F0 + NFW); of the other fields it only follows the centre value (the coupling term)
@@ -488,16 +501,16 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
     for (int f = 0; f < NIT; f++) { keep_prev[f] = prev[f]; keep_cen[f] = cen[f]; }
 #pragma unroll
     for (int f = 0; f < NRO1; f++) { keep_rcen[f] = rcen[f]; keep_rnorth[f] = rnorth[f]; }
-    const int k_inner = (EX_CH * 4 + EX_CH <= nrows - 3) ? 4 : 0; // a chunk whose rows are all inner rows, if the frame has one
+    const int k_inner = (EX_CH * NFP + EX_CH <= nrows - 3) ? NFP : 0; // a chunk whose rows are all inner rows, if the frame has one
 
     P8S_DECL;
     int bi = 0; // k % NBUF
     for (int kk = -2; kk < NC; kk++) {
         const bool dry = kk < 0;
         const int k = dry ? (kk == -2 ? 0 : k_inner) : kk;
-        if (!dry) { WKS_BEGIN; }
+        if (!dry) { WKS_BEGIN; pause(12); }
         const float *stage = smem + bi * L::BUF, *edge = stage + NF * L::FIELD + L::PACK;
-        const float4 *cimg = reinterpret_cast<const float4 *>(stage + NF * L::FIELD) + lane * CS;
+        const float4 *cimg = reinterpret_cast<const float4 *>(stage + NF * L::FIELD) + lw * CS;
         float *outb = outb_base + (k & 1) * L::OUTB;
         if (!dry) bi = bi + 1 == NBUF ? 0 : bi + 1;
         const int i00 = 1 + EX_CH * k;
@@ -509,7 +522,13 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
         // for, so they get a path of their own instead of the generic one (40 instead of 24 instructions per step).
         constexpr int ROWS = decltype(rows_tag)::value;
         constexpr bool ROWS_IN = ROWS == 2, ROWS_TOP = ROWS == 1, COLS_IN = decltype(cols_tag)::value == 1, INTERIOR = ROWS_IN && COLS_IN;
-#pragma unroll
+#ifndef PDEIP_WALK_UNROLL_MQ
+#define PDEIP_WALK_UNROLL_MQ 1
+#endif
+        // a rolled loop over the four 4-step groups of a chunk: a quarter of the code (the kernel's five bodies x two compute waves
+        // were 90 KB unrolled, more than the instruction cache two compute units share, and its run time moved by 15-20 % with
+        // the placement of unrelated code)
+#pragma unroll PDEIP_WALK_UNROLL_MQ
         for (int mq = 0; mq < EX_CH / 4; mq++) {
             float4 s4[NF], e4[NF], res[NIT];
             float cflat[4 * NCF]; // coefficients of the four rows of this group, [row][f]: granules NCF mq .. NCF mq + NCF - 1 of my run
@@ -520,8 +539,8 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
             }
 #pragma unroll
             for (int f = 0; f < NF; f++) {
-                s4[f] = *reinterpret_cast<const float4 *>(&stage[f * L::FIELD + 4 * (4 * lane + (mq ^ sw))]);
-                e4[f] = *reinterpret_cast<const float4 *>(&edge[f * 32 + (lane == 63 ? 16 : 0) + 4 * mq]);
+                s4[f] = *reinterpret_cast<const float4 *>(&stage[f * L::FIELD + 4 * (4 * lw + (mq ^ sw))]);
+                e4[f] = *reinterpret_cast<const float4 *>(&edge[f * 32 + (lane >= W - 1 ? 16 : 0) + 4 * mq]);
             }
 #pragma unroll
             for (int x = 0; x < 4; x++) {
@@ -537,7 +556,8 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
                     const float sraw = el(s4[f]);
                     c[f] = cen[f];
                     if (mine(f)) {
-                        const float eraw = dpp_from_upper_lane(sraw, el(e4[f]));
+                        float eraw = dpp_from_upper_lane(sraw, el(e4[f]));
+                        if (W < 64 && lane == W - 1) eraw = el(e4[f]); // the strip's last lane: the east column, not an idle lane's value
                         const float wnew = dpp_from_lower_lane(prev[f], el(e4[f]));
                         float nv = prev[f];
                         if (!ROWS_IN && i == 1) nv = first_sweep ? topb[f] : cen[f];
@@ -555,6 +575,7 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
                     if (NRO > 0) {
                         rsouth[f] = el(s4[(NRO > 0 ? NIT + f : 0)]);
                         reast[f] = dpp_from_upper_lane(rsouth[f], el(e4[(NRO > 0 ? NIT + f : 0)]));
+                        if (W < 64 && lane == W - 1) reast[f] = el(e4[(NRO > 0 ? NIT + f : 0)]);
                         rwest[f] = dpp_from_lower_lane(rnorth[f], el(e4[(NRO > 0 ? NIT + f : 0)]));
                     } else {
                         rsouth[f] = reast[f] = rwest[f] = 0.0f;
@@ -576,12 +597,13 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
                 }
             }
 #pragma unroll
-            for (int f = F0; f < F0 + NFW; f++) *reinterpret_cast<float4 *>(&outb[f * L::FIELD + 4 * (4 * lane + (mq ^ sw))]) = res[f];
+            for (int f = F0; f < F0 + NFW; f++)
+                if (lane_in) *reinterpret_cast<float4 *>(&outb[f * L::FIELD + 4 * (4 * lane + (mq ^ sw))]) = res[f];
         }
         };
         {
-            const int lo_row = i00 - 63, hi_row = i00 + EX_CH - 1;
-            const bool rows_in = (lo_row >= 2) && (hi_row <= nrows - 3), rows_top = hi_row <= nrows - 3, cols_in = (jbase >= 2) && (jbase + 63 <= ncols - 3);
+            const int lo_row = i00 - (W - 1), hi_row = i00 + EX_CH - 1;
+            const bool rows_in = (lo_row >= 2) && (hi_row <= nrows - 3), rows_top = hi_row <= nrows - 3, cols_in = (jbase >= 2) && (jbase + W - 1 <= ncols - 3);
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>;
@@ -601,7 +623,7 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
 #pragma unroll
                 for (int f = F0; f < F0 + NFW; f++) {
                     v2u_t wv;
-                    wv.x = __float_as_uint(outb[f * L::FIELD + 4 * (4 * 63 + ((lane >> 2) ^ 3)) + (lane & 3)]); // column 63: s(63) = 3
+                    wv.x = __float_as_uint(outb[f * L::FIELD + 4 * (4 * (W - 1) + ((lane >> 2) ^ 3)) + (lane & 3)]); // column W-1: s(W-1) = 3
                     wv.y = 1u;
                     __builtin_amdgcn_raw_buffer_store_b64(wv, rs_mail, (unsigned)(((size_t)f * NC * EX_CH + r - 1) * 8), 0, 16); // sc1
                 }

@@ -108,15 +108,19 @@ class SlabDomain:
         mine = self.owned(local).contiguous()
         if self.world == 1:
             return mine
+        # gloo moves host memory only (rehearsal of the multi-rank path on CUDA tensors): stage through the host there
+        via_host = mine.is_cuda and dist.get_backend(self.group) == "gloo"
+        wire = mine.cpu() if via_host else mine
         if self.rank == dst:
-            parts = [torch.empty((c1 - c0, self.nrows), dtype=mine.dtype, device=mine.device)
+            parts = [torch.empty((c1 - c0, self.nrows), dtype=wire.dtype, device=wire.device)
                      for c0, c1 in split_columns(self.ncols, self.world)]
-            parts[dst] = mine
+            parts[dst] = wire
             reqs = [dist.irecv(parts[r], r, self.group) for r in range(self.world) if r != dst]
             for q in reqs:
                 q.wait()
-            return torch.cat(parts, dim=0)
-        dist.send(mine, dst, self.group)
+            out = torch.cat(parts, dim=0)
+            return out.to(mine.device) if via_host else out
+        dist.send(wire, dst, self.group)
         return None
 
 

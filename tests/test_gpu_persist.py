@@ -12,15 +12,24 @@ import problems as pb
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def persist_on():
-    old = os.environ.get("PDEIP_EXACT_PERSIST")
+@pytest.fixture(params=["persist", "walk64", "walk48", "walk32"])
+def persist_on(request):
+    """The one-launch form, through round 2's kernel (k_sor_exact_persist, the default) and through round 3's opt-in walker
+    (k_sor_walk: PDEIP_EXACT_WALK=1) at each of its strip widths."""
+    keys = ("PDEIP_EXACT_PERSIST", "PDEIP_EXACT_WALK", "PDEIP_WALK_W")
+    old = {k: os.environ.get(k) for k in keys}
     os.environ["PDEIP_EXACT_PERSIST"] = "1"
-    yield
-    if old is None:
-        os.environ.pop("PDEIP_EXACT_PERSIST", None)
+    if request.param.startswith("walk"):
+        os.environ["PDEIP_EXACT_WALK"] = "1"
+        os.environ["PDEIP_WALK_W"] = request.param[4:]
     else:
-        os.environ["PDEIP_EXACT_PERSIST"] = old
+        os.environ["PDEIP_EXACT_WALK"] = "0"
+    yield
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def _ok(pdeip):

@@ -80,3 +80,76 @@ def test_pingpong_solver_matches_in_place(pdeip):
     assert [t.data_ptr() for t in b] != first  # three calls of one launch each: the iterate sits in the other set
     for f in range(2):
         assert pb.bit_equal(b[f].cpu().numpy(), a[f].cpu().numpy())
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_real_slab_shapes_elin4_4k(pdeip, world):
+    """The slabs `bench.py --gpus N` will meet: the 2160 x 3840 frame cut N ways with the 32-column halo of k = 16 sweeps per
+    exchange -- 2160 x (1920+32 | 960+64 | 480+64) -- each relaxed by the four-sweeps-per-launch pipeline, four calls of iter = 4
+    between two exchanges, relaxing into a second plane set like SlabSolver.solve_pingpong.  Two exchange rounds (32 sweeps);
+    owned columns bit for bit the single domain's."""
+    dev = importlib.import_module("pde-based-image-processing_amd.device")
+    slab = importlib.import_module("pde-based-image-processing_amd.slab")
+    nrows, ncols, k_ex, it = 2160, 3840, 16, 4
+    iterate, coef = _planes("elin4", nrows, ncols)
+    cur = [dev.to_device(a) for a in iterate]
+    cf_g = [dev.to_device(a) for a in coef]
+    sweep = slab.HIP_SWEEPS["elin4"]
+
+    ref, other = [t.clone() for t in cur], [torch.empty_like(t) for t in cur]
+    for _ in range(2 * k_ex // it):
+        sweep(ref, cf_g, it, 1.7, 0, out=other)
+        ref, other = other, ref
+
+    doms = [slab.SlabDomain(ncols, nrows, r, world, halo=2 * k_ex) for r in range(world)]
+    assert max(d.ncols_local for d in doms) == ncols // world + (2 * k_ex if world == 2 else 4 * k_ex)
+    cf_l = [[d.slice_local(t) for t in cf_g] for d in doms]
+    for _ in range(2):
+        nxt = [torch.empty_like(t) for t in cur]
+        for d, cfl in zip(doms, cf_l):
+            a = [d.slice_local(t) for t in cur]              # == the halo exchange from a consistent state
+            b = [torch.empty_like(t) for t in a]
+            for _ in range(k_ex // it):
+                sweep(a, cfl, it, 1.7, d.col0, out=b)
+                a, b = b, a
+            for f in range(len(cur)):
+                nxt[f][d.c0:d.c1] = d.owned(a[f])
+        cur = nxt
+    torch.cuda.synchronize()
+    for f in range(len(cur)):
+        assert torch.equal(cur[f], ref[f]) or pb.bit_equal(cur[f].cpu().numpy(), ref[f].cpu().numpy()), \
+            "world %d field %d: %s" % (world, f, pb.describe_mismatch(cur[f].cpu().numpy(), ref[f].cpu().numpy()))
+
+
+def test_real_slab_shapes_c5_weights_and_sweeps(pdeip):
+    """BASELINE config C5 cut eight ways: 1988 x (360 + 2 x 9) slabs, the loop `DdiffWeights(U + dU)` (a radius-1 stencil stage
+    evaluated locally) + four disparity sweeps on a 9-column halo, one exchange per pass; owned columns bit for bit the single domain's."""
+    dev = importlib.import_module("pde-based-image-processing_amd.device")
+    slab = importlib.import_module("pde-based-image-processing_amd.slab")
+    nrows, ncols, world, k, outer, eps = 1988, 2880, 8, 4, 3, 1e-3
+    iterate, coef = _planes("disp4", nrows, ncols)           # dU | U, Cu, Du, wW, wN, wE, wS
+    dU = dev.to_device(iterate[0])
+    cf_g = [dev.to_device(a) for a in coef]
+    sweep = slab.HIP_SWEEPS["disp4"]
+
+    def loop_body(dU_l, cf_l, col0):
+        dev.diffweights6(cf_l[0] + dU_l, eps, *cf_l[3:])
+        sweep([dU_l], cf_l, k, 1.7, col0)
+
+    ref, cf_ref = dU.clone(), [t.clone() for t in cf_g]
+    for _ in range(outer):
+        loop_body(ref, cf_ref, 0)
+
+    doms = [slab.SlabDomain(ncols, nrows, r, world, halo=2 * k + 1) for r in range(world)]
+    assert doms[3].ncols_local == 360 + 18
+    cf_l = [[d.slice_local(t) for t in cf_g] for d in doms]
+    cur = dU.clone()
+    for _ in range(outer):
+        nxt = torch.empty_like(cur)
+        for d, cfl in zip(doms, cf_l):
+            a = d.slice_local(cur)
+            loop_body(a, cfl, d.col0)
+            nxt[d.c0:d.c1] = d.owned(a)
+        cur = nxt
+    torch.cuda.synchronize()
+    assert pb.bit_equal(cur.cpu().numpy(), ref.cpu().numpy()), pb.describe_mismatch(cur.cpu().numpy(), ref.cpu().numpy())

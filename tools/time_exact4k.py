@@ -1,7 +1,8 @@
 """Exact-order elin4 at 2160 x 3840 (and 1080p): us per call for iter in argv (default 1 4), 20 calls each; environment knobs as set."""
 import importlib, sys, time
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 dev = importlib.import_module("pde-based-image-processing_amd.device")
 iters = [int(a) for a in sys.argv[1:]] or [1, 4]
 for nr, nc in ((2160, 3840), (1080, 1920)):

@@ -25,7 +25,7 @@ for _ in range(3):
     assert fn(None, U.data_ptr(), V.data_ptr(), *[c.data_ptr() for c in coef], nr, nc, it, 1.0, 0) == 0
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 4096)()
-assert lib.pdeip_debug_read_walk_stamps(buf) == 0
+assert lib.pdeip_debug_read_walk2_stamps(buf) == 0
 NC = (nr - 2 + 63 + 15) // 16
 names = ["storer", "compute0", "loader", "compute1", "poller"]
 LOAD, C0 = 2, 1
@@ -44,7 +44,7 @@ if (0, 0) in starts:
                 continue
             st, du = starts[(b, t)]
             cur = ((st - t00) / 1e3, (st + du - t00) / 1e3)
-            if b % 12 == 0 or b >= 58 or b <= 2:
+            if b % 12 == 0 or b >= 58 or b <= 2 or os.environ.get("WALK_STAMPS_ALL"):
                 print("  b=%2d  start %8.1f (%5.1f)   end %8.1f (%5.1f)   walk %6.1f" % (b, cur[0], cur[0] - prev[0] if prev else 0.0, cur[1], cur[1] - prev[1] if prev else 0.0, du / 1e3))
             prev = cur
 print("%d x %d, iter %d, %d chunks; per chunk: busy ns (of the walk's ns per chunk)" % (nr, nc, it, NC))
