@@ -109,6 +109,9 @@ SIGNATURES = {
     "pdeip_warp_bilinear_dev": [_P, _P, _P, _P, _I, _I, _I, _P],
     "pdeip_fst_derivatives5_dev": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     "pdeip_snd_derivatives5_dev": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    # whole drivers, resident (csrc/pdeip_drivers.hip)
+    "pdeip_flow_nd_llin": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "pdeip_disp_nd_llin": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     # library state
     "pdeip_set_mode": [_I],
     "pdeip_get_mode": [],

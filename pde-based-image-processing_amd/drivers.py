@@ -13,7 +13,10 @@ capi.MODE_RED_BLACK the parallel one).
     DispEminND_llin_sym_2D      matlab/disparity/DispEminND_llin_sym_2D.m         symmetric stereo
     TVdenoise8 / TVdenoise4     matlab/denoising/TVdenoise{8,4}.m                 total-variation denoising
 
-Not carried over: the spatial a-priori inputs at driver level (the levels take them: Us=, Vs=) and `scales` limits.
+`Us=`, `Vs=` (param.Us / param.Vs: spatial a-priori fields, double, NaN = no constraint) and `scales=` (param.scales) are taken
+by the late-linearisation flow drivers and the disparity driver as the reference's drivers take them.
+The same two drivers also exist behind the C-ABI (pdeip_flow_nd_llin / pdeip_disp_nd_llin, csrc/pdeip_drivers.hip) for callers
+that are not Python -- the MATLAB session the toolbox runs in: `capi_drivers` below calls those.
 `graph=True` (the llin flow drivers and the FAS driver, parallel orderings): the run's launches are captured into a HIP graph
 on the first call for a frame size and replayed afterwards (graphs.py) -- same kernels and bits, no per-launch host work.
 """
@@ -59,23 +62,51 @@ def _terms(d0, d1, fst, snd):
 _GRAPHS = {}   # (driver, frame shape, parameters) -> graphs.GraphedRun of its device part
 
 
+def _apriori_pyramid(field, shapes, scl_factor):
+    """param.Us down the pyramid (FlowEminND_llin_2D_v10.m:162-184): NaN -> 0, USap{scl} = imresize(USap{scl-1} .* scl_factor), doubles.
+    shapes: (rows, cols) per scale.  Returns the host arrays (finest first)."""
+    us = np.array(field, dtype=np.float64)
+    us[np.isnan(us)] = 0.0
+    out = [us]
+    for rows, cols in shapes[1:]:
+        out.append(pyramid.resize(out[-1] * scl_factor, rows, cols, "bilinear", out_dtype=np.float64))
+    return out
+
+
 def _flow_llin(level_cls, Iin, channels, fstTerm, sndTerm, defaults, mode, param):
     param = dict(param)
     graph = bool(param.pop("graph", False)) and mode != capi.MODE_EXACT_ORDER   # the exact-order schedule tables are uploaded per shape
+    Us, Vs, scales = param.pop("Us", None), param.pop("Vs", None), param.pop("scales", None)
     p = dict(defaults, **param)
     p["sndTerm"] = sndTerm.lower()
     I0, I1 = _frames(Iin, channels)
+    if (Us is not None or Vs is not None) and graph:
+        raise ValueError("graph=True replays a captured run: not with a-priori fields")
 
     def device_part(f0, f1):
-        P0, P1 = pyramid.build_dev(f0, f1, p["scl_factor"], 20)
+        P0, P1 = pyramid.build_dev(f0, f1, p["scl_factor"], 20, max_scales=scales)
         level = level_cls(p, mode=mode)
         U = _zeros_like_plane(P0[-1])
         V = torch.zeros_like(U)
+        shapes = [(t.shape[-1], t.shape[-2]) for t in P0]
+        ap = {}
+        for name, field in (("Us", Us), ("Vs", Vs)):
+            if field is not None:
+                ap[name] = _apriori_pyramid(field, shapes, p["scl_factor"])
+        if "Us" in ap:   # U = USap{scales} (:178): MATLAB's double array; here its float32 rounding, as in the disparity driver
+            U = dev.to_device(ap["Us"][-1].astype(np.float32))
+        if "Vs" in ap:
+            V = dev.to_device(ap["Vs"][-1].astype(np.float32))
         for scl in range(len(P0) - 1, -1, -1):
             d0, d1 = P0[scl], P1[scl]
             (a0, a1), (b0, b1) = _terms(d0, d1, fstTerm, sndTerm)
             args = (a0, a1, U, V) + ((d0,) if level_cls is fl.FlowAdLevel else ()) + (b0, b1)
-            U, V = level.run(*args)
+            kw = {}
+            if ap:
+                on_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(U.device)
+                kw = dict(Us=on_dev(ap["Us"][scl]) if "Us" in ap else None, Vs=on_dev(ap["Vs"][scl]) if "Vs" in ap else None,
+                          as_diff=2.0 * p["scl_factor"] ** scl, u_double=(scl == len(P0) - 1))
+            U, V = level.run(*args, **kw)
             if scl > 0:
                 cols, rows = P0[scl - 1].shape[-2:]
                 U, V = _up(U, 1.0 / p["scl_factor"], rows, cols), _up(V, 1.0 / p["scl_factor"], rows, cols)
@@ -83,7 +114,7 @@ def _flow_llin(level_cls, Iin, channels, fstTerm, sndTerm, defaults, mode, param
 
     f0, f1 = dev.div_scalar(I0, 255.0), dev.div_scalar(I1, 255.0)
     if graph:   # the few thousand launches of the run replayed as one HIP graph (graphs.py); same kernels, same results
-        key = (level_cls.__name__, tuple(I0.shape), fstTerm.lower(), sndTerm.lower(), int(mode), tuple(sorted((k, repr(v)) for k, v in p.items())))
+        key = (level_cls.__name__, tuple(I0.shape), fstTerm.lower(), sndTerm.lower(), int(mode), scales, tuple(sorted((k, repr(v)) for k, v in p.items())))
         if key not in _GRAPHS:
             _GRAPHS[key] = graphs.GraphedRun(device_part)
         U, V = _GRAPHS[key](f0, f1)
@@ -146,14 +177,14 @@ def FlowEminNDFASFMG_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **pa
 DISP_DEFAULTS = dict(alpha=0.042, gammaS=0.005, omega=1.9, firstLoop=4, secondLoop=6, iter=4, b1=1.48, b2=0.29, scl_factor=0.75, solver=2)   # DispEminND_llin_2D.m:51-63
 
 
-def DispEminND_llin_2D(Il, Ir, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, Us=None, **param):
+def DispEminND_llin_2D(Il, Ir, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, Us=None, scales=None, **param):
     """Us: param.Us of the reference, a spatial a-priori disparity map at full resolution (double; NaN = no constraint there,
     zeroed as DispEminND_llin_2D.m:170 does).  It is scaled down with the pyramid (:172-176), starts the coarsest scale (:178;
     there MATLAB's U is that double array itself -- here its float32 rounding, a 1e-8 relative difference in the first
     firstLoop of the coarsest scale) and enters every assembly through the exp influence function (:277-292)."""
     p = dict(DISP_DEFAULTS, **param)
     p["sndTerm"] = sndTerm.lower()
-    P0, P1 = pyramid.build_dev(dev.div_scalar(_c3(Il), 255.0), dev.div_scalar(_c3(Ir), 255.0), p["scl_factor"], 10)
+    P0, P1 = pyramid.build_dev(dev.div_scalar(_c3(Il), 255.0), dev.div_scalar(_c3(Ir), 255.0), p["scl_factor"], 10, max_scales=scales)
     level = fl.DispLlinLevel(p, mode=mode)
     U = _zeros_like_plane(P0[-1])
     USap = None
@@ -233,3 +264,64 @@ def TVdenoise8(I_in, mode=capi.MODE_EXACT_ORDER, **param):
 def TVdenoise4(I_in, mode=capi.MODE_EXACT_ORDER, **param):
     p = dict(dict(alpha=5.0, omega=1.75, outer_iter=10, inner_iter=5, solver=2, scl=0.5, scl_factor=0.75), mode=mode, **param)
     return _tv(I_in, fl.Tv4Level, p, pyramid.gaussian(7, 2.0), smooth_last=True)
+
+
+# ---- the same two drivers through the C-ABI (what the MEX stubs call): host arrays in, host arrays out ----------------------
+_TERM = {"NONE": 0, "RGB": 1, "GRAD": 2, "GRADMAG": 3}
+
+
+def _c_params(param):
+    import ctypes
+
+    class P(ctypes.Structure):
+        _fields_ = [(k, ctypes.c_double) for k in ("alpha", "omega", "gammaS", "b1", "b2", "scl_factor")] + \
+                   [(k, ctypes.c_int) for k in ("firstLoop", "secondLoop", "iter", "solver", "scales")]
+    s = P()
+    for k, _ in P._fields_:
+        setattr(s, k, type(getattr(s, k))(param.get(k, 0) or 0))
+    return s
+
+
+def _f_single(a):
+    a = np.asarray(a, dtype=np.float32)
+    return np.asfortranarray(a if a.ndim == 3 else a[:, :, None])
+
+
+def _f_double(a):
+    return None if a is None else np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def capi_FlowEminND_llin_2D_v10(Iin, channels, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, Us=None, Vs=None, **param):
+    """pdeip_flow_nd_llin on MATLAB-shaped numpy arrays: the C++ twin of FlowEminND_llin_2D_v10 above, same bits."""
+    import ctypes
+    I = _f_single(Iin)
+    rows, cols = I.shape[:2]
+    U, V = np.zeros((rows, cols), np.float32, order="F"), np.zeros((rows, cols), np.float32, order="F")
+    us, vs = _f_double(Us), _f_double(Vs)
+    prm = _c_params(param)
+    old = capi.get_mode()
+    capi.set_mode(mode)
+    try:
+        capi.call("pdeip_flow_nd_llin", I.ctypes.data, rows, cols, int(channels), _TERM[fstTerm.upper()], _TERM[sndTerm.upper()], ctypes.addressof(prm),
+                  None if us is None else us.ctypes.data, None if vs is None else vs.ctypes.data, U.ctypes.data, V.ctypes.data)
+    finally:
+        capi.set_mode(old)
+    return U, V
+
+
+def capi_DispEminND_llin_2D(Il, Ir, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, Us=None, **param):
+    """pdeip_disp_nd_llin on MATLAB-shaped numpy arrays."""
+    import ctypes
+    L, R = _f_single(Il), _f_single(Ir)
+    rows, cols, C = L.shape
+    U = np.zeros((rows, cols), np.float32, order="F")
+    us = _f_double(Us)
+    prm = _c_params(param)
+    old = capi.get_mode()
+    capi.set_mode(mode)
+    try:
+        capi.call("pdeip_disp_nd_llin", L.ctypes.data, R.ctypes.data, rows, cols, C, _TERM[fstTerm.upper()], _TERM[sndTerm.upper()], ctypes.addressof(prm),
+                  None if us is None else us.ctypes.data, U.ctypes.data)
+    finally:
+        capi.set_mode(old)
+    return U

@@ -54,6 +54,21 @@ static float *pdeip_out_like(mxArray **slot, const mxArray *like)
     return (float *)mxGetData(*slot);
 }
 
+/* an optional double [rows x cols] input (param.Us / param.Vs of the drivers): NULL when the argument is empty */
+static const double *pdeip_double_plane(const mxArray *a, int rows, int cols, const char *who, const char *name)
+{
+    char msg[256];
+    if (mxGetNumberOfElements(a) == 0) return NULL;
+    if (!mxIsDouble(a) || mxIsComplex(a) || pdeip_rows(a) != rows || pdeip_cols(a) != cols) {
+        strcpy(msg, who);
+        strcat(msg, ": '");
+        strcat(msg, name);
+        strcat(msg, "' must be a real double matrix of the image's size (or empty).");
+        mexErrMsgTxt(msg);
+    }
+    return (const double *)mxGetData(a);
+}
+
 static void pdeip_check(int rc)
 {
     if (rc != PDEIP_OK) mexErrMsgTxt(pdeip_last_error());

@@ -114,13 +114,15 @@ def build(I0, I1, scl_factor=0.75, min_size=20, G=None):
             return P0, P1
 
 
-def build_dev(d0, d1, scl_factor=0.75, min_size=20, G=None, smooth_last=True):
+def build_dev(d0, d1, scl_factor=0.75, min_size=20, G=None, smooth_last=True, max_scales=None):
     """build() on the device: d0, d1 torch planes [C, ncols, nrows]; the same definitions, bit for bit (device.pyr_resize /
-    pyr_smooth).  smooth_last=False: the symmetric stereo driver leaves its coarsest scale unsmoothed."""
+    pyr_smooth).  smooth_last=False: the symmetric stereo driver leaves its coarsest scale unsmoothed.  max_scales: param.scales
+    of the drivers -- their loop `for scl=2:param.scales` simply ends there, so a scale reached by the limit stays unsmoothed
+    (FlowEminND_llin_2D_v10.m:105-127)."""
     from . import device as dev
     G = gaussian5() if G is None else G
     P0, P1 = [d0], [d1]
-    while True:
+    while max_scales is None or len(P0) < max_scales:
         ncols, nrows = P0[-1].shape[-2:]
         nr, nc = int(math.ceil(nrows * scl_factor)), int(math.ceil(ncols * scl_factor))
         P0.append(dev.pyr_resize(P0[-1], nr, nc))
@@ -130,6 +132,7 @@ def build_dev(d0, d1, scl_factor=0.75, min_size=20, G=None, smooth_last=True):
             if smooth_last:
                 P0[-1], P1[-1] = dev.pyr_smooth(P0[-1], G), dev.pyr_smooth(P1[-1], G)
             return P0, P1
+    return P0, P1
 
 
 def median3(A):

@@ -12,6 +12,7 @@ typedef enum { mxDOUBLE_CLASS = 6, mxSINGLE_CLASS = 7 } mxClassID;
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
 
 bool mxIsSingle(const mxArray *a);
+bool mxIsDouble(const mxArray *a);
 bool mxIsComplex(const mxArray *a);
 void *mxGetData(const mxArray *a);
 size_t mxGetNumberOfElements(const mxArray *a);

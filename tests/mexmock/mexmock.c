@@ -18,6 +18,7 @@ static char g_err[512];
 static size_t elsize(mxClassID c) { return c == mxSINGLE_CLASS ? 4 : 8; }
 
 bool mxIsSingle(const mxArray *a) { return a->classid == mxSINGLE_CLASS; }
+bool mxIsDouble(const mxArray *a) { return a->classid == mxDOUBLE_CLASS; }
 bool mxIsComplex(const mxArray *a) { (void)a; return false; }
 void *mxGetData(const mxArray *a) { return a->data; }
 size_t mxGetNumberOfElements(const mxArray *a)

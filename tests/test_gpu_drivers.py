@@ -150,3 +150,58 @@ def test_graph_replay_gives_the_eager_bits(pdeip):
     a = D.FlowEminND_llin_2D_v10(I, 1, "rgb", "none", solver=1, graph=True)
     b = D.FlowEminND_llin_2D_v10(I, 1, "rgb", "none", solver=1)
     assert pb.bit_equal(a[0], b[0])
+
+
+def test_resident_cxx_drivers_equal_the_python_drivers(pdeip):
+    """pdeip_flow_nd_llin / pdeip_disp_nd_llin (csrc/pdeip_drivers.hip: the level loop in C++ behind the C-ABI, what a MATLAB
+    session reaches through the *_gpu MEX stubs) against the Python drivers, bit for bit: Yosemite as runme.m configures the
+    flow driver ('grad', 'gradmag'), both orderings and solvers, a limited pyramid (param.scales), spatial a-priori fields
+    (param.Us / param.Vs, NaN = unconstrained); the disparity driver on a synthetic stereo pair likewise."""
+    I, Ut, Vt = _yosemite255()
+    D = drv()
+    rng = np.random.default_rng(11)
+    rows, cols = I.shape[:2]
+    cases = [dict(fst="grad", snd="gradmag", kw={}),
+             dict(fst="rgb", snd="none", kw=dict(mode=pdeip.MODE_RED_BLACK, solver=1, omega=1.5)),
+             dict(fst="rgb", snd="rgb", kw=dict(scales=3, firstLoop=2)),
+             dict(fst="grad", snd="none", kw=dict(scales=1, secondLoop=2)),
+             dict(fst="rgb", snd="gradmag", kw=dict(scales=5, Us=np.where(rng.random((rows, cols)) < 0.2, np.nan, Ut).astype(np.float64),
+                                                      Vs=Vt.astype(np.float64), gammaS=0.02, mode=pdeip.MODE_RED_BLACK))]
+    for c in cases:
+        want = D.FlowEminND_llin_2D_v10(I, 1, c["fst"], c["snd"], **c["kw"])
+        got = D.capi_FlowEminND_llin_2D_v10(I, 1, c["fst"], c["snd"], **c["kw"])
+        for g, w in zip(got, want):
+            assert pb.bit_equal(g, w), "flow %s/%s %s: %s" % (c["fst"], c["snd"], sorted(c["kw"]), pb.describe_mismatch(g, w))
+    left, right = _stereo_pair()
+    L3, R3 = np.stack([left] * 3, axis=2).astype(np.float32), np.stack([right] * 3, axis=2).astype(np.float32)
+    us = np.full(left.shape, 3.0)
+    us[::3] = np.nan
+    for fst, snd, kw in (("grad", "gradmag", {}), ("rgb", "none", dict(mode=pdeip.MODE_RED_BLACK, solver=1, omega=1.5, scales=4)),
+                         ("rgb", "rgb", dict(Us=us, firstLoop=2))):
+        want = D.DispEminND_llin_2D(L3, R3, fst, snd, **kw)
+        got = D.capi_DispEminND_llin_2D(L3, R3, fst, snd, **kw)
+        assert pb.bit_equal(got, want), "disparity %s/%s %s: %s" % (fst, snd, sorted(kw), pb.describe_mismatch(got, want))
+    with pytest.raises(pdeip.capi.PdeipError):
+        D.capi_FlowEminND_llin_2D_v10(I, 1, "gradmag", "none")   # 'No such fstTerm'
+
+
+def test_driver_stubs_through_the_mock_mex_runtime(pdeip):
+    """mex/FlowEminND_llin_2D_v10_gpu.c and mex/DispEminND_llin_2D_gpu.c called as MATLAB would call them (numeric arguments:
+    the .m wrappers under matlab/ translate the drivers' own argument lists): the Python driver's bits."""
+    import test_mex_stubs as tm
+    I, Ut, Vt = _yosemite255()
+    D = drv()
+    f = np.float32
+    pv = np.array([0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 6], dtype=np.float32).reshape(1, 11)   # firstLoop = 2, scales = 6, the rest default
+    err, outs = tm.call(tm.build_stub("FlowEminND_llin_2D_v10_gpu", pdeip), 2, [I, f(1), f(2), f(3), pv])
+    assert err is None, err
+    want = D.FlowEminND_llin_2D_v10(I, 1, "grad", "gradmag", firstLoop=2, scales=6)
+    assert pb.bit_equal(outs[0], want[0]) and pb.bit_equal(outs[1], want[1])
+    err, _ = tm.call(tm.build_stub("FlowEminND_llin_2D_v10_gpu", pdeip), 2, [I, f(2), f(2), f(3), pv])
+    assert "2*channels" in err
+    left, right = _stereo_pair()
+    L3, R3 = np.stack([left] * 3, axis=2).astype(np.float32), np.stack([right] * 3, axis=2).astype(np.float32)
+    us = np.full(left.shape, 3.0)
+    err, outs = tm.call(tm.build_stub("DispEminND_llin_2D_gpu", pdeip), 1, [L3, R3, f(1), f(0), np.zeros((1, 11), np.float32), us])
+    assert err is None, err
+    assert pb.bit_equal(outs[0], D.DispEminND_llin_2D(L3, R3, "rgb", "none", Us=us))
