@@ -419,6 +419,20 @@ def main():
                 if mode == capi.MODE_EXACT_ORDER:
                     hc["exact_order_max_abs_vs_cpu"] = float(max(np.abs(ou.astype(np.float64) - first[0]).max(), np.abs(ov.astype(np.float64) - first[1]).max()))
             hc["bytes_over_pcie"] = (13 + 2) * 4 * N
+            # the link as this process sees it: one pageable 33 MB plane up, timed alone (what the entry point's own copies do)
+            probe_h, probe_d = U0.cpu(), torch.empty_like(U0)
+            for _ in range(3):
+                probe_d.copy_(probe_h)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                probe_d.copy_(probe_h)
+            torch.cuda.synchronize()
+            up_s = (time.perf_counter() - t0) / 10
+            hc["h2d_gbs_one_plane"] = round(4 * N / up_s / 1e9, 1)
+            hc["link_bound_ms"] = {"13_planes_up": round(13 * up_s * 1e3, 3), "13_up_plus_2_down_serial": round(15 * up_s * 1e3, 3)}
+            hc["overlap"] = "red-black call cut into 6 column slabs on two worker threads (upload | sweeps | download of different slabs), PDEIP_HOST_OVERLAP"
+            del probe_h, probe_d
             hc["workload"] = "pdeip_oflow_sor_elin4, host pointers, 2160x3840, iter=4, median of 7 calls"
             out["host_call"] = hc
             del Ur, Vr, Ux, Vx

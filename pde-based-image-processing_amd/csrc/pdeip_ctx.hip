@@ -220,6 +220,8 @@ static void release_device(DeviceState *d)
         d->ws[s] = nullptr;
         d->ws_bytes[s] = 0;
     }
+    if (d->worker_stream) (void)hipStreamDestroy(d->worker_stream);
+    d->worker_stream = nullptr;
     d->reset_caches();
 }
 

@@ -37,6 +37,7 @@ struct DeviceState {
     bool abort_latched = false;   // a persistent kernel's abort word was seen set before its buffer went away
     std::map<const void *, size_t> lds_opt_in; // kernel -> dynamic LDS bytes opted into (hipFuncSetAttribute is per device)
     std::map<const void *, int> resident_waves; // kernel -> waves the device holds at once (occupancy query)
+    hipStream_t worker_stream = nullptr; // the stream a worker thread of a slab-split host call uses on this device (pdeip_multi.hip)
     void reset_caches()
     {
         order_B = order_T = 0;

@@ -25,8 +25,10 @@ using namespace pdeip;
 
 namespace pdeip {
 
+constexpr int OVERLAP_SLABS = 6;
 struct SlabPlan {
-    int nslabs = 1, halo = 0;
+    int nslabs = 1, halo = 0, nrows = 0;
+    bool overlap = false;
     int c0[MAX_DEVICES], c1[MAX_DEVICES], lo[MAX_DEVICES], hi[MAX_DEVICES], dev[MAX_DEVICES];
 };
 
@@ -37,6 +39,14 @@ int multi_plan(int ncols, int halo, SlabPlan *plan)
     int want = g.ngroup;
     const int virt = env_int("PDEIP_VIRTUAL_SLABS", 0); // testing: that many slabs, dealt round-robin over the group
     if (virt > want) want = virt;
+    // One device and a large frame: the call is a PCIe transfer (13-17 planes up, 1-2 down) with a short kernel in between.
+    // Cut into OVERLAP_SLABS column slabs on two worker threads with a stream each, the upload of one slab runs beside the
+    // sweeps and the download of another (the link is full duplex): PDEIP_HOST_OVERLAP=0 keeps the single serial pass.
+    plan->overlap = false;
+    if (want == 1 && virt <= 0 && env_int("PDEIP_HOST_OVERLAP", 1) != 0 && (long)ncols * plan->nrows >= (1L << 21) && ncols / OVERLAP_SLABS >= 4 * (halo + 1)) {
+        want = OVERLAP_SLABS;
+        plan->overlap = true;
+    }
     if (want > MAX_DEVICES) want = MAX_DEVICES;
     while (want > 1 && ncols / want < halo + 1) want--; // every slab wider than its halo
     plan->nslabs = want;
@@ -56,7 +66,7 @@ int multi_plan(int ncols, int halo, SlabPlan *plan)
 }
 
 // One solver call on one slab (MultiCall: pdeip_ctx.hpp).  Runs in the calling thread on the current device.
-static int slab_run(const MultiCall &mc, const SlabPlan &plan, int k)
+static int slab_run(const MultiCall &mc, const SlabPlan &plan, int k, hipStream_t st)
 {
     const int lo = plan.lo[k], hi = plan.hi[k], ncl = hi - lo, nrows = mc.nrows, F = mc.frames;
     const size_t full = (size_t)nrows * mc.ncols, slab = (size_t)nrows * ncl;
@@ -71,7 +81,7 @@ static int slab_run(const MultiCall &mc, const SlabPlan &plan, int k)
     };
     auto up = [&](float *dst, const float *src) -> int { // columns [lo, hi) of every frame
         for (int f = 0; f < F; f++)
-            HIPCHK(hipMemcpy(dst + (size_t)f * slab, src + (size_t)f * full + (size_t)lo * nrows, slab * sizeof(float), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpyAsync(dst + (size_t)f * slab, src + (size_t)f * full + (size_t)lo * nrows, slab * sizeof(float), hipMemcpyHostToDevice, st));
         return PDEIP_OK;
     };
     float *d_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr}, *d_ro[2] = {nullptr, nullptr}, *d_cf[11] = {};
@@ -91,24 +101,24 @@ static int slab_run(const MultiCall &mc, const SlabPlan &plan, int k)
     const int mode = PDEIP_MODE_RED_BLACK, col0 = lo;
     switch (mc.kind) {
     case 0:
-        RC(pdeip_oflow_sor_elin4_dev_to(nullptr, d_in[0], d_in[1], d_out[0], d_out[1], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4], d_cf[5], d_cf[6],
+        RC(pdeip_oflow_sor_elin4_dev_to(st, d_in[0], d_in[1], d_out[0], d_out[1], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4], d_cf[5], d_cf[6],
                                         d_cf[7], d_cf[8], nrows, ncl, mc.iter, mc.omega, mode, col0));
         break;
     case 1:
-        RC(pdeip_oflow_sor_llin4_dev_to(nullptr, d_ro[0], d_ro[1], d_in[0], d_in[1], d_out[0], d_out[1], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4],
+        RC(pdeip_oflow_sor_llin4_dev_to(st, d_ro[0], d_ro[1], d_in[0], d_in[1], d_out[0], d_out[1], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4],
                                         d_cf[5], d_cf[6], d_cf[7], d_cf[8], nrows, ncl, mc.iter, mc.omega, mode, col0));
         break;
     case 2:
-        RC(pdeip_disp_sor_llin4_dev_to(nullptr, d_ro[0], d_in[0], d_out[0], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4], d_cf[5], nrows, ncl, mc.iter,
+        RC(pdeip_disp_sor_llin4_dev_to(st, d_ro[0], d_in[0], d_out[0], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4], d_cf[5], nrows, ncl, mc.iter,
                                        mc.omega, mode, col0));
         break;
     case 3:
-        RC(pdeip_pde_sor4_dev_to(nullptr, d_in[0], d_out[0], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4], d_cf[5], nrows, ncl, F, mc.iter, mc.omega,
+        RC(pdeip_pde_sor4_dev_to(st, d_in[0], d_out[0], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4], d_cf[5], nrows, ncl, F, mc.iter, mc.omega,
                                  mode, col0));
         break;
     case 4: // the 9-point solver relaxes in place: on a copy
-        HIPCHK(hipMemcpyAsync(d_out[0], d_in[0], slab * F * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
-        RC(pdeip_pde_sor8_dev(nullptr, d_out[0], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4], d_cf[5], d_cf[6], d_cf[7], d_cf[8], d_cf[9], nrows, ncl, F,
+        HIPCHK(hipMemcpyAsync(d_out[0], d_in[0], slab * F * sizeof(float), hipMemcpyDeviceToDevice, st));
+        RC(pdeip_pde_sor8_dev(st, d_out[0], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4], d_cf[5], d_cf[6], d_cf[7], d_cf[8], d_cf[9], nrows, ncl, F,
                               mc.iter, mc.omega, mode, col0));
         break;
     default:
@@ -118,8 +128,9 @@ static int slab_run(const MultiCall &mc, const SlabPlan &plan, int k)
     const int own0 = plan.c0[k] - lo, nown = plan.c1[k] - plan.c0[k];
     for (int p = 0; p < mc.n_it; p++)
         for (int f = 0; f < F; f++)
-            HIPCHK(hipMemcpy(mc.it_out[p] + (size_t)f * full + (size_t)plan.c0[k] * nrows, d_out[p] + (size_t)f * slab + (size_t)own0 * nrows,
-                             (size_t)nown * nrows * sizeof(float), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpyAsync(mc.it_out[p] + (size_t)f * full + (size_t)plan.c0[k] * nrows, d_out[p] + (size_t)f * slab + (size_t)own0 * nrows,
+                                  (size_t)nown * nrows * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st)); // the arena is reused by this worker's next slab; the caller's planes are pageable
     return PDEIP_OK;
 }
 
@@ -130,6 +141,7 @@ int multi_sor(const MultiCall &mc, int *handled)
     *handled = 0;
     if (mc.iter <= 0) return PDEIP_OK;
     SlabPlan plan;
+    plan.nrows = mc.nrows;
     if (multi_plan(mc.ncols, 2 * mc.iter, &plan) <= 1) return PDEIP_OK;
     *handled = 1;
     // one thread per distinct device; each walks its slabs in order.  PDEIP_VIRTUAL_THREADS=n (testing, one-device group
@@ -139,7 +151,7 @@ int multi_sor(const MultiCall &mc, int *handled)
     char errs[MAX_DEVICES][256] = {};
     std::thread th[MAX_DEVICES];
     int nth = 0, devs[MAX_DEVICES], slot[MAX_DEVICES], owner[MAX_DEVICES];
-    int vthreads = g.ngroup == 1 ? env_int("PDEIP_VIRTUAL_THREADS", 0) : 0;
+    int vthreads = g.ngroup == 1 ? env_int("PDEIP_VIRTUAL_THREADS", plan.overlap ? 2 : 0) : 0;
     if (vthreads > plan.nslabs) vthreads = plan.nslabs;
     if (vthreads > MAX_DEVICES / 2) vthreads = MAX_DEVICES / 2;
     if (vthreads > 1) {
@@ -168,14 +180,21 @@ int multi_sor(const MultiCall &mc, int *handled)
         }
         const int keep_slot = tls.dev_slot;
         tls.dev_slot = slot[ti];
-        cur_dev()->device = devs[ti];
+        DeviceState *ds = cur_dev();
+        ds->device = devs[ti];
+        if (ds->worker_stream == nullptr && hipStreamCreateWithFlags(&ds->worker_stream, hipStreamNonBlocking) != hipSuccess) {
+            rc[ti] = PDEIP_ERR_DEVICE;
+            snprintf(errs[ti], sizeof errs[ti], "multi-device call: cannot create a stream on device %d", devs[ti]);
+            tls.dev_slot = keep_slot;
+            return;
+        }
         for (int k = 0; k < plan.nslabs && rc[ti] == PDEIP_OK; k++)
             if (owner[k] == ti) {
-                rc[ti] = slab_run(mc, plan, k);
+                rc[ti] = slab_run(mc, plan, k, ds->worker_stream);
                 launches[ti] += tls.last_launches;
                 if (rc[ti] != PDEIP_OK) snprintf(errs[ti], sizeof errs[ti], "%s", tls.err); // this thread's own text
             }
-        if (rc[ti] == PDEIP_OK && hipDeviceSynchronize() != hipSuccess) rc[ti] = PDEIP_ERR_DEVICE;
+        if (rc[ti] == PDEIP_OK && hipStreamSynchronize(ds->worker_stream) != hipSuccess) rc[ti] = PDEIP_ERR_DEVICE;
         tls.dev_slot = keep_slot;
     };
     if (nth == 1) work(0); // virtual slabs on one device: no thread needed
