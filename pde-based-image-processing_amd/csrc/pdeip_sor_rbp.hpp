@@ -195,11 +195,14 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
     // R*: own fields after this sweep's red half at x-2, x-1, x.
     float O0[NIT][4], O1[NIT][4], O2[NIT][4], R0[NF][4], R1[NF][4], R2[NF][4];
     float Q2[NRO1][4], Q1[NRO1][4], Q0[NRO1][4], Qn[NRO1][4]; // read-only fields at x-2, x-1, x, x+1 (moved: four columns, few planes)
-    float KA[NCF][4], KB[NCF][4]; // coefficients of columns x-1 and x, roles alternating: each column is read from the K ring once
+    // coefficients of columns x-1, x and x+1, roles rotating: each column is read from the K ring once -- one step AHEAD of its
+    // use (round 3): a step then waits for the two planes its predecessor handed over, not for nine more (the K column of
+    // group t has landed when step t begins: the loader brings it in with the O column the same step reads)
+    float KA[NCF][4], KB[NCF][4], KC[NCF][4];
 #pragma unroll
     for (int f = 0; f < NCF; f++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) KA[f][e] = KB[f][e] = 0.0f;
+        for (int e = 0; e < 4; e++) KA[f][e] = KB[f][e] = KC[f][e] = 0.0f;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
 #pragma unroll
@@ -214,20 +217,25 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
     int ki = ((-3 * s - 1) % L::NK + L::NK) % L::NK, qi = ((-3 * s) % L::NQ + L::NQ) % L::NQ, oi = 0, hp = 1;
 
     auto step = [&](int t, float (&Om)[NIT][4], float (&Oc)[NIT][4], float (&Op)[NIT][4], float (&Rpp)[NF][4], float (&Rp)[NF][4],
-                    float (&Rc)[NF][4], const float (&Kp)[NCF][4], float (&Kc)[NCF][4]) __attribute__((always_inline)) {
+                    float (&Rc)[NF][4], const float (&Kp)[NCF][4], float (&Kc)[NCF][4], float (&Kn)[NCF][4]) __attribute__((always_inline)) {
         const int x = xbase + t - 3 * s; // this wave's red column; black on x-1
 #ifdef PDEIP_RBP_STAMPS
         const bool stamp_on = (blockIdx.x == 100) && (s == RBP_STAMP_SWEEP) && (F0 == 0) && (t >= RBP_STAMP_T0) && (t < RBP_STAMP_T0 + 24);
 #endif
         RBP_STAMP(0);
         // ---- take in column x+1 of the previous sweep's result, and the coefficients of columns x and x-1 ----
-        float *const ks = Kring + (size_t)ki * NCF * COL; // column x; column x-1 (Kp) is the Kc of the previous step, kept in registers
+        float *const ks = Kring + (size_t)ki * NCF * COL; // slot of column x (Kc, read one step ago; column x-1 is Kp)
         {
             const float *src = (s == 0) ? Oring + (size_t)oi * NIT * COL : Hring + (size_t)((s - 1) * 2 + hp) * NIT * COL;
 #pragma unroll
             for (int f = 0; f < NIT; f++) rbp_lds_read(Op[f], src + f * COL, lane);
+            if (t == 0) {
 #pragma unroll
-            for (int f = 0; f < NCF; f++) rbp_lds_read(Kc[f], ks + f * COL, lane);
+                for (int f = 0; f < NCF; f++) rbp_lds_read(Kc[f], ks + f * COL, lane);
+            }
+            const float *kn = Kring + (size_t)(ki + 1 == L::NK ? 0 : ki + 1) * NCF * COL; // column x+1, for the next step
+#pragma unroll
+            for (int f = 0; f < NCF; f++) rbp_lds_read(Kn[f], kn + f * COL, lane);
 #pragma unroll
             for (int f = 0; f < NRO1; f++)
                 if (NRO > 0) {
@@ -378,14 +386,11 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
     };
 
     rbp_barrier(); // group 0 is in LDS
-    // the O/R windows rotate with period 3, the coefficient pair (column x-1, column x) with period 2: six steps per trip
-    for (int t = 0; t < nsteps; t += 6) {
-        step(t, O0, O1, O2, R0, R1, R2, KA, KB);
-        if (t + 1 < nsteps) step(t + 1, O1, O2, O0, R1, R2, R0, KB, KA);
-        if (t + 2 < nsteps) step(t + 2, O2, O0, O1, R2, R0, R1, KA, KB);
-        if (t + 3 < nsteps) step(t + 3, O0, O1, O2, R0, R1, R2, KB, KA);
-        if (t + 4 < nsteps) step(t + 4, O1, O2, O0, R1, R2, R0, KA, KB);
-        if (t + 5 < nsteps) step(t + 5, O2, O0, O1, R2, R0, R1, KB, KA);
+    // the O/R windows and the coefficient triple (columns x-1, x, x+1) rotate with period 3: three steps per trip
+    for (int t = 0; t < nsteps; t += 3) {
+        step(t, O0, O1, O2, R0, R1, R2, KA, KB, KC);
+        if (t + 1 < nsteps) step(t + 1, O1, O2, O0, R1, R2, R0, KB, KC, KA);
+        if (t + 2 < nsteps) step(t + 2, O2, O0, O1, R2, R0, R1, KC, KA, KB);
     }
 }
 
