@@ -349,12 +349,23 @@ def main():
         edt, ems, enl = timed(step_exact, e_steps, max(3, args.warmup // 10))
         e_launch_s = ems * 1e-3 / max(enl, 1)
         e_bytes = BYTES_PER_PIXEL_SWEEP * N * ITER * e_steps / max(enl, 1)  # tiles of one front per launch
+        e_kernel = "k_sor_walk<ModelElin4>" if os.environ.get("PDEIP_EXACT_WALK", "0") not in ("", "0") else "k_sor_exact_persist<ModelElin4>"
+        e_traffic = None
+        try:   # PMC FETCH_SIZE x 2 + WRITE_SIZE of the walkers' launch, per schedule kind (profiles/traffic.json)
+            tkey = "k_sor_exact_persist_elin4_2160x3840_exact_" + ("xcd_affine" if os.environ.get("PDEIP_PERSIST_XCD", "0") not in ("", "0") else "single_list")
+            e_traffic = json.load(open(tr)).get(tkey, {}).get("bytes_per_launch") if e_kernel.startswith("k_sor_exact") else None
+        except (ValueError, OSError):
+            pass
         out["exact_order"] = {
             "value": round(e_steps * ITER / edt, 2), "unit": "iterations/s", "ms_per_step": round(edt / e_steps * 1e3, 4),
-            "launches_per_step": enl // e_steps,
-            "roofline": {"bound": "hbm", "kernel": "k_sor_exact_persist<ModelElin4>", "achieved": round(e_bytes / e_launch_s / 1e9, 1),
+            "launches_per_step": enl // e_steps, "timed_calls": e_steps,
+            "schedule": "per-XCD lists (PDEIP_PERSIST_XCD=1: needs the grid resident)" if os.environ.get("PDEIP_PERSIST_XCD", "0") not in ("", "0") else "single key-ordered list (default)",
+            "roofline": {"bound": "hbm", "kernel": e_kernel, "achieved": round(e_bytes / e_launch_s / 1e9, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e_bytes / e_launch_s / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": None, "launch_us": round(e_launch_s * 1e6, 2)},
+                         "traffic": e_traffic, "launch_us": round(e_launch_s * 1e6, 2),
+                         "frac_hbm": round(e_traffic / e_launch_s / 1e9 / HBM_PEAK_GBS, 4) if e_traffic else None,
+                         "limiter": "one compute unit's memory pipeline per 16-row chunk (46 KB in + 8 KB out per walker) and the strips' start-up "
+                                    "chain: DESIGN.md 5.2 (stamped model), profiles/NOTES.md R3.1"},
         }
         # the same frame with iter=20 per call (the Horn-Schunck driver's setting): the persistent kernel
         def step_exact20():

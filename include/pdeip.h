@@ -91,6 +91,10 @@ int pdeip_workspace_generation(void);
 /* Waits for the device and reports PDEIP_ERR_DEVICE if a bounded dependency wait of the persistent
  * exact-order kernel (PDEIP_EXACT_PERSIST=1) timed out during the preceding calls. */
 int pdeip_persist_error(void);
+/* Diagnostic: sets the sticky abort word as a timed-out dependency wait of an exact-order walker would (calls made while it is set
+ * drain at once, their results are invalid), to exercise the reporting path: pdeip_persist_error() must return PDEIP_ERR_DEVICE
+ * once and clear it. */
+int pdeip_debug_raise_abort(void);
 /* Diagnostic: the schedule table the exact-order walkers would use for B strips x T sweeps (affine: the XCD-affine lists of
  * PDEIP_PERSIST_XCD=1), built on the device as a call builds it and copied to `table` (16 + B*T ints: list offsets 0..8, items
  * b | t << 16 from int 16 on). */

@@ -123,6 +123,7 @@ SIGNATURES = {
     "pdeip_workspace_generation": [],
     "pdeip_persist_error": [],
     "pdeip_debug_persist_order": [_I, _I, _I, ctypes.POINTER(ctypes.c_int)],
+    "pdeip_debug_raise_abort": [],
     "pdeip_profile_enable": [_I],
     "pdeip_profile_read": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
 }

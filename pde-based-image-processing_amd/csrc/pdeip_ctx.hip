@@ -306,6 +306,22 @@ extern "C" int pdeip_persist_error(void)
     if (bad) return set_err(PDEIP_ERR_DEVICE, "persistent exact-order kernel: a dependency wait timed out (results are invalid)");
     return PDEIP_OK;
 }
+// Diagnostic: raises the abort word of the current device's control block as a timed-out dependency wait of a walker would (the
+// walkers' waits then fall through: a call made with the word set drains at once and its results are invalid), so that the
+// reporting path -- pdeip_persist_error(), the latch across a regrown control block, the host entry points' check -- can be
+// tested without waiting half a second for a real time-out.
+extern "C" int pdeip_debug_raise_abort(void)
+{
+    RC(use_device());
+    float *ctl = nullptr;
+    RC(ws_get(WS_CTL, 16, &ctl));
+    const unsigned one = 1u;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(ctl, &one, sizeof one, hipMemcpyHostToDevice));
+    cur_dev()->persist_used = true;
+    return PDEIP_OK;
+}
+
 extern "C" int pdeip_profile_enable(int on)
 {
     g.profile = (on != 0);

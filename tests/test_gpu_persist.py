@@ -212,3 +212,31 @@ def test_schedule_table_built_on_the_device(pdeip, B, T):
         hdr, items = _host_order(B, T, affine)
         assert list(buf[:9]) == hdr, (B, T, affine, list(buf[:9]), hdr)
         assert list(buf[16:]) == items, (B, T, affine)
+
+
+def test_abort_word_is_reported_once_and_survives_a_regrown_control_block(pdeip, oracle):
+    """The reporting path of a timed-out dependency wait, without the half second: pdeip_debug_raise_abort sets the sticky word
+    as a walker would.  A call made while it is set still terminates (every wait falls through); the host entry point then
+    fails loudly instead of handing back invalid planes; pdeip_persist_error reports once and clears; a control block that is
+    regrown (a larger call) in between does not lose the report; afterwards results are exact again."""
+    lib, api = pdeip.capi.load(), pdeip.mex_api
+    api.set_mode(0)
+    p = pb.elin4(841, 70, 150)
+    run = lambda q=p, it=3: api.Oflow_sor_elin4_2d(*q.values(), np.float32(it), np.float32(1.9), np.float32(1))
+    want = oracle.Oflow_sor_elin4_2d(*p.values(), 3, 1.9)
+    for g, w in zip(run(), want):
+        assert pb.bit_equal(g, w)
+    assert lib.pdeip_debug_raise_abort() == 0
+    with pytest.raises(api.MexError):          # the gateway checks pdeip_persist_error() before it returns planes
+        run()
+    assert lib.pdeip_persist_error() == 0      # reported by the failed call: cleared
+    for g, w in zip(run(), want):
+        assert pb.bit_equal(g, w)
+    # latch: raise it, then make a call that needs a larger control block (more strips x sweeps) -- the old block is read before it goes
+    assert lib.pdeip_debug_raise_abort() == 0
+    big = pb.elin4(842, 40, 2300)
+    with pytest.raises(api.MexError):
+        run(big, 9)
+    assert lib.pdeip_persist_error() == 0
+    for g, w in zip(run(), want):
+        assert pb.bit_equal(g, w)

@@ -1,6 +1,6 @@
 """Two FlowEminND_llin_2D_v10 runs at 1080p (red-black SOR) for rocprofv3 --kernel-trace --stats: the driver's kernel mix."""
 import importlib, sys
-sys.path.insert(0, "."); import numpy as np, torch
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); import numpy as np, torch
 drivers = importlib.import_module("pde-based-image-processing_amd.drivers"); capi = importlib.import_module("pde-based-image-processing_amd").capi
 jj, ii = np.meshgrid(np.arange(1920), np.arange(1080))
 tex = lambda di, dj, c: (np.sin(0.021 * (ii + di) + c) * np.cos(0.017 * (jj + dj) - c) + 0.3 * np.sin(0.11 * (ii + di) + 0.07 * (jj + dj))).astype(np.float32)

@@ -1,6 +1,6 @@
 """Does a whole FAS-FMG run replay as a HIP graph (torch.cuda.graph capture of the library's launches)?"""
 import sys, time, importlib
-sys.path.insert(0, "."); import numpy as np, torch
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); import numpy as np, torch
 fas = importlib.import_module("pde-based-image-processing_amd.fas"); dev = importlib.import_module("pde-based-image-processing_amd.device")
 nr, nc = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2160, 3840)
 jj, ii = np.meshgrid(np.arange(nc), np.arange(nr))

@@ -1,7 +1,7 @@
 """Zebra line relaxation per call (iter = 4, elin4 / llin4 / disp4) on the pyramids' coarse scales: us per call."""
 import importlib, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 dev = importlib.import_module("pde-based-image-processing_amd.device")
 for nr, nc in [(135, 240), (82, 145), (68, 120), (34, 60), (17, 30), (61, 108)]:
     g = torch.Generator(device="cuda").manual_seed(1)

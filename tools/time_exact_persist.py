@@ -1,6 +1,6 @@
 """Exact-order point SOR: launch-per-front vs persistent kernel by iter and frame size (run twice: PDEIP_EXACT_PERSIST=0 / 1)."""
 import importlib, os, sys, time
-sys.path.insert(0, "."); import torch
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); import torch
 dev = importlib.import_module("pde-based-image-processing_amd.device")
 print("PDEIP_EXACT_PERSIST =", os.environ.get("PDEIP_EXACT_PERSIST"))
 for nr, nc in ((2160, 3840), (1080, 1920), (388, 584), (135, 240), (34, 60)):

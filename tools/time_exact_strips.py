@@ -2,7 +2,7 @@
 the strip hand-off lag (columns) of the persistent wavefront kernel, separated."""
 import importlib, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 dev = importlib.import_module("pde-based-image-processing_amd.device")
 import os
 for nr, nc in [tuple(int(x) for x in v.split('x')) for v in os.environ.get('SHAPES', '2160x1026,2160x2050,2160x3840').split(',')]:

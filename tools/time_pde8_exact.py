@@ -3,7 +3,7 @@
 import importlib, os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 dev = importlib.import_module("pde-based-image-processing_amd.device")
 capi = importlib.import_module("pde-based-image-processing_amd.capi")
 shapes = [(2160, 3840, 4), (2160, 3840, 20), (1080, 1920, 4), (540, 960, 4), (135, 240, 4)]

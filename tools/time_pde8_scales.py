@@ -1,5 +1,5 @@
 import sys, time, importlib
-sys.path.insert(0, "."); import torch
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); import torch
 dev = importlib.import_module("pde-based-image-processing_amd.device")
 for nr, nc in ((2160, 3840), (540, 960), (135, 240), (34, 60)):
     g = torch.Generator(device="cuda").manual_seed(1)

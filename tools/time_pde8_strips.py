@@ -1,7 +1,7 @@
 """k_pde8_exact_persist: time per call against the number of strips and sweeps (chunk time, strip lag, sweep lag)."""
 import importlib, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 dev = importlib.import_module("pde-based-image-processing_amd.device")
 capi = importlib.import_module("pde-based-image-processing_amd.capi")
 def run(nr, nc, it):

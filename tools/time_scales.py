@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 pk = importlib.import_module("pde-based-image-processing_amd")
 dev = importlib.import_module("pde-based-image-processing_amd.device")
 capi = importlib.import_module("pde-based-image-processing_amd.capi")

@@ -1,7 +1,7 @@
 """Red-black solver call (iter = 4, in place) per pyramid scale: us per call for each model, A/B over env knobs."""
 import importlib, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 dev = importlib.import_module("pde-based-image-processing_amd.device")
 shapes = [(540, 960), (270, 480), (135, 240), (68, 120), (34, 60), (17, 30), (456, 810), (342, 608), (257, 456), (193, 342), (145, 257), (109, 193), (82, 145), (61, 108)]
 if len(sys.argv) > 1:
