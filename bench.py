@@ -143,6 +143,9 @@ def host_call(capi, U, V, coef, mode, reps=7):
 
 
 def main():
+    # The bench owns the device: the exact-order walkers may take the per-XCD lists (an opt-in because they are live only while
+    # the call's whole grid is resident: DESIGN.md 5.2).  Reported in config.knobs; PDEIP_PERSIST_XCD=0 in the environment wins.
+    os.environ.setdefault("PDEIP_PERSIST_XCD", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -592,13 +595,13 @@ def main():
                     drv.run(d0, d1)
                 torch.cuda.synchronize()
                 fmg[name] = round((time.perf_counter() - t0) / nrep * 1e3, 2)
-                if mode == capi.MODE_RED_BLACK:
+                if True:
                     # the same launches replayed from a captured HIP graph (graphs.py): bit-identical, no per-launch host work;
                     # the eager figure above is bound by the host enqueueing ~1 700 launches
                     ref = [t.clone() for t in drv.run(d0, d1)]
                     drv.run_graph(d0, d1)
                     torch.cuda.synchronize()
-                    reps = 20
+                    reps = nrep
                     t0 = time.perf_counter()
                     for _ in range(reps):
                         got = drv.run_graph(d0, d1)

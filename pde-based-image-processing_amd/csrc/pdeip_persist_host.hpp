@@ -33,6 +33,13 @@ static __device__ __forceinline__ int persist_count_below(int lim, int B, int af
     if (n <= 0) return 0;
     return affine ? (n - x + 7) / 8 : n;
 }
+// Clears the control block and the mailbox of a call (words 1 .. n-1; word 0 is the sticky abort word).  A kernel rather than
+// hipMemsetAsync: an exact-order call captured into a HIP graph replayed with stale counters when the clear was a memset node.
+static __global__ void k_persist_clear(unsigned *words, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i < n) words[i] = 0u;
+}
 static __global__ void k_persist_order(int *table, int B, int T, int affine)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,16 +76,25 @@ inline int persist_prepare(hipStream_t s, int B, int iter, int nframes, size_t m
     // finished, whatever else holds compute units.  The XCD-affine lists (3-5 % faster at 4K) are live only while every
     // workgroup of the grid is resident, which a library inside somebody else's process cannot know: opt-in, PDEIP_PERSIST_XCD=1.
     const int affine = (env_int("PDEIP_PERSIST_XCD", 0) != 0 && nprog <= (size_t)dst->num_cus) ? 1 : 0;
+    // While the stream is being captured into a HIP graph the table is rebuilt by every call: what the cache says at capture time
+    // need not be what the buffer holds when the graph is replayed (other calls may have run in between)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (capturing) dst->order_B = dst->order_T = 0;
     if (dst->order_B != B || dst->order_T != iter || dst->order_affine != affine) {
         // built on the call's stream by a kernel: no host table, no synchronisation, capturable into a HIP graph
         const int nitems = B * iter;
         hipLaunchKernelGGL(k_persist_order, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, s, reinterpret_cast<int *>(order_f), B, iter, affine);
         HIPCHK(hipGetLastError());
-        dst->order_B = B;
-        dst->order_T = iter;
+        dst->order_B = capturing ? 0 : B; // a captured build says nothing about the buffer's content outside the graph
+        dst->order_T = capturing ? 0 : iter;
         dst->order_affine = affine;
     }
-    HIPCHK(hipMemsetAsync(reinterpret_cast<unsigned *>(ctl_f) + 1, 0, ctl_bytes - sizeof(unsigned) + mail_bytes, s));
+    {
+        const size_t nwords = (ctl_bytes + mail_bytes) / sizeof(unsigned);
+        hipLaunchKernelGGL(k_persist_clear, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, s, reinterpret_cast<unsigned *>(ctl_f), nwords);
+        HIPCHK(hipGetLastError());
+    }
     ctl->abort_flag = reinterpret_cast<unsigned *>(ctl_f);
     ctl->ticket = ctl->abort_flag + 4;
     ctl->progress = ctl->abort_flag + PERSIST_HDR_WORDS;

@@ -75,7 +75,7 @@ def _apriori_pyramid(field, shapes, scl_factor):
 
 def _flow_llin(level_cls, Iin, channels, fstTerm, sndTerm, defaults, mode, param):
     param = dict(param)
-    graph = bool(param.pop("graph", False)) and mode != capi.MODE_EXACT_ORDER   # the exact-order schedule tables are uploaded per shape
+    graph = bool(param.pop("graph", False))   # exact order too since round 3: the walkers' schedule table is built on the stream
     Us, Vs, scales = param.pop("Us", None), param.pop("Vs", None), param.pop("scales", None)
     p = dict(defaults, **param)
     p["sndTerm"] = sndTerm.lower()

@@ -106,9 +106,8 @@ class FasFmgFlow:
 
     def run_graph(self, I0, I1):
         """run() replayed as a HIP graph (captured on the first call per frame shape; graphs.py).  The returned planes are the
-        graph's output buffers: valid until the next call.  Exact order falls back to run() (schedule tables are uploaded)."""
-        if self.mode == capi.MODE_EXACT_ORDER:
-            return self.run(I0, I1)
+        graph's output buffers: valid until the next call.  Every ordering (round 3: the exact-order walkers' schedule table
+        is built on the call's stream, so those calls are capturable too)."""
         key = (tuple(I0.shape), tuple(I1.shape))
         if key not in self._graphs:
             self._graphs[key] = graphs.GraphedRun(self.run)

@@ -146,10 +146,17 @@ def test_graph_replay_gives_the_eager_bits(pdeip):
     want = D.FlowEminND_llin_2D_v10(I, 1, "grad", "gradmag", **kw)
     got = D.FlowEminND_llin_2D_v10(I, 1, "grad", "gradmag", graph=True, **kw)
     assert pb.bit_equal(got[0], want[0]) and pb.bit_equal(got[1], want[1])
-    # exact order: graph=True is accepted and runs eagerly
-    a = D.FlowEminND_llin_2D_v10(I, 1, "rgb", "none", solver=1, graph=True)
+    # exact order is captured too (round 3: the walkers' schedule table is built by a kernel on the call's stream, every scale its own
+    # shape, rebuilt by every call while capturing); twice: capture + replay, then a replay of the cached graph
     b = D.FlowEminND_llin_2D_v10(I, 1, "rgb", "none", solver=1)
-    assert pb.bit_equal(a[0], b[0])
+    for _ in range(2):
+        a = D.FlowEminND_llin_2D_v10(I, 1, "rgb", "none", solver=1, graph=True)
+        assert pb.bit_equal(a[0], b[0]) and pb.bit_equal(a[1], b[1])
+    b = D.FlowEminNDFASFMG_elin_2D_v10(I, 1, solver=1, omega=1.0)
+    for _ in range(2):
+        a = D.FlowEminNDFASFMG_elin_2D_v10(I, 1, solver=1, omega=1.0, graph=True)
+        assert pb.bit_equal(a[0], b[0]) and pb.bit_equal(a[1], b[1])
+    assert pdeip.capi.load().pdeip_persist_error() == 0
 
 
 def test_resident_cxx_drivers_equal_the_python_drivers(pdeip):
