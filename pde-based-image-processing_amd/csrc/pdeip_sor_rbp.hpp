@@ -80,14 +80,30 @@ template <class Mdl, int S> struct RbpLayout {
 };
 
 // one column of one plane: 64 lanes x 16 bytes, contiguous
+// (explicit LDS address space: with generic pointers the compiler merged the hand-off write of sweeps 0..S-2 with the global
+// store of sweep S-1 into ONE flat store behind a pointer select -- an LDS write through the flat path, counted on vmcnt too)
+typedef float rbp_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) rbp_f4 rbp_lds_f4;
 __device__ __forceinline__ void rbp_lds_read(float (&d)[4], const float *col, int lane)
 {
-    const float4 t = *reinterpret_cast<const float4 *>(col + 4 * lane);
+    const rbp_f4 t = *(const rbp_lds_f4 *)(col + 4 * lane);
     d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
 }
 __device__ __forceinline__ void rbp_lds_write(float *col, int lane, const float (&d)[4])
 {
-    *reinterpret_cast<float4 *>(col + 4 * lane) = make_float4(d[0], d[1], d[2], d[3]);
+    const rbp_f4 t = {d[0], d[1], d[2], d[3]};
+    *(rbp_lds_f4 *)(col + 4 * lane) = t;
+}
+
+// rows first (opticalflowSolvers.c:161-170): border row 0 <- row 1, border row nrows-1 <- row nrows-2, in the lane that holds them.
+// The empty asm makes the four values opaque: without it the compiler turns the first select into a load from a SELECTED
+// ADDRESS of d[], which keeps the whole array in scratch memory.
+__device__ __forceinline__ void rbp_replicate_rows(float (&d)[4], bool top_lane, bool bot_lane)
+{
+    float a0 = d[0], a1 = d[1], a2 = d[2], a3 = d[3];
+    asm("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    d[0] = top_lane ? a1 : a0;
+    d[3] = bot_lane ? a2 : a3;
 }
 
 // address-space casts for __builtin_amdgcn_global_load_lds (global source per lane, LDS destination = wave-uniform base + 16 x lane)
@@ -224,18 +240,11 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
 #endif
         RBP_STAMP(0);
         // ---- take in column x+1 of the previous sweep's result, and the coefficients of columns x and x-1 ----
-        float *const ks = Kring + (size_t)ki * NCF * COL; // slot of column x (Kc, read one step ago; column x-1 is Kp)
+        float *const ks = Kring + (size_t)ki * NCF * COL; // slot of column x (Kc, read one step ago -- before the loop for step 0; column x-1 is Kp)
         {
             const float *src = (s == 0) ? Oring + (size_t)oi * NIT * COL : Hring + (size_t)((s - 1) * 2 + hp) * NIT * COL;
 #pragma unroll
             for (int f = 0; f < NIT; f++) rbp_lds_read(Op[f], src + f * COL, lane);
-            if (t == 0) {
-#pragma unroll
-                for (int f = 0; f < NCF; f++) rbp_lds_read(Kc[f], ks + f * COL, lane);
-            }
-            const float *kn = Kring + (size_t)(ki + 1 == L::NK ? 0 : ki + 1) * NCF * COL; // column x+1, for the next step
-#pragma unroll
-            for (int f = 0; f < NCF; f++) rbp_lds_read(Kn[f], kn + f * COL, lane);
 #pragma unroll
             for (int f = 0; f < NRO1; f++)
                 if (NRO > 0) {
@@ -309,8 +318,7 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
             }
 #pragma unroll
             for (int f = 0; f < NF; f++) { // rows first (:161-170): border row 0 <- row 1, border row nrows-1 <- row nrows-2
-                F[f][0] = top_lane ? F[f][1] : F[f][0];
-                F[f][3] = bot_lane ? F[f][2] : F[f][3];
+                rbp_replicate_rows(F[f], top_lane, bot_lane);
             }
         } else {
             // ---- columns at the image border (and the clamped columns outside it) ----
@@ -347,8 +355,7 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
                 PDEIP_RBP_PHASE(F, Rp, Wv, Ev, Om, Q1, Q2, Q0, Kp);
 #pragma unroll
                 for (int f = 0; f < NF; f++) {
-                    F[f][0] = top_lane ? F[f][1] : F[f][0];
-                    F[f][3] = bot_lane ? F[f][2] : F[f][3];
+                    rbp_replicate_rows(F[f], top_lane, bot_lane);
                 }
             } else {
 #pragma unroll
@@ -359,6 +366,13 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
         }
 #undef PDEIP_RBP_PHASE
         RBP_STAMP(2); // both half-sweeps issued
+        {
+            // coefficients of column x+1, for the next step.  Read here, behind the arithmetic: at the top of the step they sat
+            // between the barrier and the first multiply (the compiler waits for every outstanding LDS read there)
+            const float *kn = Kring + (size_t)(ki + 1 == L::NK ? 0 : ki + 1) * NCF * COL;
+#pragma unroll
+            for (int f = 0; f < NCF; f++) rbp_lds_read(Kn[f], kn + f * COL, lane);
+        }
         if (s < S - 1) {
             float *dst = Hring + (size_t)(s * 2 + (hp ^ 1)) * NIT * COL;
 #pragma unroll
@@ -386,6 +400,8 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
     };
 
     rbp_barrier(); // group 0 is in LDS
+#pragma unroll
+    for (int f = 0; f < NCF; f++) rbp_lds_read(KB[f], Kring + ((size_t)ki * NCF + f) * COL, lane); // "column x" of step 0
     // the O/R windows and the coefficient triple (columns x-1, x, x+1) rotate with period 3: three steps per trip
     for (int t = 0; t < nsteps; t += 3) {
         step(t, O0, O1, O2, R0, R1, R2, KA, KB, KC);
