@@ -99,6 +99,11 @@ int pdeip_debug_raise_abort(void);
  * PDEIP_PERSIST_XCD=1), built on the device as a call builds it and copied to `table` (16 + B*T ints: list offsets 0..8, items
  * b | t << 16 from int 16 on). */
 int pdeip_debug_persist_order(int B, int T, int affine, int *table);
+/* Diagnostic: compares the fused pipeline's fast reciprocal (v_rcp_f32 + one Newton step, taken by the divisor planes of
+ * opticalflowSolvers.c:111-127 when every denominator is a normal number with a normal reciprocal) with the IEEE quotient
+ * 1.0f / d for EVERY such float (exponent field 1..252, both signs); counts[0] = inputs compared, counts[1] = results that differ
+ * in any bit (must be 0). */
+int pdeip_debug_rcp_check(unsigned long long *counts);
 /* Sweep-kernel timing for bench.py's roofline figure.  While enabled, every *_dev solver call
  * brackets its back-to-back sweep launches (not its prologue) with a pair of HIP events on the
  * call's stream.  pdeip_profile_read() waits for the recorded events, returns the summed elapsed

@@ -124,6 +124,7 @@ SIGNATURES = {
     "pdeip_persist_error": [],
     "pdeip_debug_persist_order": [_I, _I, _I, ctypes.POINTER(ctypes.c_int)],
     "pdeip_debug_raise_abort": [],
+    "pdeip_debug_rcp_check": [ctypes.POINTER(ctypes.c_ulonglong)],
     "pdeip_profile_enable": [_I],
     "pdeip_profile_read": [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)],
 }

@@ -21,6 +21,33 @@ __device__ __forceinline__ bool is_nan(float x) { return x != x; }
 
 template <int N> struct at_least_one { static constexpr int value = N > 0 ? N : 1; };
 
+// Reciprocals of the divisor planes (Model::derive).  RcpIeee is the reference's `1.0f / d` (HIP's correctly rounded division:
+// two v_div_scale, v_rcp, six fused steps, v_div_fmas, v_div_fixup).  RcpFast = v_rcp_f32 + ONE Newton step with two explicit
+// FMAs: bit-identical to the IEEE quotient for every normal d whose reciprocal is normal (exponent field 1..252, either sign) --
+// all 4 227 858 432 such inputs compared on gfx950 (tools/rcp_probe.hip; tests/test_gpu_rcp.py repeats it through the library).
+// RcpRange only records whether its arguments are inside that range (NaN, zero, infinities and denormals are not); a caller
+// runs derive() with it first and takes RcpIeee for the whole wave when any lane is outside.
+struct RcpIeee {
+    __device__ __forceinline__ float operator()(float d) const { return 1.0f / d; }
+};
+struct RcpFast {
+    __device__ __forceinline__ float operator()(float d) const
+    {
+        const float r = __builtin_amdgcn_rcpf(d);
+        const float e = __builtin_fmaf(-d, r, 1.0f);
+        return __builtin_fmaf(e, r, r);
+    }
+};
+struct RcpRange {
+    bool &ok;
+    __device__ __forceinline__ float operator()(float d) const
+    {
+        const float a = __builtin_fabsf(d);
+        ok = ok && (a >= 0x1p-126f) && (a < 0x1p126f);
+        return d;
+    }
+};
+
 // Value of the neighbouring lane in one VALU instruction (DPP wave_shr:1 / wave_shl:1 across the whole
 // 64-lane wave); the first / last lane keeps its own value, like __shfl_up(v, 1) / __shfl_down(v, 1) --
 // which compile to an LDS-crossbar ds_bpermute with a round trip that nothing hides at one wave per SIMD.
@@ -38,15 +65,17 @@ struct ModelElin4 {
     static constexpr int NIT = 2, NRO = 0, NCF = 9;
     enum { cM = 0, cCu, cCv, cDivU, cDivV, cWW, cWN, cWE, cWS };
     static constexpr int D0 = cDivU, D1 = cDivV; // derived planes; their slots hold Du, Dv before derive()
+    static constexpr bool DERIVE_WE_SYMMETRIC = true; // derive() gives the same bits with wW and wE exchanged ((wW + wE) + ...)
     // opticalflowSolvers.c:111-127: the divisors the reference builds during its first sweep
-    __device__ __forceinline__ static void derive(float (&k)[9])
+    // WHICH: bit 0 = the divisor of u, bit 1 = the divisor of v (a wave that relaxes one field derives that field's only)
+    template <int WHICH = 3, class R = RcpIeee> __device__ __forceinline__ static void derive(float (&k)[9], R rcp = R())
     {
         float t1 = k[cWW] + k[cWE];
         const float t2 = k[cWN] + k[cWS];
         t1 += t2;
         const float du = k[cDivU], dv = k[cDivV];
-        k[cDivU] = is_nan(du) ? 1.0f / t1 : 1.0f / (t1 + du);
-        k[cDivV] = is_nan(dv) ? 1.0f / t1 : 1.0f / (t1 + dv);
+        if (WHICH & 1) k[cDivU] = rcp(is_nan(du) ? t1 : t1 + du);
+        if (WHICH & 2) k[cDivV] = rcp(is_nan(dv) ? t1 : t1 + dv);
     }
     __device__ __forceinline__ static void update(float (&c)[2], const float (&W)[2],
                                                   const float (&E)[2], const float (&N)[2],
@@ -94,7 +123,8 @@ struct ModelLlin4 {
     static constexpr int NIT = 2, NRO = 2, NCF = 9;
     enum { cM = 0, cCu, cCv, cDivU, cDivV, cWW, cWN, cWE, cWS };
     static constexpr int D0 = cDivU, D1 = cDivV;
-    __device__ __forceinline__ static void derive(float (&k)[9]) { ModelElin4::derive(k); } // :606-622
+    static constexpr bool DERIVE_WE_SYMMETRIC = true;
+    template <int WHICH = 3, class R = RcpIeee> __device__ __forceinline__ static void derive(float (&k)[9], R rcp = R()) { ModelElin4::derive<WHICH, R>(k, rcp); } // :606-622
     __device__ __forceinline__ static float neigh(float dW, float dE, float dN, float dS, float uW,
                                                   float uE, float uN, float uS, float uc,
                                                   const float (&cf)[9])
@@ -147,8 +177,9 @@ struct ModelDisp4 {
     static constexpr int NIT = 1, NRO = 1, NCF = 6;
     enum { cDividend = 0, cDiv, cWW, cWN, cWE, cWS };
     static constexpr int D0 = cDividend, D1 = cDiv; // slots hold Cu, Du before derive()
+    static constexpr bool DERIVE_WE_SYMMETRIC = false; // ((Du + wE) + wW) + ...: the order of wE and wW matters
     // disparitySolvers.c:94-113
-    __device__ __forceinline__ static void derive(float (&k)[6])
+    template <int WHICH = 3, class R = RcpIeee> __device__ __forceinline__ static void derive(float (&k)[6], R rcp = R())
     {
         const float cu = k[cDividend];
         const bool ok = !is_nan(cu);
@@ -157,7 +188,7 @@ struct ModelDisp4 {
         t = t + k[cWS];
         t = t + k[cWN];
         k[cDividend] = ok ? cu : 0.0f;
-        k[cDiv] = 1.0f / t;
+        k[cDiv] = rcp(t);
     }
     __device__ __forceinline__ static float neigh(float dW, float dE, float dN, float dS, float uW,
                                                   float uE, float uN, float uS, float uc,
@@ -214,14 +245,15 @@ struct ModelPde4 {
     static constexpr int NIT = 1, NRO = 0, NCF = 6;
     enum { cB = 0, cInv, cWW, cWN, cWE, cWS };
     static constexpr int D0 = cB, D1 = cInv; // slots hold B, TRACE before derive()
+    static constexpr bool DERIVE_WE_SYMMETRIC = true;
     // pdeSolvers.c:99-115
-    __device__ __forceinline__ static void derive(float (&k)[6])
+    template <int WHICH = 3, class R = RcpIeee> __device__ __forceinline__ static void derive(float (&k)[6], R rcp = R())
     {
         const float tr = k[cInv];
         float t = k[cWE] + k[cWW];
         t += k[cWS] + k[cWN];
         const bool ok = !is_nan(tr);
-        k[cInv] = ok ? 1.0f / tr : 1.0f / t;
+        k[cInv] = rcp(ok ? tr : t);
         k[cB] = ok ? k[cB] : 0.0f;
     }
     __device__ __forceinline__ static void update(float (&c)[1], const float (&W)[1],

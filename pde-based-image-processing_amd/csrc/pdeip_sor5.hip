@@ -299,8 +299,13 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
             // the derived planes leave the kernel only if a later launch of this call reads them
             const bool keep = first && it + PS < iter;
             const dim3 pgrid((unsigned)nunits, (unsigned)nframes), pblock(PL::THREADS);
-            if (first) hipLaunchKernelGGL((k_sor_rbp<Mdl, PS, true>), pgrid, pblock, PL::LDS_BYTES, s, P, keep ? aux0 : nullptr, keep ? aux1 : nullptr, nrows, ncols, TJP, ntiles_p, nunits, omega, col0, n);
-            else hipLaunchKernelGGL((k_sor_rbp<Mdl, PS, false>), pgrid, pblock, PL::LDS_BYTES, s, P, nullptr, nullptr, nrows, ncols, TJP, ntiles_p, nunits, omega, col0, n);
+            // PDEIP_RBP_SERPENTINE = 1: alternate strips march backwards (k_sor_rbp, `mirror_mode`), 2: every strip (tests).  Same bits;
+            // neighbouring strips then meet at the halo columns they share (-6 % bytes fetched), but at 4K the launch is not
+            // faster for it (97.7 vs 94.6 us, same run) -- the wave pipeline's step, not the memory system, sets its time.  Off.
+            const int serp = env_int("PDEIP_RBP_SERPENTINE", 0);
+            const int mirror_mode = serp < 0 || serp > 2 ? 0 : serp;
+            if (first) hipLaunchKernelGGL((k_sor_rbp<Mdl, PS, true>), pgrid, pblock, PL::LDS_BYTES, s, P, keep ? aux0 : nullptr, keep ? aux1 : nullptr, nrows, ncols, TJP, ntiles_p, nunits, omega, col0, n, mirror_mode);
+            else hipLaunchKernelGGL((k_sor_rbp<Mdl, PS, false>), pgrid, pblock, PL::LDS_BYTES, s, P, nullptr, nullptr, nrows, ncols, TJP, ntiles_p, nunits, omega, col0, n, mirror_mode);
             if (first) {
                 P.cf[Mdl::D0] = aux0;
                 P.cf[Mdl::D1] = aux1;
@@ -360,6 +365,42 @@ extern "C" int pdeip_debug_persist_order(int B, int T, int affine, int *table)
     const hipError_t e = hipMemcpy(table, dev, n * sizeof(int), hipMemcpyDeviceToHost);
     (void)hipFree(dev);
     if (e != hipSuccess) return set_err(PDEIP_ERR_DEVICE, "pdeip_debug_persist_order: %s", hipGetErrorString(e));
+    return PDEIP_OK;
+}
+
+namespace {
+__global__ void k_rcp_check(unsigned long long *counts)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long n = 0, bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const unsigned bits = (unsigned)i;
+        const float d = __uint_as_float(bits);
+        bool in_range = true;
+        RcpRange{in_range}(d);
+        if (in_range != (((bits >> 23) & 0xff) >= 1 && ((bits >> 23) & 0xff) <= 252)) bad++; // the range test is the exponent test
+        if (!in_range) continue;
+        n++;
+        if (__float_as_uint(RcpFast()(d)) != __float_as_uint(RcpIeee()(d))) bad++;
+    }
+    atomicAdd(counts + 0, n);
+    atomicAdd(counts + 1, bad);
+}
+} // namespace
+
+extern "C" int pdeip_debug_rcp_check(unsigned long long *counts)
+{
+    if (counts == nullptr) return set_err(PDEIP_ERR_ARG, "pdeip_debug_rcp_check: null pointer");
+    RC(use_device());
+    unsigned long long *dev = nullptr;
+    HIPCHK(hipMalloc(&dev, 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(dev, 0, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_rcp_check, dim3(4096), dim3(256), 0, nullptr, dev);
+        e = hipMemcpy(counts, dev, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dev);
+    if (e != hipSuccess) return set_err(PDEIP_ERR_DEVICE, "pdeip_debug_rcp_check: %s", hipGetErrorString(e));
     return PDEIP_OK;
 }
 

@@ -192,13 +192,14 @@ __device__ __forceinline__ void rbp_phase(float (&OUT)[NF][4], const float (&C)[
 template <class Mdl, int S, bool FIRST, int F0, int NF>
 __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float *dout0, float *dout1, float *Kring, float *Qring, float *Oring, float *Hring,
                                                int s, int lane, int r, int nrows, int ncols, int j0, int j1, int xbase, int nsteps,
-                                               float omega, int col0, size_t fo)
+                                               float omega, int col0, size_t fo, int mirror)
 {
     using L = RbpLayout<Mdl, S>;
     constexpr int NIT = L::NIT, NRO = L::NRO, NRO1 = at_least_one<NRO>::value, NCF = L::NCF, COL = L::COL;
     const float om1 = 1.0f - omega;
     const bool store_lane = (lane >= 2) && (lane <= 61);
     auto inner = [&](int col) { return col >= 1 && col <= ncols - 2; };
+    auto cmap = [&](int col) { return mirror ? ncols - 1 - col : col; }; // march column -> column in memory (see k_sor_rbp)
     // per-lane row predicates, fixed for the whole march: which of the lane's four rows are interior pixels, and whether
     // the lane holds the top / bottom border row (nrows is a multiple of 4 here, so they are elements 0 and 3)
     bool ok[4];
@@ -269,21 +270,62 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
             // raw; derive it, put the derived planes back into its K-ring slot (this wave reads them again as column x-1 in the
             // next step, the later sweeps three steps from now) and store them if launches follow that need them.  A wave
             // that owns one field of a coupled model derives that field's divisor.
+            // The reciprocals are this wave's heaviest arithmetic (the whole workgroup waits for it at the barrier): v_rcp_f32 + one
+            // Newton step where every denominator of the wave is in the range in which that equals the IEEE quotient bit for
+            // bit (RcpFast, pdeip_models.hpp), the division itself otherwise.
+            constexpr int WHICH = (NF == NIT) ? 3 : (1 << F0);
+            // the raw coefficients of row e; a mirrored launch has wW and wE swapped, and a derive() that adds them in a fixed order
+            // (disparitySolvers.c:94-113) gets them back in their memory roles
+            auto raw = [&](float (&k)[NCF], int e) __attribute__((always_inline)) {
+#pragma unroll
+                for (int f = 0; f < NCF; f++) k[f] = Kc[f][e];
+                if (!Mdl::DERIVE_WE_SYMMETRIC) {
+                    const float w = k[Mdl::cWW], ea = k[Mdl::cWE];
+                    k[Mdl::cWW] = mirror ? ea : w;
+                    k[Mdl::cWE] = mirror ? w : ea;
+                }
+            };
+            bool in_range = true;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 float k[NCF];
+                raw(k, e);
+                Mdl::template derive<WHICH>(k, RcpRange{in_range});
+            }
+            float D[2][4]; // the fast form unconditionally (three instructions a value, harmless outside its range) ...
 #pragma unroll
-                for (int f = 0; f < NCF; f++) k[f] = Kc[f][e];
-                Mdl::derive(k);
-                Kc[Mdl::D0][e] = k[Mdl::D0];
-                Kc[Mdl::D1][e] = k[Mdl::D1];
+            for (int e = 0; e < 4; e++) {
+                float k[NCF];
+                raw(k, e);
+#ifdef RBP_IEEE_DIV /* A/B aid: the division always */
+                Mdl::template derive<WHICH>(k, RcpIeee());
+#else
+                Mdl::template derive<WHICH>(k, RcpFast());
+#endif
+                D[0][e] = k[Mdl::D0];
+                D[1][e] = k[Mdl::D1];
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!in_range) != 0, 0)) { // ... and the division for the whole wave in the rare case
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float k[NCF];
+                    raw(k, e);
+                    Mdl::template derive<WHICH>(k, RcpIeee());
+                    D[0][e] = k[Mdl::D0];
+                    D[1][e] = k[Mdl::D1];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                Kc[Mdl::D0][e] = D[0][e];
+                Kc[Mdl::D1][e] = D[1][e];
             }
             const bool d0_mine = (NF == NIT) || F0 == 0, d1_mine = (NF == NIT) || F0 == 1;
             if (d0_mine) rbp_lds_write(ks + Mdl::D0 * COL, lane, Kc[Mdl::D0]);
             if (d1_mine) rbp_lds_write(ks + Mdl::D1 * COL, lane, Kc[Mdl::D1]);
             if (dout0 != nullptr && store_lane && x >= j0 && x < j1) {
-                if (d0_mine) rb_store4<true>(Kc[Mdl::D0], dout0 + fo, x, r, nrows);
-                if (d1_mine) rb_store4<true>(Kc[Mdl::D1], dout1 + fo, x, r, nrows);
+                if (d0_mine) rb_store4<true>(Kc[Mdl::D0], dout0 + fo, cmap(x), r, nrows);
+                if (d1_mine) rb_store4<true>(Kc[Mdl::D1], dout1 + fo, cmap(x), r, nrows);
             }
         }
 
@@ -303,6 +345,14 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
                 OpF[f][e] = Op[F0 + f][e];
             }
 
+        // Coefficients of column x+1, for the next step: read BETWEEN the two half-sweeps.  At the top of the step they sat between
+        // the barrier and the first multiply (the compiler waits for every outstanding LDS read there); behind both half-sweeps they
+        // sat in front of the hand-off write, whose acknowledgement the barrier waits for.  Here the black half hides them.
+        auto read_next_coefficients = [&]() __attribute__((always_inline)) {
+            const float *kn = Kring + (size_t)(ki + 1 == L::NK ? 0 : ki + 1) * NCF * COL;
+#pragma unroll
+            for (int f = 0; f < NCF; f++) rbp_lds_read(Kn[f], kn + f * COL, lane);
+        };
         const int xb = x - 1;
         float F[NF][4];
         if (x >= 3 && x <= ncols - 3) {
@@ -311,9 +361,11 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
             // (the other fields' centre values at the black pixels are still the previous sweep's: the red half left them alone)
             if (p == 0) {
                 rbp_phase<Mdl, F0, NF, 0>(Rc, OcF, OmF, OpF, Oc, Q0, Q1, Qn, Kc, ok, omega, om1);
+                read_next_coefficients();
                 rbp_phase<Mdl, F0, NF, 0>(F, Rp, Rpp, Rc, Om, Q1, Q2, Q0, Kp, ok, omega, om1);
             } else {
                 rbp_phase<Mdl, F0, NF, 1>(Rc, OcF, OmF, OpF, Oc, Q0, Q1, Qn, Kc, ok, omega, om1);
+                read_next_coefficients();
                 rbp_phase<Mdl, F0, NF, 1>(F, Rp, Rpp, Rc, Om, Q1, Q2, Q0, Kp, ok, omega, om1);
             }
 #pragma unroll
@@ -322,6 +374,7 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
             }
         } else {
             // ---- columns at the image border (and the clamped columns outside it) ----
+            read_next_coefficients();
             if (inner(x)) {
                 // sweeps after the first see a border column as the replicate of its inner neighbour after the previous sweep
                 // (:172-179), i.e. as this column itself; the first sweep of a launch reads the stored border
@@ -366,13 +419,6 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
         }
 #undef PDEIP_RBP_PHASE
         RBP_STAMP(2); // both half-sweeps issued
-        {
-            // coefficients of column x+1, for the next step.  Read here, behind the arithmetic: at the top of the step they sat
-            // between the barrier and the first multiply (the compiler waits for every outstanding LDS read there)
-            const float *kn = Kring + (size_t)(ki + 1 == L::NK ? 0 : ki + 1) * NCF * COL;
-#pragma unroll
-            for (int f = 0; f < NCF; f++) rbp_lds_read(Kn[f], kn + f * COL, lane);
-        }
         if (s < S - 1) {
             float *dst = Hring + (size_t)(s * 2 + (hp ^ 1)) * NIT * COL;
 #pragma unroll
@@ -381,9 +427,9 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
 #pragma unroll
             for (int f = 0; f < NF; f++) {
                 float *out = P.it_out[F0 + f] + fo;
-                rb_store4<true>(F[f], out, xb, r, nrows);
-                if (xb == 1) rb_store4<true>(F[f], out, 0, r, nrows); // then columns (:172-179)
-                if (xb == ncols - 2) rb_store4<true>(F[f], out, ncols - 1, r, nrows);
+                rb_store4<true>(F[f], out, cmap(xb), r, nrows);
+                if (xb == 1) rb_store4<true>(F[f], out, cmap(0), r, nrows); // then columns (:172-179)
+                if (xb == ncols - 2) rb_store4<true>(F[f], out, cmap(ncols - 1), r, nrows);
             }
         }
         ki = (ki + 1 == L::NK) ? 0 : ki + 1;
@@ -410,10 +456,17 @@ __device__ __forceinline__ void rbp_sweep_wave(const SweepPlanes<Mdl> &P, float 
     }
 }
 
+// Mirrored units (`mirror_mode` 1: the odd strips, 2: every strip, 0: none) march their strip from its last column to its first.
+// A red-black half-sweep does not depend on the order its pixels are visited in, so a mirrored unit is the same code on mirrored
+// column addresses (loader, stores) with the planes wW and wE exchanged and the colour of column 0 adjusted: the two products
+// W*wW and E*wE reach the same addition in the other order, which IEEE addition does not notice (a derive() that adds wE and
+// wW in a fixed order gets them back in their memory roles).  Why: strip b reads the halo columns it shares with strip b+1 at the
+// END of a forward march and strip b+1 reads them at the START of one; with alternate strips mirrored both neighbours are at
+// their common edge at the same time, and with the strip-major unit order mostly behind the same L2.
 template <class Mdl, int S, bool FIRST>
 __global__ void __launch_bounds__((RbpLayout<Mdl, S>::THREADS))
 k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, int TJ, int ntiles_r, int nunits, float omega,
-          int col0, size_t frame_stride)
+          int col0, size_t frame_stride, int mirror_mode)
 {
     using L = RbpLayout<Mdl, S>;
     constexpr int NIT = L::NIT, NRO = L::NRO, NCF = L::NCF, COL = L::COL, NW = L::NW;
@@ -433,9 +486,26 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
     if (unit >= nunits) return;
     const size_t fo = (size_t)blockIdx.y * frame_stride;
     const int nstrips = nunits / ntiles_r;
-    const int a = unit / nstrips, b = unit % nstrips;
+    // Strip-major: the row tiles of one strip are consecutive units, i.e. (with the ranges above) run on ONE XCD and march in step.
+    // A column piece of 256 rows starts 8 rows above the tile (32 bytes into a 128-byte line: nine lines for eight lines' worth)
+    // and overlaps its vertical neighbours' by 16 rows; with the neighbours behind the same L2 those lines are fetched once.
+    // (Horizontal neighbours share halo COLUMNS, but one reads them at the end of its march and the other at the start.)
+#ifndef RBP_STRIP_MAJOR
+#define RBP_STRIP_MAJOR 1
+#endif
+    const int a = RBP_STRIP_MAJOR ? unit % ntiles_r : unit / nstrips, b = RBP_STRIP_MAJOR ? unit / ntiles_r : unit % nstrips;
     const int r = a * RBP_OWN_ROWS - 8 + 4 * lane;
-    const int j0 = b * TJ, j1 = (j0 + TJ < ncols) ? j0 + TJ : ncols;
+    int j0 = b * TJ, j1 = (j0 + TJ < ncols) ? j0 + TJ : ncols;
+    const int mirror = mirror_mode == 2 ? 1 : (mirror_mode == 1 ? (b & 1) : 0);
+    if (mirror) { // the strip, the colour of column 0 and the west / east planes in march coordinates (column x <-> ncols - 1 - x)
+        const int t0 = ncols - j1;
+        j1 = ncols - j0;
+        j0 = t0;
+        col0 += ncols - 1;
+        const float *w = P.cf[Mdl::cWW];
+        P.cf[Mdl::cWW] = P.cf[Mdl::cWE];
+        P.cf[Mdl::cWE] = w;
+    }
     const int nsteps = L::nsteps(TJ);
     // red column of sweep 0 in step t: x0(t) = xbase + t; sweep s: x0(t) - 3s.  Two warm-up steps fill the windows.
     const int xbase = j0 - L::HALO + 1 - 2;
@@ -448,7 +518,7 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
         auto issue = [&](int g) __attribute__((always_inline)) {
             const int y = xbase + 1 + g;
             const int cc = y < 0 ? 0 : (y > ncols - 1 ? ncols - 1 : y);
-            const size_t off = fo + (size_t)cc * nrows + rr;
+            const size_t off = fo + (size_t)(mirror ? ncols - 1 - cc : cc) * nrows + rr;
             float *kdst = Kring + (size_t)kslot * NCF * COL, *qdst = Qring + (size_t)qslot * NRO * COL;
 #pragma unroll
             for (int f = 0; f < NCF; f++)
@@ -467,10 +537,23 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
         for (int g = 0; g < L::P; g++) issue(g);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L::P - 1) * L::GROUP) : "memory"); // group 0 has landed
         rbp_barrier();
+#ifndef RBP_LOADER_SLEEP
+#define RBP_LOADER_SLEEP 0 /* A/B aid: s_sleep units (64 cycles) between the barrier and the step's DMA issue */
+#endif
         for (int t = 0; t < nsteps; t++) {
+#ifdef PDEIP_RBP_STAMPS
+            const bool stamp_on = (blockIdx.x == 100) && (RBP_STAMP_SWEEP == 9) && (t >= RBP_STAMP_T0) && (t < RBP_STAMP_T0 + 24);
+#endif
+            RBP_STAMP(0);
+            if (RBP_LOADER_SLEEP > 0) __builtin_amdgcn_s_sleep(RBP_LOADER_SLEEP);
             issue(t + L::P);
+            RBP_STAMP(1); // the step's DMA instructions issued
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L::P - 1) * L::GROUP) : "memory"); // group t+1 has landed
+            RBP_STAMP(2);
+            RBP_STAMP(3);
+            RBP_STAMP(4);
             rbp_barrier();
+            RBP_STAMP(5);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may land in LDS after the workgroup has gone
         return;
@@ -480,12 +563,22 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
     // Coupled two-field models run two waves per sweep, one per field (u is updated from the OLD v of the same pixel and vice
     // versa -- opticalflowSolvers.c:129-149 -- so the two halves of a half-sweep are independent); the workgroup then has two
     // waves per SIMD, which is what keeps the VALUs busy while a wave waits for LDS or the barrier.
+    // Which wave plays which sweep: waves w, w+4, w+8 of a workgroup share a SIMD (the hardware deals them out cyclically).  Sweep 0
+    // of a call's first launch is the heavy one (two exact divisions per pixel for the divisor planes), so it is paired with ONE
+    // other sweep wave, and the loader (the last wave) sits with two plain ones.
+#ifndef RBP_ROLE_REMAP
+#define RBP_ROLE_REMAP 1
+#endif
     if constexpr (NW == 2) {
-        const int s = wave >> 1;
-        if ((wave & 1) == 0) rbp_sweep_wave<Mdl, S, FIRST, 0, 1>(P, dout0, dout1, Kring, Qring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
-        else rbp_sweep_wave<Mdl, S, FIRST, 1, 1>(P, dout0, dout1, Kring, Qring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
+        // wave 0..7 -> (sweep, field): (1,0) (0,0) (0,1) (1,1) (3,0) (2,0) (2,1) (3,1); SIMD classes {0,4,L} {1,5} {2,6} {3,7}
+        const int q = wave & 3;
+        const int s = (RBP_ROLE_REMAP && S == 4) ? ((wave >> 2) << 1) | ((q == 0 || q == 3) ? 1 : 0) : wave >> 1;
+        const int fld = (RBP_ROLE_REMAP && S == 4) ? (wave >> 1) & 1 : wave & 1;
+        if (fld == 0) rbp_sweep_wave<Mdl, S, FIRST, 0, 1>(P, dout0, dout1, Kring, Qring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo, mirror);
+        else rbp_sweep_wave<Mdl, S, FIRST, 1, 1>(P, dout0, dout1, Kring, Qring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo, mirror);
     } else {
-        rbp_sweep_wave<Mdl, S, FIRST, 0, NIT>(P, dout0, dout1, Kring, Qring, Oring, Hring, wave, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo);
+        const int s = (RBP_ROLE_REMAP && wave < 2) ? wave ^ 1 : wave; // the loader (wave S) shares a SIMD with wave 0: sweep 1, not sweep 0
+        rbp_sweep_wave<Mdl, S, FIRST, 0, NIT>(P, dout0, dout1, Kring, Qring, Oring, Hring, s, lane, r, nrows, ncols, j0, j1, xbase, nsteps, omega, col0, fo, mirror);
     }
 }
 

@@ -9,7 +9,11 @@ os.makedirs(os.path.dirname(out), exist_ok=True)
 src = sorted(glob.glob(os.path.join(ROOT, "pde-based-image-processing_amd", "csrc", "*.hip")))
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17", "-shared",
        "-DPDEIP_RBP_STAMPS", "-DRBP_STAMP_SWEEP=" + sweep, "-o", out] + src
-subprocess.run(cmd, check=True, cwd=os.path.join(ROOT, "pde-based-image-processing_amd", "csrc"))
+pre = os.path.join(ROOT, "pde-based-image-processing_amd", "libpdeip_st%s.so" % sweep)  # tools/build_variant.py st<n> -DPDEIP_RBP_STAMPS -DRBP_STAMP_SWEEP=<n>
+if os.path.exists(pre):
+    out = pre
+else:
+    subprocess.run(cmd, check=True, cwd=os.path.join(ROOT, "pde-based-image-processing_amd", "csrc"))
 import torch
 lib = ctypes.CDLL(out)
 nr, nc = 2160, 3840
