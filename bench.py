@@ -316,8 +316,10 @@ def main():
                      "sweeps_per_launch": round(sweeps_per_launch, 3),
                      "effective_achieved": round(effective, 1), "effective_frac": round(effective / HBM_PEAK_GBS, 4),
                      "effective_bytes_per_launch": effective_bytes,
-                     "limiter": "instruction issue and the barrier per column of the wave pipeline, not HBM (SQ_WAIT_ANY 46 % of wave cycles: "
-                                "profiles/README.md, DESIGN.md kernel table)",
+                     "limiter": "the memory stream of one loader wave per compute unit: 485 MB per launch with the LDS rings full at a four-column "
+                                "lead (44 KB in flight per unit, 11 MB chip-wide); the same launch with every workgroup barrier removed "
+                                "(waves free-running, results invalid) takes 92 us against 96 us -- the wave pipeline's meeting per column "
+                                "costs 4 %, the stream the rest (DESIGN.md 5.1, profiles/NOTES.md R3.4)",
                      "note": "achieved/frac = the bytes a launch of k fused sweeps must move (13 planes x 4 B x pixels) / launch time / peak; "
                              "effective_* = SURVEY 8(d)'s per-sweep figure (52 B x pixels x k sweeps) / launch time -- an effective rate that can "
                              "exceed what HBM delivers; frac_hbm = measured traffic / time / peak is the HBM utilisation, overfetch = traffic / bytes_per_launch"},

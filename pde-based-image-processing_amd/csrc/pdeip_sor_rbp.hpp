@@ -129,7 +129,11 @@ __device__ unsigned long long g_rbp_stamps[256];
 #endif
 
 // LDS traffic only: the loader's DMA stays in flight across it (a __syncthreads() would drain vmcnt)
+#ifdef RBP_NO_BARRIER /* timing experiment only (results are garbage): what the step costs without the workgroup-wide meeting */
+__device__ __forceinline__ void rbp_barrier() { asm volatile("" ::: "memory"); }
+#else
 __device__ __forceinline__ void rbp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // One colour of one column, branch-free, for the fields [F0, F0+NF) of the model: OUT <- CEN with elements {E0, E0+2}
 // relaxed where the row is an interior pixel (ok[], fixed per lane for the whole march).  XC holds the centre values of ALL
@@ -546,9 +550,13 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
 #endif
             RBP_STAMP(0);
             if (RBP_LOADER_SLEEP > 0) __builtin_amdgcn_s_sleep(RBP_LOADER_SLEEP);
-            issue(t + L::P);
-            RBP_STAMP(1); // the step's DMA instructions issued
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L::P - 1) * L::GROUP) : "memory"); // group t+1 has landed
+            if (t + L::P < nsteps) { // group nsteps-1 is the last one a sweep wave reads (as "column x+1" of its last step)
+                issue(t + L::P);
+                RBP_STAMP(1); // the step's DMA instructions issued
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L::P - 1) * L::GROUP) : "memory"); // group t+1 has landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the tail: nothing new to fetch, everything issued has landed
+            }
             RBP_STAMP(2);
             RBP_STAMP(3);
             RBP_STAMP(4);
