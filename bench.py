@@ -316,10 +316,10 @@ def main():
                      "sweeps_per_launch": round(sweeps_per_launch, 3),
                      "effective_achieved": round(effective, 1), "effective_frac": round(effective / HBM_PEAK_GBS, 4),
                      "effective_bytes_per_launch": effective_bytes,
-                     "limiter": "the memory stream of one loader wave per compute unit: 485 MB per launch with the LDS rings full at a four-column "
-                                "lead (44 KB in flight per unit, 11 MB chip-wide); the same launch with every workgroup barrier removed "
-                                "(waves free-running, results invalid) takes 92 us against 96 us -- the wave pipeline's meeting per column "
-                                "costs 4 %, the stream the rest (DESIGN.md 5.1, profiles/NOTES.md R3.4)",
+                     "limiter": "the compute units' memory pipelines: 443 MB of column pieces (eleven planes in, halo included) + 66 MB out per "
+                                "launch at 22 GB/s per unit = 5.6-5.7 TB/s chip-wide, the rate the library's plain streaming kernels reach; the same "
+                                "launch with every workgroup barrier removed (waves free-running, results invalid) takes 92 us against 96 us; "
+                                "fewer HBM bytes (L2 hits), a deeper DMA lead and a second loader wave change nothing (DESIGN.md 5.1, profiles/NOTES.md R3.4)",
                      "note": "achieved/frac = the bytes a launch of k fused sweeps must move (13 planes x 4 B x pixels) / launch time / peak; "
                              "effective_* = SURVEY 8(d)'s per-sweep figure (52 B x pixels x k sweeps) / launch time -- an effective rate that can "
                              "exceed what HBM delivers; frac_hbm = measured traffic / time / peak is the HBM utilisation, overfetch = traffic / bytes_per_launch"},

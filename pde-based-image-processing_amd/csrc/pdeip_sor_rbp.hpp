@@ -37,10 +37,15 @@ template <class Mdl, int S> struct RbpLayout {
     static constexpr int NRING = NCF + NRO;            // planes every sweep wave reads: coefficients, then read-only fields
     static constexpr int COL = 256;                    // floats per plane column (64 lanes x 4 rows)
     static constexpr int GROUP = NRING + NIT;          // LDS-DMA instructions per column
-    // K-ring columns for a DMA lead of p steps.  Column group g lands before step g; wave s reads it (as "column x") in step
-    // g + 3s + 1 and keeps it in registers for the step after; its slot is refilled by group g + NK, issued in step
-    // g + NK - p, which has to come after wave S-1's read.
-    static constexpr int nk_for(int p) { return p + 3 * (S - 1) + 2; }
+    // K-ring columns for a DMA lead of p steps.  Column group g lands before step g; wave s reads it into registers (as "column
+    // x+1", one step ahead of its use) in step g + 3s -- sweep 0 of a first launch writes the derived planes back into the slot in
+    // step g + 1 --; the slot is refilled by group g + NK, issued in step g + NK - p, which has to be a LATER step than wave S-1's
+    // read in step g + 3(S-1): NK >= p + 3(S-1) + 1.  (Until the coefficients were read a step ahead this was one column more;
+    // the column saved is what lets the lead grow from four to five for the coupled models.)
+#ifndef RBP_NK_SLACK
+#define RBP_NK_SLACK 1
+#endif
+    static constexpr int nk_for(int p) { return p + 3 * (S - 1) + RBP_NK_SLACK; }
     // The read-only fields (late-linearisation models) live in a ring of their own: they ride one column ahead of the
     // coefficients (the red half reads them at x+1) into register windows, so wave s reads group g once, in step g + 3s;
     // the last reader is wave S-1 in step g + 3(S-1): one column fewer than the coefficient ring needs.
@@ -72,7 +77,12 @@ template <class Mdl, int S> struct RbpLayout {
     static constexpr int H_FLOATS = (S - 1) * 2 * NIT * COL;
     static constexpr size_t LDS_BYTES = (size_t)(K_FLOATS + Q_FLOATS + O_FLOATS + H_FLOATS) * sizeof(float);
     static constexpr int NW = (NIT == 2) ? 2 : 1;      // waves per sweep: the two fields of a coupled model are relaxed by two waves
-    static constexpr int THREADS = 64 * (S * NW + 1);  // sweep waves + the loader wave
+#ifndef RBP_LOADERS
+#define RBP_LOADERS 1
+#endif
+    static constexpr int NLOAD = RBP_LOADERS;          // loader waves: loader w issues the pieces i of a column group with i % NLOAD == w
+    static constexpr int THREADS = 64 * (S * NW + NLOAD); // sweep waves + the loader wave(s)
+    static constexpr int pieces_of(int w) { return (GROUP - w + NLOAD - 1) / NLOAD; }
     static constexpr int HALO = 2 * S;                 // columns per side
     static constexpr bool FITS = P >= 2 && LDS_BYTES <= 160 * 1024 && (P - 1) * GROUP <= 63;
     // wave S-1 finishes column j1-1 in step TJ + 5S - 2 (two warm-up steps, 2S halo columns, three columns of lag per sweep)
@@ -481,7 +491,7 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
     float *const Hring = Oring + L::O_FLOATS;
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 .. S*NW-1: sweep waves; S*NW: loader
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 .. S*NW-1: sweep waves; S*NW ..: loader(s)
     int unit = blockIdx.x;
     { // XCD-aware order: contiguous unit ranges per XCD (neighbouring strips share halo columns through one L2)
         const int nb = gridDim.x, per = nb >> 3;
@@ -514,9 +524,10 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
     // red column of sweep 0 in step t: x0(t) = xbase + t; sweep s: x0(t) - 3s.  Two warm-up steps fill the windows.
     const int xbase = j0 - L::HALO + 1 - 2;
 
-    if (wave == S * NW) {
-        // =========================================== loader wave =============================================
+    if (wave >= S * NW) {
+        // =========================================== loader wave(s) ==========================================
         // group g = column xbase + 1 + g, consumed by sweep 0 in step g
+        const int lw = wave - S * NW; // which loader
         const int rr = r < 0 ? 0 : (r > nrows - 4 ? nrows - 4 : r);
         int kslot = 0, qslot = 0, oslot = 0;
         auto issue = [&](int g) __attribute__((always_inline)) {
@@ -526,34 +537,43 @@ k_sor_rbp(SweepPlanes<Mdl> P, float *dout0, float *dout1, int nrows, int ncols, 
             float *kdst = Kring + (size_t)kslot * NCF * COL, *qdst = Qring + (size_t)qslot * NRO * COL;
 #pragma unroll
             for (int f = 0; f < NCF; f++)
-                __builtin_amdgcn_global_load_lds(RBP_GLB(P.cf[f] + off), RBP_LDS(kdst + f * COL), 16, 0, RBP_AUX_COEF);
+                if (L::NLOAD == 1 || f % L::NLOAD == lw)
+                    __builtin_amdgcn_global_load_lds(RBP_GLB(P.cf[f] + off), RBP_LDS(kdst + f * COL), 16, 0, RBP_AUX_COEF);
 #pragma unroll
             for (int f = 0; f < NRO; f++)
-                __builtin_amdgcn_global_load_lds(RBP_GLB(P.ro[f] + off), RBP_LDS(qdst + f * COL), 16, 0, 0);
+                if (L::NLOAD == 1 || (NCF + f) % L::NLOAD == lw)
+                    __builtin_amdgcn_global_load_lds(RBP_GLB(P.ro[f] + off), RBP_LDS(qdst + f * COL), 16, 0, 0);
             float *odst = Oring + (size_t)oslot * NIT * COL;
 #pragma unroll
             for (int f = 0; f < NIT; f++)
-                __builtin_amdgcn_global_load_lds(RBP_GLB(P.it_in[f] + off), RBP_LDS(odst + f * COL), 16, 0, 0);
+                if (L::NLOAD == 1 || (NCF + NRO + f) % L::NLOAD == lw)
+                    __builtin_amdgcn_global_load_lds(RBP_GLB(P.it_in[f] + off), RBP_LDS(odst + f * COL), 16, 0, 0);
             kslot = (kslot + 1 == L::NK) ? 0 : kslot + 1;
             qslot = (qslot + 1 == L::NQ) ? 0 : qslot + 1;
             oslot = (oslot + 1 == L::NO) ? 0 : oslot + 1;
         };
+        // all but the newest P-1 groups of THIS loader's pieces have landed (the count is an immediate: one wait per loader index)
+        auto landed = [&]() __attribute__((always_inline)) {
+            if (lw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L::P - 1) * L::pieces_of(0)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L::P - 1) * L::pieces_of(L::NLOAD > 1 ? 1 : 0)) : "memory");
+        };
+        static_assert(L::NLOAD == 1 || L::NLOAD == 2, "one or two loader waves");
         for (int g = 0; g < L::P; g++) issue(g);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L::P - 1) * L::GROUP) : "memory"); // group 0 has landed
+        landed(); // group 0 has landed
         rbp_barrier();
 #ifndef RBP_LOADER_SLEEP
 #define RBP_LOADER_SLEEP 0 /* A/B aid: s_sleep units (64 cycles) between the barrier and the step's DMA issue */
 #endif
         for (int t = 0; t < nsteps; t++) {
 #ifdef PDEIP_RBP_STAMPS
-            const bool stamp_on = (blockIdx.x == 100) && (RBP_STAMP_SWEEP == 9) && (t >= RBP_STAMP_T0) && (t < RBP_STAMP_T0 + 24);
+            const bool stamp_on = (blockIdx.x == 100) && (RBP_STAMP_SWEEP == 9) && (lw == 0) && (t >= RBP_STAMP_T0) && (t < RBP_STAMP_T0 + 24);
 #endif
             RBP_STAMP(0);
             if (RBP_LOADER_SLEEP > 0) __builtin_amdgcn_s_sleep(RBP_LOADER_SLEEP);
             if (t + L::P < nsteps) { // group nsteps-1 is the last one a sweep wave reads (as "column x+1" of its last step)
                 issue(t + L::P);
                 RBP_STAMP(1); // the step's DMA instructions issued
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((L::P - 1) * L::GROUP) : "memory"); // group t+1 has landed
+                landed(); // group t+1 has landed
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the tail: nothing new to fetch, everything issued has landed
             }

@@ -36,8 +36,13 @@ template <class Mdl, int NBUF_, int W_ = 64> struct WalkLayout {
     static constexpr size_t LDS_BYTES = (size_t)(NBUF * BUF + 2 * OUTB + CTRL) * sizeof(float);
     static constexpr int PIECES = NF * NFP + NPK + NF;         // LDS-DMA instructions per chunk
     static constexpr int NCOMP = NIT == 2 ? 2 : 1;             // compute waves (one per field of the coupled models)
-    static constexpr int THREADS = 64 * (NCOMP + 3);           // + loader, storer, poller
-    static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && (NBUF < 3 || PIECES <= 63);
+#ifndef PDEIP_WALK_LOADERS
+#define PDEIP_WALK_LOADERS 1
+#endif
+    static constexpr int NLOAD = PDEIP_WALK_LOADERS;           // loader waves: loader w issues the pieces i of a chunk with i % NLOAD == w (its own vmcnt queue)
+    static constexpr int THREADS = 64 * (NCOMP + 2 + NLOAD);   // + storer, poller, loader(s) -- the extra loader is the last wave
+    static constexpr int pieces_of(int w) { return (PIECES - w + NLOAD - 1) / NLOAD; }
+    static constexpr bool FITS = LDS_BYTES <= 160 * 1024 && (NBUF < 3 || pieces_of(0) <= 63);
     static_assert(BUF % 4 == 0 && FIELD % 256 == 0 && (W * CS) % 64 == 0 && W % 16 == 0 && W <= 64, "16-byte granules, whole pieces");
 };
 
@@ -100,7 +105,9 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
     //   NIT = 2: 0 storer, 1 compute (field 0), 2 loader, 3 compute (field 1), 4 poller;   NIT = 1: 0 storer, 1 compute, 2 loader, 3 poller
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     enum { R_STORE = 0, R_COMP0 = 1, R_LOAD = 2, R_COMP1 = 3, R_POLL = 4 };
-    const int role = (NIT == 2) ? wave : (wave == 3 ? (int)R_POLL : wave);
+    const int nbase = (NIT == 2) ? 5 : 4; // waves of the one-loader form; wave nbase is the second loader
+    const int ldw = wave >= nbase ? 1 : 0; // which loader (of a loader wave)
+    const int role = wave >= nbase ? (int)R_LOAD : ((NIT == 2) ? wave : (wave == 3 ? (int)R_POLL : wave));
 
     if (threadIdx.x == 0) {
         unsigned item = 0, fr = 0;
@@ -162,25 +169,30 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
             ve = boff(ecol, (which ? 1 - (W - 1) : 1) + 4 * (lane & 3));
         }
         const bool edge_all = lane < 8, edge_east = lane >= 4 && lane < 8;
+        auto mine = [&](int i) { return L::NLOAD == 1 || (i % L::NLOAD) == ldw; }; // piece i of the chunk is this loader's
         auto issue = [&](int buf) __attribute__((always_inline)) {
             float *base = smem + buf * L::BUF;
 #pragma unroll
             for (int f = 0; f < NF; f++)
 #pragma unroll
                 for (int d = 0; d < NFP; d++)
-                    if (f < NIT) walk_dma16<16>(rs[f], base + f * L::FIELD + d * 256, vf[d]); // sc1
-                    else walk_dma16<0>(rs[f], base + f * L::FIELD + d * 256, vf[d]);
+                    if (mine(f * NFP + d)) {
+                        if (f < NIT) walk_dma16<16>(rs[f], base + f * L::FIELD + d * 256, vf[d]); // sc1
+                        else walk_dma16<0>(rs[f], base + f * L::FIELD + d * 256, vf[d]);
+                    }
 #pragma unroll
             for (int d = 0; d < L::NPK; d++)
-                walk_dma16<0>(rs_pack, base + NF * L::FIELD + d * 256, vp[d]);
+                if (mine(NF * NFP + d)) walk_dma16<0>(rs_pack, base + NF * L::FIELD + d * 256, vp[d]);
             // edges: the east column (old values) of every field; the west column of the read-only fields, and of the iterate
             // fields only in the first strip (the frame's border column) -- a later strip's comes by mail (poller wave)
 #pragma unroll
             for (int f = 0; f < NF; f++) {
                 float *edst = base + NF * L::FIELD + L::PACK + f * 32;
-                if ((f < NIT && west_by_mail) ? edge_east : edge_all) {
-                    if (f < NIT) walk_dma16<16>(rs[f], edst, ve); // sc1
-                    else walk_dma16<0>(rs[f], edst, ve);
+                if (mine(NF * NFP + L::NPK + f)) {
+                    if ((f < NIT && west_by_mail) ? edge_east : edge_all) { // a lane mask, never empty: one instruction per field and chunk
+                        if (f < NIT) walk_dma16<16>(rs[f], edst, ve); // sc1
+                        else walk_dma16<0>(rs[f], edst, ve);
+                    }
                 }
             }
 #pragma unroll
@@ -213,13 +225,19 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
                 __builtin_amdgcn_s_sleep(2);
             }
         };
+        // all of this loader's pieces but those of the newest chunk have landed (the count is an immediate: one wait per loader index)
+        static_assert(L::NLOAD == 1 || L::NLOAD == 2, "one or two loader waves");
+        auto one_chunk_in_flight = [&]() __attribute__((always_inline)) {
+            if (ldw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::pieces_of(0)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::pieces_of(L::NLOAD > 1 ? 1 : 0)) : "memory");
+        };
         deps(0);
         issue(0);
         lds_barrier(); // A: chunk 0's dependencies hold -- the compute waves read their start state
         if (D >= 2 && NC > 1) {
             deps(1);
             issue(1 % NBUF);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::PIECES) : "memory");
+            one_chunk_in_flight();
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -233,7 +251,7 @@ k_sor_walk(SweepPlanes<Mdl> P, const float *pack, PersistCtl ctl, int nrows, int
             if (k + D < NC) {
                 deps(k + D);
                 issue(nb);
-                if (D >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L::PIECES) : "memory"); // chunk k+1 has landed
+                if (D >= 2) one_chunk_in_flight(); // chunk k+1 has landed
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
