@@ -655,6 +655,17 @@ def main():
                 nr, nc = 1988, 2880    # C5 disparity, iter = 4
                 w = planes(nr, nc, 4); Ud, = planes(nr, nc, 1, -3, 3); dUd, Cud = planes(nr, nc, 2, -0.5, 0.5); Dud, = planes(nr, nc, 1, 0.05, 2)
                 cfgs.setdefault("C5_disp4_1988x2880_iter4", {})[tag] = rate(lambda: dev.disp_sor_llin4(Ud, dUd, Cud, Dud, *w, 4, OMEGA, mode), 4)
+            # red-black roofline per config: planes a launch must move (coefficients + read-only + iterate in + out) x sweeps fused per launch
+            for key, (npx, planes, it, fuse) in {"C1_elin4_388x584_iter20": (388 * 584, 13, 20, 4), "C2_llin4_1080x1920_iter4": (1080 * 1920, 15, 4, 4),
+                                                 "C3_pde8_2160x3840_iter4": (2160 * 3840, 12, 4, 2), "C5_disp4_1988x2880_iter4": (1988 * 2880, 9, 4, 4)}.items():
+                per_call_s = it / cfgs[key]["red_black"]
+                launches = -(-it // fuse)
+                fused_min = launches * planes * npx * 4
+                cfgs[key]["roofline_red_black"] = {"bound": "hbm", "us_per_call": round(per_call_s * 1e6, 1), "launches_per_call": launches,
+                                                   "bytes_per_call": fused_min, "frac": round(fused_min / per_call_s / 1e9 / HBM_PEAK_GBS, 4),
+                                                   "effective_frac": round(it * planes * npx * 4 / per_call_s / 1e9 / HBM_PEAK_GBS, 4)}
+            cfgs["roofline_note"] = ("frac = launches x planes x 4 B x pixels (what the fused launches of a call must move) / call time / 8 TB/s; effective_frac = the "
+                                     "per-sweep figure (planes x 4 B x pixels x iter); C1 is a 0.9 MB-per-plane frame relaxed out of LDS: a latency chain, not a stream")
             cfgs["unit"] = "iterations/s"
             cfgs["note"] = "C4 (elin4 2160x3840 iter=4) is the headline workload above"
             out["configs"] = cfgs
