@@ -77,6 +77,34 @@ int ws_get(int slot, size_t bytes, float **out)
     return PDEIP_OK;
 }
 
+namespace {
+__global__ void k_copy_d2d(float *__restrict__ dst, const float *__restrict__ src, size_t n, int vec)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const size_t n4 = n >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (size_t i = tid; i < n4; i += stride) d4[i] = s4[i];
+        for (size_t i = (n4 << 2) + tid; i < n; i += stride) dst[i] = src[i];
+    } else {
+        for (size_t i = tid; i < n; i += stride) dst[i] = src[i];
+    }
+}
+} // namespace
+
+int copy_d2d(hipStream_t s, float *dst, const float *src, size_t n)
+{
+    if (n == 0 || dst == src) return PDEIP_OK;
+    const int vec = aligned16(dst) && aligned16(src) ? 1 : 0;
+    const size_t work = vec ? (n + 3) / 4 : n;
+    size_t blocks = (work + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16; // 16 workgroups of 256 threads per compute unit, grid-stride beyond
+    hipLaunchKernelGGL(k_copy_d2d, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, n, vec);
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 int ensure_lds(const void *kernel, size_t bytes)
 {
     DeviceState *d = cur_dev();

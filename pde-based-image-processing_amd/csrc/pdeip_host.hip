@@ -102,8 +102,8 @@ static int oflow_sor_host(const char *who, bool llin, bool fill_residuals, const
 
     if (iter > 0) { // copy the iterate in, relax it in place (Oflow_sor_elin4_2d.c:341-346); the point solvers relax input -> output
         if (solver == PDEIP_SOLVER_ALR) {
-            HIPCHK(hipMemcpyAsync(do0, llin ? ddU : dUin, n * sizeof(float), hipMemcpyDeviceToDevice, 0));
-            HIPCHK(hipMemcpyAsync(do1, llin ? ddV : dVin, n * sizeof(float), hipMemcpyDeviceToDevice, 0));
+            RC(copy_d2d(0, do0, llin ? ddU : dUin, n));
+            RC(copy_d2d(0, do1, llin ? ddV : dVin, n));
         }
         if (solver == PDEIP_SOLVER_ALR && diag)
             RC(pdeip_oflow_alr_llin8_dev(nullptr, dUin, dVin, do0, do1, dM, dCu, dCv, dDu, dDv, dwW, ddiag[0], dwN, ddiag[1], dwE, ddiag[2], dwS, ddiag[3], nrows, ncols, iter, omega, g.mode));

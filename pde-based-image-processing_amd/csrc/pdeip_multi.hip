@@ -117,7 +117,7 @@ static int slab_run(const MultiCall &mc, const SlabPlan &plan, int k, hipStream_
                                  mode, col0));
         break;
     case 4: // the 9-point solver relaxes in place: on a copy
-        HIPCHK(hipMemcpyAsync(d_out[0], d_in[0], slab * F * sizeof(float), hipMemcpyDeviceToDevice, st));
+        RC(copy_d2d(st, d_out[0], d_in[0], slab * F));
         RC(pdeip_pde_sor8_dev(st, d_out[0], d_cf[0], d_cf[1], d_cf[2], d_cf[3], d_cf[4], d_cf[5], d_cf[6], d_cf[7], d_cf[8], d_cf[9], nrows, ncl, F,
                               mc.iter, mc.omega, mode, col0));
         break;

@@ -101,12 +101,12 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     }
     if (iter <= 0) {
         if (dst != nullptr)
-            for (int f = 0; f < NIT; f++) HIPCHK(hipMemcpyAsync(dst[f], P.it_out[f], n * nframes * sizeof(float), hipMemcpyDeviceToDevice, s));
+            for (int f = 0; f < NIT; f++) RC(copy_d2d(s, dst[f], P.it_out[f], n * nframes));
         return PDEIP_OK;
     }
     if (dst != nullptr && mode == PDEIP_MODE_EXACT_ORDER) { // the wavefront kernels relax in place: on the destination
         for (int f = 0; f < NIT; f++) {
-            HIPCHK(hipMemcpyAsync(dst[f], P.it_out[f], n * nframes * sizeof(float), hipMemcpyDeviceToDevice, s));
+            RC(copy_d2d(s, dst[f], P.it_out[f], n * nframes));
             P.it_out[f] = dst[f];
         }
         dst = nullptr;
@@ -347,7 +347,7 @@ int run_sweeps(hipStream_t s, SweepPlanes<Mdl> P, int nrows, int ncols, int nfra
     timer.stop(nlaunch);
     if (!dst && (flips & 1)) // in place and the last launch wrote the scratch copy
         for (int f = 0; f < NIT; f++)
-            HIPCHK(hipMemcpyAsync(bufA[f], bufB[f], n * nframes * sizeof(float), hipMemcpyDeviceToDevice, s));
+            RC(copy_d2d(s, bufA[f], bufB[f], n * nframes));
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }

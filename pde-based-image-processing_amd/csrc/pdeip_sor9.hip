@@ -128,7 +128,7 @@ extern "C" int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, co
         tls.last_launches++;
     }
     timer.stop(nlaunch);
-    if (flips & 1) HIPCHK(hipMemcpyAsync(X, scratch, nf * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (flips & 1) RC(copy_d2d(s, X, scratch, nf));
     HIPCHK(hipGetLastError());
     return PDEIP_OK;
 }
