@@ -495,6 +495,18 @@ typedef struct pdeip_driver_params {
     double alpha, omega, gammaS, b1, b2, scl_factor;
     int firstLoop, secondLoop, iter, solver, scales;
 } pdeip_driver_params;
+/* Iout = TVdenoise8(I_in, param) (matlab/denoising/TVdenoise8.m, runme.m:144) and Iout = TVdenoise4(I_in, param)
+ * (TVdenoise4.m, runme.m:143) as one host-pointer call each: I_in single, 0..1, [nrows x ncols x frames] column-major; the short
+ * pyramid, the lagged-diffusivity loop (weights, PsiData / TRACE / B, PDEsolver8 | PDEsolver4) and the up-scaling stay on the
+ * device.  A member of the parameter struct that is <= 0 (or NaN) keeps the driver's own default; NULL: all defaults
+ * (TVdenoise8: alpha 500, omega 1.75, outer_iter 20, inner_iter 4, solver 2, scl 0.75, scl_factor 0.75; TVdenoise4: alpha 5,
+ * omega 1.75, outer_iter 10, inner_iter 5, solver 2, scl 0.5, scl_factor 0.75). */
+typedef struct pdeip_tv_params {
+    double alpha, omega, scl, scl_factor;
+    int outer_iter, inner_iter, solver;
+} pdeip_tv_params;
+int pdeip_tvdenoise8(const float *Iin, int nrows, int ncols, int frames, const pdeip_tv_params *prm, float *Iout);
+int pdeip_tvdenoise4(const float *Iin, int nrows, int ncols, int frames, const pdeip_tv_params *prm, float *Iout);
 /* [U V] = FlowEminND_llin_2D_v10(Iin, channels, fstTerm, sndTerm, param): Iin = cat(3, frame0, frame1), single, 0..255,
  * [nrows x ncols x 2*channels] column-major; fst_term PDEIP_TERM_RGB | _GRAD, snd_term _NONE | _RGB | _GRADMAG; Us, Vs:
  * param.Us / param.Vs, double [nrows x ncols] or NULL; U, V: [nrows x ncols].  Ordering: pdeip_set_mode / PDEIP_MODE. */

@@ -443,6 +443,80 @@ void disp_nd(Run &R, const float *Il, const float *Ir, int nrows, int ncols, int
     DOHIP(R, hipStreamSynchronize(R.s));
 }
 
+// TVdenoise8.m:36-111 / TVdenoise4.m:37-114: a short pyramid (down to scl x the frame), per scale the lagged-diffusivity loop --
+// outer_iter + 1 times [diffusion weights of the current estimate, PsiData / TRACE / B, PDEsolver8 | PDEsolver4] --, the
+// estimate resized up to the next finer scale.  drivers.py `_tv` / flow_level.py TvLevel, Tv4Level are the statement the tests
+// compare with.  TVdenoise8 leaves its coarsest scale unsmoothed (the driver writes that result to a misspelt variable, :72).
+struct TvParams {
+    double alpha, omega, scl, scl_factor;
+    int outer_iter, inner_iter, solver;
+};
+void tv_run(Run &R, const float *Iin, int nrows, int ncols, int F, const TvParams &p, bool eight, float *Iout_host)
+{
+    struct Lv {
+        int nr, nc;
+        float *I;
+    };
+    const size_t n0 = (size_t)nrows * ncols * F;
+    std::vector<Lv> L(1);
+    L[0] = {nrows, ncols, R.planes(nrows, ncols, F)};
+    DOHIP(R, hipMemcpyAsync(L[0].I, Iin, n0 * sizeof(float), hipMemcpyHostToDevice, R.s));
+    const int ds_rows = (int)std::ceil(nrows * p.scl), ds_cols = (int)std::ceil(ncols * p.scl);
+    const int gsize = eight ? 5 : 7;
+    const std::vector<double> G = gaussian_mask(gsize, eight ? 1.25 : 2.0);
+    for (;;) {
+        const Lv cur = L.back();
+        Lv nx{(int)std::ceil(cur.nr * p.scl_factor), (int)std::ceil(cur.nc * p.scl_factor), nullptr};
+        nx.I = R.planes(nx.nr, nx.nc, F);
+        DO(R, pdeip_pyr_resize_dev(R.s, cur.I, cur.nr, cur.nc, F, nx.nr, nx.nc, 0, nx.I));
+        float *sm = R.planes(cur.nr, cur.nc, F);
+        DO(R, pdeip_pyr_smooth_dev(R.s, cur.I, cur.nr, cur.nc, F, G.data(), gsize, sm));
+        L.back().I = sm;
+        L.push_back(nx);
+        // (a frame that no longer shrinks ends the pyramid too: the reference's loop would not end)
+        if (nx.nr <= ds_rows || nx.nc <= ds_cols || (nx.nr == cur.nr && nx.nc == cur.nc)) {
+            if (!eight) {
+                float *t = R.planes(nx.nr, nx.nc, F);
+                DO(R, pdeip_pyr_smooth_dev(R.s, nx.I, nx.nr, nx.nc, F, G.data(), gsize, t));
+                L.back().I = t;
+            }
+            break;
+        }
+    }
+    const float *est = L.back().I;
+    int er = L.back().nr, ec = L.back().nc;
+    for (int s = (int)L.size() - 1; s >= 0; s--) {
+        const int nr = L[s].nr, nc = L[s].nc;
+        float *X = R.planes(nr, nc, F), *TRACE = R.planes(nr, nc, F), *B = R.planes(nr, nc, F), *w[8];
+        for (int k = 0; k < (eight ? 8 : 4); k++) w[k] = R.planes(nr, nc, F);
+        DO(R, copy_d2d(R.s, X, est, (size_t)nr * nc * F));
+        (void)er; (void)ec;
+        for (int it = 0; it <= p.outer_iter; it++) { // for iter=0:param.outer_iter
+            if (eight) {
+                DO(R, pdeip_tv_assemble_dev(R.s, X, L[s].I, nr, nc, F, (float)p.alpha, TRACE, B, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]));
+                if (p.solver == PDEIP_SOLVER_SOR) DO(R, pdeip_pde_sor8_dev(R.s, X, TRACE, B, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], nr, nc, F, p.inner_iter, (float)p.omega, R.mode, 0));
+                else DO(R, pdeip_pde_alr8_dev(R.s, X, TRACE, B, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], nr, nc, F, p.inner_iter, (float)p.omega, R.mode));
+            } else {
+                DO(R, pdeip_tv4_assemble_dev(R.s, X, L[s].I, nr, nc, F, (float)p.alpha, TRACE, B, w[0], w[1], w[2], w[3]));
+                if (p.solver == PDEIP_SOLVER_SOR) DO(R, pdeip_pde_sor4_dev(R.s, X, TRACE, B, w[0], w[1], w[2], w[3], nr, nc, F, p.inner_iter, (float)p.omega, R.mode, 0));
+                else DO(R, pdeip_pde_alr4_dev(R.s, X, TRACE, B, w[0], w[1], w[2], w[3], nr, nc, F, p.inner_iter, (float)p.omega, R.mode));
+            }
+        }
+        est = X;
+        er = nr;
+        ec = nc;
+        if (s > 0) {
+            float *up = R.planes(L[s - 1].nr, L[s - 1].nc, F);
+            DO(R, pdeip_pyr_resize_dev(R.s, X, nr, nc, F, L[s - 1].nr, L[s - 1].nc, 0, up));
+            est = up;
+        }
+    }
+    DOHIP(R, hipMemcpyAsync(Iout_host, est, n0 * sizeof(float), hipMemcpyDeviceToHost, R.s));
+    DOHIP(R, hipStreamSynchronize(R.s));
+}
+
+int tv_entry(const char *who, const float *Iin, int nrows, int ncols, int frames, const pdeip_tv_params *u, const TvParams &dflt, bool eight, float *Iout);
+
 template <class Body> int play(const char *who, Body body)
 {
     RC(use_device());
@@ -462,7 +536,40 @@ template <class Body> int play(const char *who, Body body)
     return PDEIP_OK;
 }
 
+int tv_entry(const char *who, const float *Iin, int nrows, int ncols, int frames, const pdeip_tv_params *u, const TvParams &dflt, bool eight, float *Iout)
+{
+    NONNULL(who, Iin);
+    NONNULL(who, Iout);
+    RC(check_dims(who, nrows, ncols, frames));
+    read_env_once();
+    TvParams p = dflt;
+    if (u != nullptr) { // <= 0 or NaN: the driver's default
+        auto D = [](double v, double d) { return (v > 0.0) ? v : d; };
+        auto I = [](int v, int d) { return v > 0 ? v : d; };
+        p.alpha = D(u->alpha, dflt.alpha);
+        p.omega = D(u->omega, dflt.omega);
+        p.scl = D(u->scl, dflt.scl);
+        p.scl_factor = D(u->scl_factor, dflt.scl_factor);
+        p.outer_iter = I(u->outer_iter, dflt.outer_iter);
+        p.inner_iter = I(u->inner_iter, dflt.inner_iter);
+        p.solver = I(u->solver, dflt.solver);
+    }
+    RC(check_solver(who, p.solver));
+    if (!(p.scl_factor < 1.0)) return set_err(PDEIP_ERR_ARG, "%s: scl_factor must be below 1", who);
+    return play(who, [&](Run &R) { tv_run(R, Iin, nrows, ncols, frames, p, eight, Iout); });
+}
+
 } // namespace
+
+extern "C" int pdeip_tvdenoise8(const float *Iin, int nrows, int ncols, int frames, const pdeip_tv_params *prm, float *Iout)
+{
+    return tv_entry("pdeip_tvdenoise8", Iin, nrows, ncols, frames, prm, TvParams{500.0, 1.75, 0.75, 0.75, 20, 4, PDEIP_SOLVER_ALR}, true, Iout); // TVdenoise8.m:36-44
+}
+
+extern "C" int pdeip_tvdenoise4(const float *Iin, int nrows, int ncols, int frames, const pdeip_tv_params *prm, float *Iout)
+{
+    return tv_entry("pdeip_tvdenoise4", Iin, nrows, ncols, frames, prm, TvParams{5.0, 1.75, 0.5, 0.75, 10, 5, PDEIP_SOLVER_ALR}, false, Iout); // TVdenoise4.m:37-45
+}
 
 extern "C" int pdeip_flow_nd_llin(const float *Iin, int nrows, int ncols, int channels, int fst_term, int snd_term, const pdeip_driver_params *prm,
                                   const double *Us, const double *Vs, float *U, float *V)

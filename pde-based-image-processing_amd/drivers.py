@@ -325,3 +325,39 @@ def capi_DispEminND_llin_2D(Il, Ir, fstTerm="rgb", sndTerm="none", mode=capi.MOD
     finally:
         capi.set_mode(old)
     return U
+
+
+def _c_tv_params(param):
+    import ctypes
+
+    class P(ctypes.Structure):
+        _fields_ = [(k, ctypes.c_double) for k in ("alpha", "omega", "scl", "scl_factor")] + [(k, ctypes.c_int) for k in ("outer_iter", "inner_iter", "solver")]
+    s = P()
+    for k, _ in P._fields_:
+        setattr(s, k, type(getattr(s, k))(param.get(k, 0) or 0))
+    return s
+
+
+def _capi_tv(entry, I_in, mode, param):
+    import ctypes
+    I = _f_single(I_in)
+    rows, cols, F = I.shape
+    out = np.zeros((rows, cols, F), np.float32, order="F")
+    prm = _c_tv_params(param)
+    old = capi.get_mode()
+    capi.set_mode(mode)
+    try:
+        capi.call(entry, I.ctypes.data, rows, cols, F, ctypes.addressof(prm), out.ctypes.data)
+    finally:
+        capi.set_mode(old)
+    return out if np.asarray(I_in).ndim == 3 else out[:, :, 0]
+
+
+def capi_TVdenoise8(I_in, mode=capi.MODE_EXACT_ORDER, **param):
+    """pdeip_tvdenoise8 on a MATLAB-shaped numpy array: the C++ twin of TVdenoise8 above, same bits."""
+    return _capi_tv("pdeip_tvdenoise8", I_in, mode, param)
+
+
+def capi_TVdenoise4(I_in, mode=capi.MODE_EXACT_ORDER, **param):
+    """pdeip_tvdenoise4: the C++ twin of TVdenoise4."""
+    return _capi_tv("pdeip_tvdenoise4", I_in, mode, param)

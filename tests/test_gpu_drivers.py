@@ -192,6 +192,33 @@ def test_resident_cxx_drivers_equal_the_python_drivers(pdeip):
         D.capi_FlowEminND_llin_2D_v10(I, 1, "gradmag", "none")   # 'No such fstTerm'
 
 
+def test_resident_tv_drivers_equal_the_python_drivers(pdeip):
+    """pdeip_tvdenoise8 / pdeip_tvdenoise4 (runme.m:143-144 as one C-ABI call each) against the Python drivers, bit for bit:
+    grey and three-frame images, both orderings and solvers, non-default pyramids and loop counts; and through the MEX stubs."""
+    import test_mex_stubs as tm
+    D = drv()
+    rng = np.random.default_rng(21)
+    ii, jj = np.meshgrid(np.arange(96), np.arange(120), indexing="ij")
+    base = (0.5 + 0.3 * np.sin(0.11 * ii) * np.cos(0.07 * jj) + 0.2 * (ii > 40) * (jj < 70)).astype(np.float32)
+    noisy = np.clip(base + 0.08 * rng.standard_normal(base.shape).astype(np.float32), 0, 1).astype(np.float32)
+    colour = np.stack([noisy, np.roll(noisy, 3, 0), 1 - noisy], axis=2).astype(np.float32)
+    for name, img, kw in (("TVdenoise8", noisy, {}), ("TVdenoise8", colour, dict(outer_iter=3, solver=1, mode=pdeip.MODE_RED_BLACK)),
+                          ("TVdenoise8", noisy, dict(scl=0.4, outer_iter=2, inner_iter=2, alpha=120.0)),
+                          ("TVdenoise4", noisy, {}), ("TVdenoise4", colour, dict(outer_iter=2, solver=1, omega=1.5)),
+                          ("TVdenoise4", noisy, dict(scl=0.3, outer_iter=2, mode=pdeip.MODE_RED_BLACK))):
+        want = getattr(D, name)(img, **kw)
+        got = getattr(D, "capi_" + name)(img, **kw)
+        assert got.shape == want.shape
+        assert pb.bit_equal(got, want), "%s %s %s: %s" % (name, img.shape, sorted(kw), pb.describe_mismatch(got, want))
+    pv = np.array([0, 0, 2, 0, 1, 0, 0], dtype=np.float32).reshape(1, 7)   # outer_iter = 2, solver = 1, the rest default
+    for name in ("TVdenoise8", "TVdenoise4"):
+        err, outs = tm.call(tm.build_stub(name + "_gpu", pdeip), 1, [colour, pv])
+        assert err is None, err
+        assert pb.bit_equal(outs[0], getattr(D, name)(colour, outer_iter=2, solver=1))
+    err, _ = tm.call(tm.build_stub("TVdenoise8_gpu", pdeip), 1, [colour, np.zeros((1, 5), np.float32)])
+    assert "7 elements" in err
+
+
 def test_driver_stubs_through_the_mock_mex_runtime(pdeip):
     """mex/FlowEminND_llin_2D_v10_gpu.c and mex/DispEminND_llin_2D_gpu.c called as MATLAB would call them (numeric arguments:
     the .m wrappers under matlab/ translate the drivers' own argument lists): the Python driver's bits."""
