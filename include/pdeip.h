@@ -495,6 +495,19 @@ typedef struct pdeip_driver_params {
     double alpha, omega, gammaS, b1, b2, scl_factor;
     int firstLoop, secondLoop, iter, solver, scales;
 } pdeip_driver_params;
+/* [U V] = FlowEminHS_elin_2D_v10(Iin, channels, param) (matlab/optical_flow/FlowEminHS_elin_2D_v10.m, runme.m:74): Horn-Schunck
+ * with early linearisation, the whole coarse-to-fine run in one call; Iin as for pdeip_flow_nd_llin.  Of the parameter struct
+ * alpha (0.2), omega (1.9), iter (20), b1 (0.25), b2 (0.75), scl_factor (0.75) and solver (2) are this driver's. */
+int pdeip_flow_hs_elin(const float *Iin, int nrows, int ncols, int channels, const pdeip_driver_params *prm, float *U, float *V);
+/* U = DispEminND_llin_sym_2D(Il, Ir, param) (matlab/disparity/DispEminND_llin_sym_2D.m, runme.m:28): symmetric stereo, both
+ * views' disparities; Il, Ir single [nrows x ncols x channels] (this driver does not divide by 255); U: [nrows x ncols x 2].
+ * A member that is <= 0 (or NaN) keeps the driver's default (alpha 0.035, beta 0.4, omega 1.9, firstLoop 3, secondLoop 4, iter 4,
+ * b1 0.25, b2 0.72, scl_factor 0.75, solver 2); NULL: all defaults. */
+typedef struct pdeip_sym_params {
+    double alpha, beta, omega, b1, b2, scl_factor;
+    int firstLoop, secondLoop, iter, solver;
+} pdeip_sym_params;
+int pdeip_disp_nd_llin_sym(const float *Il, const float *Ir, int nrows, int ncols, int channels, const pdeip_sym_params *prm, float *U);
 /* Iout = TVdenoise8(I_in, param) (matlab/denoising/TVdenoise8.m, runme.m:144) and Iout = TVdenoise4(I_in, param)
  * (TVdenoise4.m, runme.m:143) as one host-pointer call each: I_in single, 0..1, [nrows x ncols x frames] column-major; the short
  * pyramid, the lagged-diffusivity loop (weights, PsiData / TRACE / B, PDEsolver8 | PDEsolver4) and the up-scaling stay on the

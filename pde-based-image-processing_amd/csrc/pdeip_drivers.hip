@@ -27,6 +27,12 @@ __global__ void k_scale(float *out, const float *in, size_t n, float s, int divi
     if (i < n) out[i] = divide ? in[i] / s : in[i] * s; // a true division where MATLAB divides (Iin ./ 255)
 }
 
+__global__ void k_fill(float *out, size_t n, float v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
 // One run: a stream, a device arena and a dry mode.  The arena is one cached workspace buffer per device, bump-allocated;
 // a run is played twice -- dry (nothing is launched: the sizes only depend on the frame's dimensions) to learn how much it
 // needs, then for real.
@@ -185,7 +191,8 @@ struct Level {
 // The image pyramid of both frames (:100-127 / DispEminND_llin_2D.m:77-104): resize to ceil(size * scl_factor), the level
 // just left is smoothed after it has been resized; downscaling stops at min_size (then the last scale is smoothed too) or at
 // param.scales (then it is not: the loop `for scl=2:param.scales` simply ends).
-std::vector<Level> build_pyramid(Run &R, float *f0, float *f1, int nrows, int ncols, int C, const Params &p, int min_size, const std::vector<double> &G, int gsize)
+std::vector<Level> build_pyramid(Run &R, float *f0, float *f1, int nrows, int ncols, int C, const Params &p, int min_size, const std::vector<double> &G, int gsize,
+                                 bool smooth_last = true)
 {
     std::vector<Level> L(1);
     L[0].nr = nrows;
@@ -208,6 +215,7 @@ std::vector<Level> build_pyramid(Run &R, float *f0, float *f1, int nrows, int nc
         L.back().I1 = s1;
         L.push_back(nx);
         if (nx.nr <= min_size || nx.nc <= min_size) {
+            if (!smooth_last) break; // DispEminND_llin_sym_2D.m:94-98 leaves its coarsest scale as resized
             float *t0 = R.planes(nx.nr, nx.nc, C), *t1 = R.planes(nx.nr, nx.nc, C);
             DO(R, pdeip_pyr_smooth_dev(R.s, nx.I0, nx.nr, nx.nc, C, G.data(), gsize, t0));
             DO(R, pdeip_pyr_smooth_dev(R.s, nx.I1, nx.nr, nx.nc, C, G.data(), gsize, t1));
@@ -443,6 +451,147 @@ void disp_nd(Run &R, const float *Il, const float *Ir, int nrows, int ncols, int
     DOHIP(R, hipStreamSynchronize(R.s));
 }
 
+// DispEminND_llin_sym_2D.m:51-275 (runme.m:28): symmetric stereo -- both views' disparities at once, each warped into the other for
+// the symmetry term.  flow_level.py DispSymLevel.run / drivers.py DispEminND_llin_sym_2D are the statement the tests compare with
+// (same `_dev` stages, same order).  No division by 255 in this driver (:81-82), a 3 x 3 Gaussian, coarsest scale unsmoothed.
+struct SymParams {
+    double alpha, beta, omega, b1, b2, scl_factor;
+    int firstLoop, secondLoop, iter, solver;
+};
+void sym_level(Run &R, const SymParams &p, const Level &lv, int C, float *(&U)[2], double sr_diff)
+{
+    const int nr = lv.nr, nc = lv.nc;
+    const size_t n = (size_t)nr * nc;
+    const double kS = C * p.beta / p.alpha, sr2 = std::pow(sr_diff, 2.0);
+    const float *I[2] = {lv.I0, lv.I1};
+    float *zero = R.planes(nr, nc), *X = R.planes(nr, nc), *Y = R.planes(nr, nc), *S = R.planes(nr, nc);
+    float *warped[2], *der[2][8], *CuG[2], *DuG[2], *w[2][4], *Un[2], *dU[2];
+    double *Uw[2], *sym[2][4];
+    for (int v = 0; v < 2; v++) {
+        warped[v] = R.planes(nr, nc, C);
+        for (auto &q : der[v]) q = R.planes(nr, nc, C);
+        CuG[v] = R.planes(nr, nc);
+        DuG[v] = R.planes(nr, nc);
+        for (auto &q : w[v]) q = R.planes(nr, nc);
+        Un[v] = R.planes(nr, nc);
+        dU[v] = R.planes(nr, nc);
+        Uw[v] = R.dplane(nr, nc);
+        for (auto &q : sym[v]) q = R.dplane(nr, nc);
+    }
+    DOHIP(R, hipMemsetAsync(zero, 0, n * sizeof(float), R.s));
+    for (int fl = 0; fl < p.firstLoop; fl++) {
+        for (int v = 0; v < 2; v++) { // view v: own image, the other view warped by U{v}
+            DO(R, pdeip_flow_coords_dev(R.s, U[v], zero, nr, nc, X, Y));
+            DO(R, pdeip_warp_bilinear_dev(R.s, I[1 - v], X, Y, nr, nc, C, warped[v]));
+        }
+        DO(R, pdeip_sym_warp_flow_dev(R.s, U[0], U[1], nr, nc, Uw[0]));
+        DO(R, pdeip_sym_warp_flow_dev(R.s, U[1], U[0], nr, nc, Uw[1]));
+        for (int v = 0; v < 2; v++) {
+            DO(R, pdeip_fst_derivatives5_dev(R.s, I[v], warped[v], nr, nc, C, der[v][0], der[v][1], der[v][2]));
+            DO(R, pdeip_snd_derivatives5_dev(R.s, I[v], warped[v], nr, nc, C, der[v][3], der[v][4], der[v][5], der[v][6], der[v][7]));
+            DO(R, pdeip_sym_flow_terms_dev(R.s, U[v], Uw[1 - v], nr, nc, sym[v][0], sym[v][1], sym[v][2], sym[v][3]));
+            DOHIP(R, hipMemsetAsync(dU[v], 0, n * sizeof(float), R.s));
+        }
+        for (int k = 0; k < p.secondLoop; k++) {
+            for (int v = 0; v < 2; v++) {
+                DO(R, pdeip_sym_assemble_dev(R.s, der[v][0], der[v][1], der[v][3], der[v][4], der[v][5], der[v][7], C, sym[v][0], sym[v][1], sym[v][2], sym[v][3], dU[v],
+                                             (float)p.b1, (float)p.b2, (float)p.alpha, kS, sr2, k == 0 ? 1 : 0, nr, nc, CuG[v], DuG[v]));
+                DO(R, pdeip_add_dev(R.s, U[v], dU[v], nr, nc, S));
+                DO(R, pdeip_diffweights6_dev(R.s, S, nr, nc, 1, (float)0.00001, w[v][0], w[v][1], w[v][2], w[v][3]));
+            }
+            DO(R, pdeip_disp_sor_llin_sym4_dev(R.s, U[0], dU[0], CuG[0], DuG[0], w[0][0], w[0][1], w[0][2], w[0][3], U[1], dU[1], CuG[1], DuG[1], w[1][0], w[1][1],
+                                               w[1][2], w[1][3], nr, nc, p.iter, (float)p.omega, p.solver, R.mode, 0));
+        }
+        for (int v = 0; v < 2; v++) {
+            DO(R, pdeip_median3_dev(R.s, U[v], dU[v], nr, nc, Un[v]));
+            std::swap(U[v], Un[v]);
+        }
+    }
+}
+void disp_sym(Run &R, const float *Il, const float *Ir, int nrows, int ncols, int C, const SymParams &p, float *U_out)
+{
+    const size_t n = (size_t)nrows * ncols;
+    float *fr = R.planes(nrows, ncols, 2 * C);
+    DOHIP(R, hipMemcpyAsync(fr, Il, C * n * sizeof(float), hipMemcpyHostToDevice, R.s));
+    DOHIP(R, hipMemcpyAsync(fr + C * n, Ir, C * n * sizeof(float), hipMemcpyHostToDevice, R.s));
+    Params pp{};
+    pp.scl_factor = p.scl_factor;
+    pp.scales = 0x7fffffff;
+    const std::vector<double> G = gaussian_mask(3, 1.0);
+    const std::vector<Level> L = build_pyramid(R, fr, fr + C * n, nrows, ncols, C, pp, 10, G, 3, false);
+    const Level top = L.back();
+    float *U[2] = {R.planes(top.nr, top.nc), R.planes(top.nr, top.nc)};
+    for (auto *u : U) DOHIP(R, hipMemsetAsync(u, 0, (size_t)top.nr * top.nc * sizeof(float), R.s));
+    const float inv = (float)(1.0 / p.scl_factor);
+    for (int s = (int)L.size() - 1; s >= 0; s--) {
+        // the level gets its own copies of the two fields (the Python level clones them): its ping-pong may end in either plane set
+        float *W[2] = {R.planes(L[s].nr, L[s].nc), R.planes(L[s].nr, L[s].nc)};
+        for (int v = 0; v < 2; v++) DO(R, copy_d2d(R.s, W[v], U[v], (size_t)L[s].nr * L[s].nc));
+        sym_level(R, p, L[s], C, W, 2.0 * std::pow(1.0 / p.scl_factor, (double)(-s))); // srDiff = 2*(1/scl_factor)^-(scl-1), scl 1-based there
+        U[0] = W[0];
+        U[1] = W[1];
+        if (s > 0) {
+            const Level &f = L[s - 1];
+            for (int v = 0; v < 2; v++) {
+                float *sc = R.planes(L[s].nr, L[s].nc), *up = R.planes(f.nr, f.nc);
+                scale(R, sc, U[v], (size_t)L[s].nr * L[s].nc, inv, false);
+                DO(R, pdeip_pyr_resize_dev(R.s, sc, L[s].nr, L[s].nc, 1, f.nr, f.nc, 0, up));
+                U[v] = up;
+            }
+        }
+    }
+    DOHIP(R, hipMemcpyAsync(U_out, U[0], n * sizeof(float), hipMemcpyDeviceToHost, R.s));
+    DOHIP(R, hipMemcpyAsync(U_out + n, U[1], n * sizeof(float), hipMemcpyDeviceToHost, R.s));
+    DOHIP(R, hipStreamSynchronize(R.s));
+}
+
+// FlowEminHS_elin_2D_v10.m:52-200 (runme.m:74): Horn-Schunck with early linearisation.  Per scale the data terms from the unwarped
+// frames (k_hs_assemble), a constant diffusion weight alpha * channels and ONE Oflow_sor_elin4_2d call; between scales
+// imresize(medfilt2(U .* (1/scl_factor)), 'OutputSize', ...) with imresize's default, bicubic, kernel (:189-190).  drivers.py
+// FlowEminHS_elin_2D_v10 / flow_level.py FlowHsLevel are the statement the tests compare with.
+void flow_hs(Run &R, const float *Iin, int nrows, int ncols, int C, const Params &p, float *U_out, float *V_out)
+{
+    const size_t n = (size_t)nrows * ncols;
+    float *up = R.planes(nrows, ncols, 2 * C), *fr = R.planes(nrows, ncols, 2 * C);
+    DOHIP(R, hipMemcpyAsync(up, Iin, 2 * C * n * sizeof(float), hipMemcpyHostToDevice, R.s));
+    scale(R, fr, up, 2 * C * n, 255.0f, true);
+    const std::vector<double> G = gaussian_mask(5, 1.25);
+    const std::vector<Level> L = build_pyramid(R, fr, fr + C * n, nrows, ncols, C, p, 20, G, 5);
+    const Level top = L.back();
+    float *U = R.planes(top.nr, top.nc), *V = R.planes(top.nr, top.nc);
+    DOHIP(R, hipMemsetAsync(U, 0, (size_t)top.nr * top.nc * sizeof(float), R.s));
+    DOHIP(R, hipMemsetAsync(V, 0, (size_t)top.nr * top.nc * sizeof(float), R.s));
+    const float inv = (float)(1.0 / p.scl_factor);
+    for (int s = (int)L.size() - 1; s >= 0; s--) {
+        const int nr = L[s].nr, nc = L[s].nc;
+        const size_t m = (size_t)nr * nc;
+        float *coef[5], *W = R.planes(nr, nc);
+        for (auto &q : coef) q = R.planes(nr, nc);
+        DO(R, pdeip_hs_assemble_dev(R.s, L[s].I0, L[s].I1, C, (float)p.b1, (float)p.b2, nr, nc, coef[0], coef[1], coef[2], coef[3], coef[4]));
+        if (!R.dry && R.rc == PDEIP_OK) hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, R.s, W, m, (float)(p.alpha * C)); // W = alpha*channels*ones (:121)
+        if (p.iter > 0) {
+            if (p.solver == PDEIP_SOLVER_SOR) DO(R, pdeip_oflow_sor_elin4_dev(R.s, U, V, coef[0], coef[1], coef[2], coef[3], coef[4], W, W, W, W, nr, nc, p.iter, (float)p.omega, R.mode, 0));
+            else DO(R, pdeip_oflow_alr_elin4_dev(R.s, U, V, coef[0], coef[1], coef[2], coef[3], coef[4], W, W, W, W, nr, nc, p.iter, (float)p.omega, R.mode));
+        }
+        if (s > 0) {
+            const Level &f = L[s - 1];
+            float *sU = R.planes(nr, nc), *sV = R.planes(nr, nc), *mU = R.planes(nr, nc), *mV = R.planes(nr, nc);
+            scale(R, sU, U, m, inv, false);
+            scale(R, sV, V, m, inv, false);
+            DO(R, pdeip_median3_dev(R.s, sU, nullptr, nr, nc, mU));
+            DO(R, pdeip_median3_dev(R.s, sV, nullptr, nr, nc, mV));
+            float *Un = R.planes(f.nr, f.nc), *Vn = R.planes(f.nr, f.nc);
+            DO(R, pdeip_pyr_resize_dev(R.s, mU, nr, nc, 1, f.nr, f.nc, 1, Un));
+            DO(R, pdeip_pyr_resize_dev(R.s, mV, nr, nc, 1, f.nr, f.nc, 1, Vn));
+            U = Un;
+            V = Vn;
+        }
+    }
+    DOHIP(R, hipMemcpyAsync(U_out, U, n * sizeof(float), hipMemcpyDeviceToHost, R.s));
+    DOHIP(R, hipMemcpyAsync(V_out, V, n * sizeof(float), hipMemcpyDeviceToHost, R.s));
+    DOHIP(R, hipStreamSynchronize(R.s));
+}
+
 // TVdenoise8.m:36-111 / TVdenoise4.m:37-114: a short pyramid (down to scl x the frame), per scale the lagged-diffusivity loop --
 // outer_iter + 1 times [diffusion weights of the current estimate, PsiData / TRACE / B, PDEsolver8 | PDEsolver4] --, the
 // estimate resized up to the next finer scale.  drivers.py `_tv` / flow_level.py TvLevel, Tv4Level are the statement the tests
@@ -587,6 +736,51 @@ extern "C" int pdeip_flow_nd_llin(const float *Iin, int nrows, int ncols, int ch
     RC(check_solver(who, p.solver));
     if (!(p.scl_factor < 1.0)) return set_err(PDEIP_ERR_ARG, "%s: scl_factor must be below 1", who);
     return play(who, [&](Run &R) { flow_nd(R, Iin, nrows, ncols, channels, fst_term, snd_term, p, Us, Vs, U, V); });
+}
+
+extern "C" int pdeip_flow_hs_elin(const float *Iin, int nrows, int ncols, int channels, const pdeip_driver_params *prm, float *U, float *V)
+{
+    const char *who = "pdeip_flow_hs_elin";
+    NONNULL(who, Iin);
+    NONNULL(who, U);
+    NONNULL(who, V);
+    RC(check_dims(who, nrows, ncols, channels));
+    read_env_once();
+    // FlowEminHS_elin_2D_v10.m:52-62 (gammaS, firstLoop, secondLoop, scales: not parameters of this driver)
+    const Params dflt{0.2, 1.9, 0.0, 0.25, 0.75, 0.75, 1, 1, 20, PDEIP_SOLVER_ALR, 0x7fffffff};
+    Params p = merge(prm, dflt);
+    p.scales = 0x7fffffff;
+    RC(check_solver(who, p.solver));
+    if (!(p.scl_factor < 1.0)) return set_err(PDEIP_ERR_ARG, "%s: scl_factor must be below 1", who);
+    return play(who, [&](Run &R) { flow_hs(R, Iin, nrows, ncols, channels, p, U, V); });
+}
+
+extern "C" int pdeip_disp_nd_llin_sym(const float *Il, const float *Ir, int nrows, int ncols, int channels, const pdeip_sym_params *u, float *U)
+{
+    const char *who = "pdeip_disp_nd_llin_sym";
+    NONNULL(who, Il);
+    NONNULL(who, Ir);
+    NONNULL(who, U);
+    RC(check_dims(who, nrows, ncols, channels));
+    read_env_once();
+    SymParams p{0.035, 0.4, 1.9, 0.25, 0.72, 0.75, 3, 4, 4, PDEIP_SOLVER_ALR}; // DispEminND_llin_sym_2D.m:51-62
+    if (u != nullptr) { // <= 0 or NaN: the driver's default
+        auto D = [](double v, double d) { return (v > 0.0) ? v : d; };
+        auto I = [](int v, int d) { return v > 0 ? v : d; };
+        p.alpha = D(u->alpha, p.alpha);
+        p.beta = D(u->beta, p.beta);
+        p.omega = D(u->omega, p.omega);
+        p.b1 = D(u->b1, p.b1);
+        p.b2 = D(u->b2, p.b2);
+        p.scl_factor = D(u->scl_factor, p.scl_factor);
+        p.firstLoop = I(u->firstLoop, p.firstLoop);
+        p.secondLoop = I(u->secondLoop, p.secondLoop);
+        p.iter = I(u->iter, p.iter);
+        p.solver = I(u->solver, p.solver);
+    }
+    RC(check_solver(who, p.solver));
+    if (!(p.scl_factor < 1.0)) return set_err(PDEIP_ERR_ARG, "%s: scl_factor must be below 1", who);
+    return play(who, [&](Run &R) { disp_sym(R, Il, Ir, nrows, ncols, channels, p, U); });
 }
 
 extern "C" int pdeip_disp_nd_llin(const float *Il, const float *Ir, int nrows, int ncols, int channels, int fst_term, int snd_term,

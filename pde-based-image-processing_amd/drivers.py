@@ -361,3 +361,41 @@ def capi_TVdenoise8(I_in, mode=capi.MODE_EXACT_ORDER, **param):
 def capi_TVdenoise4(I_in, mode=capi.MODE_EXACT_ORDER, **param):
     """pdeip_tvdenoise4: the C++ twin of TVdenoise4."""
     return _capi_tv("pdeip_tvdenoise4", I_in, mode, param)
+
+
+def capi_FlowEminHS_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
+    """pdeip_flow_hs_elin: the C++ twin of FlowEminHS_elin_2D_v10 above, same bits."""
+    import ctypes
+    I = _f_single(Iin)
+    rows, cols = I.shape[:2]
+    U, V = np.zeros((rows, cols), np.float32, order="F"), np.zeros((rows, cols), np.float32, order="F")
+    prm = _c_params(param)
+    old = capi.get_mode()
+    capi.set_mode(mode)
+    try:
+        capi.call("pdeip_flow_hs_elin", I.ctypes.data, rows, cols, int(channels), ctypes.addressof(prm), U.ctypes.data, V.ctypes.data)
+    finally:
+        capi.set_mode(old)
+    return U, V
+
+
+def capi_DispEminND_llin_sym_2D(Il, Ir, mode=capi.MODE_EXACT_ORDER, **param):
+    """pdeip_disp_nd_llin_sym: the C++ twin of DispEminND_llin_sym_2D above, same bits; -> U [nrows, ncols, 2]."""
+    import ctypes
+
+    class P(ctypes.Structure):
+        _fields_ = [(k, ctypes.c_double) for k in ("alpha", "beta", "omega", "b1", "b2", "scl_factor")] + \
+                   [(k, ctypes.c_int) for k in ("firstLoop", "secondLoop", "iter", "solver")]
+    prm = P()
+    for k, _ in P._fields_:
+        setattr(prm, k, type(getattr(prm, k))(param.get(k, 0) or 0))
+    L, R = _f_single(Il), _f_single(Ir)
+    rows, cols, C = L.shape
+    U = np.zeros((rows, cols, 2), np.float32, order="F")
+    old = capi.get_mode()
+    capi.set_mode(mode)
+    try:
+        capi.call("pdeip_disp_nd_llin_sym", L.ctypes.data, R.ctypes.data, rows, cols, C, ctypes.addressof(prm), U.ctypes.data)
+    finally:
+        capi.set_mode(old)
+    return U

@@ -1,0 +1,10 @@
+function [U V] = FlowEminHS_elin_2D_v10_gpu(Iin, channels, varargin)
+%[U V] = FlowEminHS_elin_2D_v10_gpu(Iin, channels, varargin)
+%
+%Same call as FlowEminHS_elin_2D_v10 (matlab/optical_flow/FlowEminHS_elin_2D_v10.m of the toolbox); the whole coarse-to-fine
+%run happens on the GPU in one MEX call (mex/FlowEminHS_elin_2D_v10_gpu.c -> libpdeip.so pdeip_flow_hs_elin).
+%NOT RUN IN THIS REPOSITORY (no MATLAB in its build image); the MEX entry is tested through a mock MEX runtime.
+param.alpha = 0; param.omega = 0; param.iter = 0; param.b1 = 0; param.b2 = 0; param.scl_factor = 0; param.solver = 0;	%0 = the driver's default
+param = setParameters(param, varargin{:});
+pv = single([param.alpha param.omega param.iter param.b1 param.b2 param.scl_factor param.solver]);
+[U V] = FlowEminHS_elin_2D_v10_mex(single(Iin), single(channels), pv);

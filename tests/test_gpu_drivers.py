@@ -219,6 +219,47 @@ def test_resident_tv_drivers_equal_the_python_drivers(pdeip):
     assert "7 elements" in err
 
 
+def test_resident_hs_driver_equals_the_python_driver(pdeip):
+    """pdeip_flow_hs_elin (runme.m:74 as one C-ABI call) against drivers.FlowEminHS_elin_2D_v10, bit for bit: Yosemite (one channel)
+    and a three-channel pair, both orderings and solvers; and through the MEX stub."""
+    import test_mex_stubs as tm
+    I, _, _ = _yosemite255()
+    D = drv()
+    I3 = np.concatenate([np.stack([I[:, :, k]] * 3, axis=2) * np.float32([1.0, 0.9, 0.8]) for k in range(2)], axis=2).astype(np.float32)
+    for img, ch, kw in ((I, 1, {}), (I, 1, dict(mode=pdeip.MODE_RED_BLACK, solver=1, iter=8)), (I3, 3, dict(alpha=0.3, iter=6)),
+                        (I3, 3, dict(mode=pdeip.MODE_RED_BLACK, iter=3, scl_factor=0.6))):
+        want = D.FlowEminHS_elin_2D_v10(img, ch, **kw)
+        got = D.capi_FlowEminHS_elin_2D_v10(img, ch, **kw)
+        for g, w in zip(got, want):
+            assert pb.bit_equal(g, w), "HS %d channels %s: %s" % (ch, sorted(kw), pb.describe_mismatch(g, w))
+    pv = np.array([0, 0, 5, 0, 0, 0, 1], dtype=np.float32).reshape(1, 7)   # iter = 5, solver = 1
+    err, outs = tm.call(tm.build_stub("FlowEminHS_elin_2D_v10_gpu", pdeip), 2, [I3, np.float32(3), pv])
+    assert err is None, err
+    want = D.FlowEminHS_elin_2D_v10(I3, 3, iter=5, solver=1)
+    assert pb.bit_equal(outs[0], want[0]) and pb.bit_equal(outs[1], want[1])
+    err, _ = tm.call(tm.build_stub("FlowEminHS_elin_2D_v10_gpu", pdeip), 2, [I3, np.float32(2), pv])
+    assert "2*channels" in err
+
+
+def test_resident_symmetric_stereo_driver_equals_the_python_driver(pdeip):
+    """pdeip_disp_nd_llin_sym (runme.m:28 as one C-ABI call) against drivers.DispEminND_llin_sym_2D, bit for bit: grey and
+    three-channel pairs, both orderings and solvers; and through the MEX stub."""
+    import test_mex_stubs as tm
+    D = drv()
+    left, right = _stereo_pair()
+    L3, R3 = np.stack([left] * 3, axis=2).astype(np.float32), np.stack([right, right * 0.95, right] , axis=2).astype(np.float32)
+    for a, b, kw in ((left, right, {}), (L3, R3, dict(mode=pdeip.MODE_RED_BLACK, solver=1, omega=1.5)),
+                     (L3, R3, dict(firstLoop=2, secondLoop=2, beta=0.2, scl_factor=0.6)), (left, right, dict(mode=pdeip.MODE_RED_BLACK, firstLoop=1))):
+        want = D.DispEminND_llin_sym_2D(a, b, **kw)
+        got = D.capi_DispEminND_llin_sym_2D(a, b, **kw)
+        assert got.shape == want.shape
+        assert pb.bit_equal(got, want), "sym %s %s: %s" % (np.asarray(a).shape, sorted(kw), pb.describe_mismatch(got, want))
+    pv = np.array([0, 0, 0, 2, 2, 0, 0, 0, 0, 1], dtype=np.float32).reshape(1, 10)   # firstLoop = secondLoop = 2, solver = 1
+    err, outs = tm.call(tm.build_stub("DispEminND_llin_sym_2D_gpu", pdeip), 1, [L3, R3, pv])
+    assert err is None, err
+    assert pb.bit_equal(outs[0], D.DispEminND_llin_sym_2D(L3, R3, firstLoop=2, secondLoop=2, solver=1))
+
+
 def test_driver_stubs_through_the_mock_mex_runtime(pdeip):
     """mex/FlowEminND_llin_2D_v10_gpu.c and mex/DispEminND_llin_2D_gpu.c called as MATLAB would call them (numeric arguments:
     the .m wrappers under matlab/ translate the drivers' own argument lists): the Python driver's bits."""
