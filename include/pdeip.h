@@ -495,6 +495,12 @@ typedef struct pdeip_driver_params {
     double alpha, omega, gammaS, b1, b2, scl_factor;
     int firstLoop, secondLoop, iter, solver, scales;
 } pdeip_driver_params;
+/* [U V] = FlowEminAD_llin_2D_v10(Iin, channels, fstTerm, sndTerm, param) (matlab/optical_flow/FlowEminAD_llin_2D_v10.m,
+ * runme.m:54,64): the anisotropic-diffusion flow driver; arguments as pdeip_flow_nd_llin plus param.quantile (<= 0: 0.9) and
+ * param.diffusion (flow_diffusion 0: 'image', the default -- eight weights from frame 0 of a scale, once per scale; 1: 'flow' --
+ * from U+dU+V+dV in every inner iteration). */
+int pdeip_flow_ad_llin(const float *Iin, int nrows, int ncols, int channels, int fst_term, int snd_term, const pdeip_driver_params *prm,
+                       double quantile, int flow_diffusion, const double *Us, const double *Vs, float *U, float *V);
 /* [U V] = FlowEminHS_elin_2D_v10(Iin, channels, param) (matlab/optical_flow/FlowEminHS_elin_2D_v10.m, runme.m:74): Horn-Schunck
  * with early linearisation, the whole coarse-to-fine run in one call; Iin as for pdeip_flow_nd_llin.  Of the parameter struct
  * alpha (0.2), omega (1.9), iter (20), b1 (0.25), b2 (0.75), scl_factor (0.75) and solver (2) are this driver's. */

@@ -306,6 +306,67 @@ void flow_level(Run &R, const Params &p, const Level &lv, const float *I1t0, con
     R.release(m);
 }
 
+// The anisotropic-diffusion twin: FlowEminAD_llin_2D_v10.m:198-366, flow_level.py FlowAdLevel.run -- eight ADdiffWeights from the
+// image (`flow_diffusion` false: once per level, from frame 0 of the scale) or from U+dU+V+dV (true: every inner iteration), and
+// Oflow_sor_llin8_2d, whose point solver runs the 4-neighbour arithmetic on W, N, E, S (opticalflowSolvers.c:1487).
+void flow_ad_level(Run &R, const Params &p, const Level &lv, int C, const float *I1t0, const float *I1t1, int C1, const float *I2t0, const float *I2t1, int C2,
+                   bool gradmag, double quantile, bool flow_diffusion, float *&U, float *&V, float *&Ua, float *&Va, double as_diff, bool u_double)
+{
+    const int nr = lv.nr, nc = lv.nc;
+    const size_t n = (size_t)nr * nc;
+    const size_t m = R.mark();
+    float *X = R.planes(nr, nc), *Y = R.planes(nr, nc), *S = R.planes(nr, nc);
+    float *w1 = R.planes(nr, nc, C1), *d1[3], *w2 = nullptr, *d2[5] = {};
+    for (auto &q : d1) q = R.planes(nr, nc, C1);
+    if (C2 > 0) {
+        w2 = R.planes(nr, nc, C2);
+        for (int k = 0; k < (gradmag ? 5 : 3); k++) d2[k] = R.planes(nr, nc, C2);
+    }
+    float *coef[5], *w8[8], *dU = R.planes(nr, nc), *dV = R.planes(nr, nc); // MGd, CuGd, CvGd, DuGd, DvGd | wW, wNW, wN, wNE, wE, wSE, wS, wSW
+    for (auto &q : coef) q = R.planes(nr, nc);
+    for (auto &q : w8) q = R.planes(nr, nc);
+    if (!flow_diffusion) DO(R, pdeip_ad_weights_dev(R.s, lv.I0, nr, nc, C, quantile, w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7]));
+    for (int first = 0; first < p.firstLoop; first++) {
+        DO(R, pdeip_flow_coords_dev(R.s, U, V, nr, nc, X, Y));
+        DO(R, pdeip_warp_bilinear_dev(R.s, I1t1, X, Y, nr, nc, C1, w1));
+        DO(R, pdeip_fst_derivatives5_dev(R.s, I1t0, w1, nr, nc, C1, d1[0], d1[1], d1[2]));
+        if (C2 > 0) {
+            DO(R, pdeip_warp_bilinear_dev(R.s, I2t1, X, Y, nr, nc, C2, w2));
+            if (gradmag) DO(R, pdeip_snd_derivatives5_dev(R.s, I2t0, w2, nr, nc, C2, d2[0], d2[1], d2[2], d2[3], d2[4]));
+            else DO(R, pdeip_fst_derivatives5_dev(R.s, I2t0, w2, nr, nc, C2, d2[0], d2[1], d2[2]));
+        }
+        DOHIP(R, hipMemsetAsync(dU, 0, n * sizeof(float), R.s));
+        DOHIP(R, hipMemsetAsync(dV, 0, n * sizeof(float), R.s));
+        for (int k = 0; k < p.secondLoop; k++) {
+            if (C2 > 0 && gradmag)
+                DO(R, pdeip_flow_assemble_gradmag_dev(R.s, d1[0], d1[1], d1[2], C1, (float)p.b1, d2[0], d2[1], d2[2], d2[3], d2[4], C2, (float)p.b2, dU, dV, (float)p.alpha,
+                                                      nr, nc, coef[0], coef[1], coef[2], coef[3], coef[4]));
+            else
+                DO(R, pdeip_flow_assemble_dev(R.s, d1[0], d1[1], d1[2], C1, (float)p.b1, C2 > 0 ? d2[0] : nullptr, C2 > 0 ? d2[1] : nullptr, C2 > 0 ? d2[2] : nullptr, C2,
+                                              C2 > 0 ? (float)p.b2 : 0.0f, dU, dV, (float)p.alpha, nr, nc, coef[0], coef[1], coef[2], coef[3], coef[4]));
+            if (lv.Us) DO(R, pdeip_flow_apriori_dev(R.s, lv.Us, U, dU, p.gammaS, p.alpha, as_diff, u_double && first == 0, k == 0, nr, nc, coef[1], coef[3]));
+            if (lv.Vs) DO(R, pdeip_flow_apriori_dev(R.s, lv.Vs, V, dV, p.gammaS, p.alpha, as_diff, u_double && first == 0, k == 0, nr, nc, coef[2], coef[4]));
+            if (flow_diffusion) { // U+dU+V+dV, left to right
+                DO(R, pdeip_add_dev(R.s, U, dU, nr, nc, S));
+                DO(R, pdeip_add_dev(R.s, S, V, nr, nc, S));
+                DO(R, pdeip_add_dev(R.s, S, dV, nr, nc, S));
+                DO(R, pdeip_ad_weights_dev(R.s, S, nr, nc, 1, quantile, w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7]));
+            }
+            if (p.solver == PDEIP_SOLVER_SOR)
+                DO(R, pdeip_oflow_sor_llin4_dev(R.s, U, V, dU, dV, coef[0], coef[1], coef[2], coef[3], coef[4], w8[0], w8[2], w8[4], w8[6], nr, nc, p.iter, (float)p.omega,
+                                                R.mode, 0));
+            else
+                DO(R, pdeip_oflow_alr_llin8_dev(R.s, U, V, dU, dV, coef[0], coef[1], coef[2], coef[3], coef[4], w8[0], w8[1], w8[2], w8[3], w8[4], w8[5], w8[6], w8[7], nr, nc,
+                                                p.iter, (float)p.omega, R.mode));
+        }
+        DO(R, pdeip_median3_dev(R.s, U, dU, nr, nc, Ua));
+        DO(R, pdeip_median3_dev(R.s, V, dV, nr, nc, Va));
+        std::swap(U, Ua);
+        std::swap(V, Va);
+    }
+    R.release(m);
+}
+
 // The stereo twin: DispEminND_llin_2D.m:202-316, flow_level.py DispLlinLevel.run
 void disp_level(Run &R, const Params &p, const Level &lv, const float *I1t0, const float *I1t1, int C1, const float *I2t0, const float *I2t1, int C2,
                 bool gradmag, float *&U, float *&Ua, double as_diff, bool u_double)
@@ -379,7 +440,12 @@ int check_terms(const char *who, int fst, int snd)
 }
 
 // the body of pdeip_flow_nd_llin for one Run (dry or real)
-void flow_nd(Run &R, const float *Iin, int nrows, int ncols, int C, int fst, int snd, const Params &p, const double *Us, const double *Vs, float *U_out, float *V_out)
+struct AdOptions { // quantile < 0: the isotropic driver
+    double quantile = -1.0;
+    bool flow_diffusion = false;
+};
+void flow_nd(Run &R, const float *Iin, int nrows, int ncols, int C, int fst, int snd, const Params &p, const double *Us, const double *Vs, float *U_out, float *V_out,
+             const AdOptions ad = AdOptions())
 {
     const size_t n = (size_t)nrows * ncols;
     float *up = R.planes(nrows, ncols, 2 * C), *fr = R.planes(nrows, ncols, 2 * C);
@@ -397,8 +463,10 @@ void flow_nd(Run &R, const float *Iin, int nrows, int ncols, int C, int fst, int
     for (int s = (int)L.size() - 1; s >= 0; s--) {
         const size_t m = R.mark();
         const Terms t = terms(R, L[s], C, fst, snd);
-        flow_level(R, p, L[s], t.a0, t.a1, t.C1, t.b0, t.b1, t.C2, snd == PDEIP_TERM_GRADMAG, U, V, Ua, Va, 2.0 * std::pow(p.scl_factor, (double)s),
-                   s == (int)L.size() - 1 && (Us != nullptr || Vs != nullptr));
+        const double as_diff = 2.0 * std::pow(p.scl_factor, (double)s);
+        const bool coarsest_apriori = s == (int)L.size() - 1 && (Us != nullptr || Vs != nullptr);
+        if (ad.quantile < 0.0) flow_level(R, p, L[s], t.a0, t.a1, t.C1, t.b0, t.b1, t.C2, snd == PDEIP_TERM_GRADMAG, U, V, Ua, Va, as_diff, coarsest_apriori);
+        else flow_ad_level(R, p, L[s], C, t.a0, t.a1, t.C1, t.b0, t.b1, t.C2, snd == PDEIP_TERM_GRADMAG, ad.quantile, ad.flow_diffusion, U, V, Ua, Va, as_diff, coarsest_apriori);
         if (s > 0) { // U = imresize(U .* (1/scl_factor), size of the finer scale, 'triangle')
             const Level &f = L[s - 1];
             scale(R, Ua, U, (size_t)L[s].nr * L[s].nc, inv, false);
@@ -736,6 +804,28 @@ extern "C" int pdeip_flow_nd_llin(const float *Iin, int nrows, int ncols, int ch
     RC(check_solver(who, p.solver));
     if (!(p.scl_factor < 1.0)) return set_err(PDEIP_ERR_ARG, "%s: scl_factor must be below 1", who);
     return play(who, [&](Run &R) { flow_nd(R, Iin, nrows, ncols, channels, fst_term, snd_term, p, Us, Vs, U, V); });
+}
+
+extern "C" int pdeip_flow_ad_llin(const float *Iin, int nrows, int ncols, int channels, int fst_term, int snd_term, const pdeip_driver_params *prm,
+                                  double quantile, int flow_diffusion, const double *Us, const double *Vs, float *U, float *V)
+{
+    const char *who = "pdeip_flow_ad_llin";
+    NONNULL(who, Iin);
+    NONNULL(who, U);
+    NONNULL(who, V);
+    RC(check_dims(who, nrows, ncols, channels));
+    RC(check_terms(who, fst_term, snd_term));
+    read_env_once();
+    // FlowEminAD_llin_2D_v10.m:52-70: the isotropic driver's defaults + quantile 0.9, diffusion 'image'
+    const Params dflt{0.042, 1.9, 0.01, 1.4843, 0.2915, 0.75, 4, 4, 4, PDEIP_SOLVER_ALR, 0x7fffffff};
+    const Params p = merge(prm, dflt);
+    RC(check_solver(who, p.solver));
+    if (!(p.scl_factor < 1.0)) return set_err(PDEIP_ERR_ARG, "%s: scl_factor must be below 1", who);
+    AdOptions ad;
+    ad.quantile = (quantile > 0.0) ? quantile : 0.9;
+    if (ad.quantile > 1.0) return set_err(PDEIP_ERR_ARG, "%s: quantile must be in (0, 1]", who);
+    ad.flow_diffusion = flow_diffusion != 0;
+    return play(who, [&](Run &R) { flow_nd(R, Iin, nrows, ncols, channels, fst_term, snd_term, p, Us, Vs, U, V, ad); });
 }
 
 extern "C" int pdeip_flow_hs_elin(const float *Iin, int nrows, int ncols, int channels, const pdeip_driver_params *prm, float *U, float *V)

@@ -399,3 +399,22 @@ def capi_DispEminND_llin_sym_2D(Il, Ir, mode=capi.MODE_EXACT_ORDER, **param):
     finally:
         capi.set_mode(old)
     return U
+
+
+def capi_FlowEminAD_llin_2D_v10(Iin, channels, fstTerm="rgb", sndTerm="none", mode=capi.MODE_EXACT_ORDER, Us=None, Vs=None, quantile=0.0, diffusion="image", **param):
+    """pdeip_flow_ad_llin: the C++ twin of FlowEminAD_llin_2D_v10 above, same bits."""
+    import ctypes
+    I = _f_single(Iin)
+    rows, cols = I.shape[:2]
+    U, V = np.zeros((rows, cols), np.float32, order="F"), np.zeros((rows, cols), np.float32, order="F")
+    us, vs = _f_double(Us), _f_double(Vs)
+    prm = _c_params(param)
+    old = capi.get_mode()
+    capi.set_mode(mode)
+    try:
+        capi.call("pdeip_flow_ad_llin", I.ctypes.data, rows, cols, int(channels), _TERM[fstTerm.upper()], _TERM[sndTerm.upper()], ctypes.addressof(prm),
+                  float(quantile), int(str(diffusion).lower() == "flow"), None if us is None else us.ctypes.data, None if vs is None else vs.ctypes.data,
+                  U.ctypes.data, V.ctypes.data)
+    finally:
+        capi.set_mode(old)
+    return U, V

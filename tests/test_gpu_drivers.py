@@ -260,6 +260,30 @@ def test_resident_symmetric_stereo_driver_equals_the_python_driver(pdeip):
     assert pb.bit_equal(outs[0], D.DispEminND_llin_sym_2D(L3, R3, firstLoop=2, secondLoop=2, solver=1))
 
 
+def test_resident_anisotropic_flow_driver_equals_the_python_driver(pdeip):
+    """pdeip_flow_ad_llin (runme.m:54,64 as one C-ABI call) against drivers.FlowEminAD_llin_2D_v10, bit for bit: Yosemite with
+    'image' and 'flow' diffusion, both solvers (the point solver runs the 4-neighbour arithmetic) and orderings, the gradient
+    magnitude term, a limited pyramid, an a-priori field; and through the MEX stub."""
+    import test_mex_stubs as tm
+    I, Ut, Vt = _yosemite255()
+    D = drv()
+    cases = [dict(fst="grad", snd="gradmag", kw=dict(scales=5)),
+             dict(fst="rgb", snd="none", kw=dict(diffusion="flow", scales=4, firstLoop=2)),
+             dict(fst="rgb", snd="rgb", kw=dict(mode=pdeip.MODE_RED_BLACK, solver=1, omega=1.5, scales=4)),
+             dict(fst="grad", snd="none", kw=dict(mode=pdeip.MODE_RED_BLACK, diffusion="flow", quantile=0.8, scales=3, secondLoop=2)),
+             dict(fst="rgb", snd="none", kw=dict(scales=3, Us=Ut.astype(np.float64), gammaS=0.02))]
+    for c in cases:
+        want = D.FlowEminAD_llin_2D_v10(I, 1, c["fst"], c["snd"], **c["kw"])
+        got = D.capi_FlowEminAD_llin_2D_v10(I, 1, c["fst"], c["snd"], **c["kw"])
+        for g, w in zip(got, want):
+            assert pb.bit_equal(g, w), "AD %s/%s %s: %s" % (c["fst"], c["snd"], sorted(c["kw"]), pb.describe_mismatch(g, w))
+    pv = np.array([0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 3, 0.85, 1], dtype=np.float32).reshape(1, 13)   # firstLoop 2, scales 3, quantile 0.85, 'flow'
+    err, outs = tm.call(tm.build_stub("FlowEminAD_llin_2D_v10_gpu", pdeip), 2, [I, np.float32(1), np.float32(1), np.float32(0), pv])
+    assert err is None, err
+    want = D.FlowEminAD_llin_2D_v10(I, 1, "rgb", "none", firstLoop=2, scales=3, quantile=float(np.float32(0.85)), diffusion="flow")
+    assert pb.bit_equal(outs[0], want[0]) and pb.bit_equal(outs[1], want[1])
+
+
 def test_driver_stubs_through_the_mock_mex_runtime(pdeip):
     """mex/FlowEminND_llin_2D_v10_gpu.c and mex/DispEminND_llin_2D_gpu.c called as MATLAB would call them (numeric arguments:
     the .m wrappers under matlab/ translate the drivers' own argument lists): the Python driver's bits."""
