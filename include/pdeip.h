@@ -501,6 +501,15 @@ typedef struct pdeip_driver_params {
  * from U+dU+V+dV in every inner iteration). */
 int pdeip_flow_ad_llin(const float *Iin, int nrows, int ncols, int channels, int fst_term, int snd_term, const pdeip_driver_params *prm,
                        double quantile, int flow_diffusion, const double *Us, const double *Vs, float *U, float *V);
+/* [U V] = FlowEminNDFASFMG_elin_2D_v10(Iin, channels, param) (matlab/optical_flow/FlowEminNDFASFMG_elin_2D_v10.m, runme.m:90): the FAS
+ * full-multigrid flow driver in one call; Iin as for pdeip_flow_nd_llin (0..255, not rescaled by this driver).  A member that is
+ * <= 0 (or NaN) keeps the driver's default (alpha 0.035, omega 1.9, firstLoop 4, iter 4, b1 0.03, b2 0.97, scl_factor 0.5,
+ * solver 2, cycle_index 1 = V-cycle, scales = until a side is <= 10 pixels); NULL: all defaults. */
+typedef struct pdeip_fas_params {
+    double alpha, omega, b1, b2, scl_factor;
+    int firstLoop, iter, solver, cycle_index, scales;
+} pdeip_fas_params;
+int pdeip_flow_fas_fmg_elin(const float *Iin, int nrows, int ncols, int channels, const pdeip_fas_params *prm, float *U, float *V);
 /* [U V] = FlowEminHS_elin_2D_v10(Iin, channels, param) (matlab/optical_flow/FlowEminHS_elin_2D_v10.m, runme.m:74): Horn-Schunck
  * with early linearisation, the whole coarse-to-fine run in one call; Iin as for pdeip_flow_nd_llin.  Of the parameter struct
  * alpha (0.2), omega (1.9), iter (20), b1 (0.25), b2 (0.75), scl_factor (0.75) and solver (2) are this driver's. */

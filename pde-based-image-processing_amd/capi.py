@@ -115,6 +115,7 @@ SIGNATURES = {
     "pdeip_flow_hs_elin": [_P, _I, _I, _I, _P, _P, _P],
     "pdeip_disp_nd_llin_sym": [_P, _P, _I, _I, _I, _P, _P],
     "pdeip_flow_ad_llin": [_P, _I, _I, _I, _I, _I, _P, ctypes.c_double, _I, _P, _P, _P, _P],
+    "pdeip_flow_fas_fmg_elin": [_P, _I, _I, _I, _P, _P, _P],
     "pdeip_tvdenoise8": [_P, _I, _I, _I, _P, _P],
     "pdeip_tvdenoise4": [_P, _I, _I, _I, _P, _P],
     # library state

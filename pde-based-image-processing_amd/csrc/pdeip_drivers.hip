@@ -660,6 +660,146 @@ void flow_hs(Run &R, const float *Iin, int nrows, int ncols, int C, const Params
     DOHIP(R, hipStreamSynchronize(R.s));
 }
 
+// FlowEminNDFASFMG_elin_2D_v10.m (runme.m:90): FAS full-multigrid flow with early linearisation.  Image pyramid by halving
+// (:104-120), per-scale derivative planes and constants (:125-153), per scale, coarse to fine (:161-183), one FAS V- or W-cycle
+// (FAS_CYCLE, :193-273) whose smoother (:367-464) is firstLoop x [robust data weights + OPdiffWeights, Oflow_sor_elin4_2d];
+// residuals through the solver's residual operator, the coarse right-hand side through Oflow_lhs_elin4_2d, full-weighting
+// restriction, bilinear prolongation of the correction, bicubic up-scaling of the flow between scales.  fas.py FasFmgFlow is the
+// statement the tests compare with: the same `_dev` stages in the same order.
+struct FasParams {
+    double alpha, omega, b1, b2, scl_factor;
+    int firstLoop, iter, solver, cycle_index, scales;
+};
+struct FasScale {
+    int nr, nc;
+    float *pl; // [13][C][nc][nr]: Idt, Idx, Idy, Idxx, Idyy, Idxy, Idxt, Idyt, M, Cu, Cv, Du, Dv
+};
+struct Fas {
+    Run &R;
+    const FasParams &p;
+    int C;
+    std::vector<FasScale> S;
+    float *plane(int s, int k) const { return S[s].pl + (size_t)k * C * S[s].nr * S[s].nc; }
+    void solve(int s, float *U, float *V, float *const (&c)[9])
+    {
+        if (p.solver == PDEIP_SOLVER_SOR) DO(R, pdeip_oflow_sor_elin4_dev(R.s, U, V, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], S[s].nr, S[s].nc, p.iter, (float)p.omega, R.mode, 0));
+        else DO(R, pdeip_oflow_alr_elin4_dev(R.s, U, V, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], S[s].nr, S[s].nc, p.iter, (float)p.omega, R.mode));
+    }
+    // in place on U, V; RU, RV ([C] planes) receive the residuals when given
+    void smooth(int s, float *U, float *V, const float *Cu, const float *Cv, float *RU, float *RV)
+    {
+        const int nr = S[s].nr, nc = S[s].nc;
+        const size_t m = R.mark();
+        float *coef[9]; // MGd CuGd CvGd DuGd DvGd wW wN wE wS
+        for (auto &q : coef) q = R.planes(nr, nc);
+        for (int it = 0; it < p.firstLoop; it++) { // robust data weights (:377-397) and OPdiffWeights(U, V) (:392): wW wN wS wE order
+            DO(R, pdeip_fas_assemble_weights_dev(R.s, S[s].pl, Cu, Cv, U, V, nr, nc, C, (float)p.b1, (float)p.b2, (float)(C * p.alpha), coef[0], coef[1], coef[2], coef[3], coef[4],
+                                                 coef[5], coef[6], coef[8], coef[7]));
+            solve(s, U, V, coef);
+        }
+        if (RU != nullptr) {
+            float *f[5];
+            for (auto &q : f) q = R.planes(nr, nc, C);
+            DO(R, pdeip_fas_assemble_dev(R.s, S[s].pl, Cu, Cv, U, V, nr, nc, C, (float)p.b1, (float)p.b2, (float)p.alpha, 1, f[0], f[1], f[2], f[3], f[4], nullptr));
+            DO(R, pdeip_flow_opdiffweights_dev(R.s, U, V, nullptr, nullptr, nr, nc, coef[5], coef[6], coef[8], coef[7]));
+            DO(R, pdeip_oflow_res_elin4_dev(R.s, RU, RV, U, V, f[0], f[1], f[2], f[3], f[4], coef[5], coef[6], coef[7], coef[8], nr, nc, C));
+        }
+        R.release(m);
+    }
+    // one V (cycle_index 1) or W (2) cycle at scale s on U, V (in place); Cu / Cv: the scale's own or the cycle's right-hand side
+    void cycle(int s, float *U, float *V, const float *Cu, const float *Cv)
+    {
+        if (s == (int)S.size() - 1) {
+            smooth(s, U, V, Cu, Cv, nullptr, nullptr);
+            return;
+        }
+        const int nr = S[s].nr, nc = S[s].nc, cr = S[s + 1].nr, cc = S[s + 1].nc;
+        const float sf = (float)p.scl_factor;
+        for (int ci = 0; ci < p.cycle_index; ci++) {
+            const size_t m = R.mark();
+            float *RU = R.planes(nr, nc, C), *RV = R.planes(nr, nc, C);
+            smooth(s, U, V, Cu, Cv, RU, RV);
+            float *RUres = R.planes(cr, cc, C), *RVres = R.planes(cr, cc, C), *Ures = R.planes(cr, cc), *Vres = R.planes(cr, cc);
+            DO(R, pdeip_fas_restrict_dev(R.s, RU, nr, nc, C, sf, RUres));
+            DO(R, pdeip_fas_restrict_dev(R.s, RV, nr, nc, C, sf, RVres));
+            DO(R, pdeip_fas_restrict_dev(R.s, U, nr, nc, 1, sf, Ures));
+            DO(R, pdeip_fas_restrict_dev(R.s, V, nr, nc, 1, sf, Vres));
+            float *MGd = R.planes(cr, cc, C), *DuGd = R.planes(cr, cc, C), *DvGd = R.planes(cr, cc, C), *gd = R.planes(cr, cc, C), *w[4];
+            for (auto &q : w) q = R.planes(cr, cc); // wW wN wE wS
+            DO(R, pdeip_fas_assemble_dev(R.s, S[s + 1].pl, nullptr, nullptr, Ures, Vres, cr, cc, C, (float)p.b1, (float)p.b2, (float)p.alpha, 1, MGd, nullptr, nullptr, DuGd, DvGd, gd));
+            DO(R, pdeip_flow_opdiffweights_dev(R.s, Ures, Vres, nullptr, nullptr, cr, cc, w[0], w[1], w[3], w[2]));
+            float *Au = R.planes(cr, cc, C), *Av = R.planes(cr, cc, C), *fu = R.planes(cr, cc, C), *fv = R.planes(cr, cc, C);
+            DO(R, pdeip_oflow_lhs_elin4_dev(R.s, Au, Av, Ures, Vres, MGd, DuGd, DvGd, w[0], w[1], w[2], w[3], cr, cc, C));
+            DO(R, pdeip_fas_rhs_dev(R.s, RUres, Au, gd, cr, cc, C, fu));
+            DO(R, pdeip_fas_rhs_dev(R.s, RVres, Av, gd, cr, cc, C, fv));
+            float *Uc = R.planes(cr, cc), *Vc = R.planes(cr, cc);
+            DO(R, copy_d2d(R.s, Uc, Ures, (size_t)cr * cc));
+            DO(R, copy_d2d(R.s, Vc, Vres, (size_t)cr * cc));
+            cycle(s + 1, Uc, Vc, fu, fv);
+            DO(R, pdeip_fas_prolong_add_dev(R.s, U, nr, nc, Uc, Ures, cr, cc, (float)(1.0 / p.scl_factor)));
+            DO(R, pdeip_fas_prolong_add_dev(R.s, V, nr, nc, Vc, Vres, cr, cc, (float)(1.0 / p.scl_factor)));
+            R.release(m);
+        }
+        smooth(s, U, V, Cu, Cv, nullptr, nullptr);
+    }
+};
+void fas_fmg(Run &R, const float *Iin, int nrows, int ncols, int C, const FasParams &p, float *U_out, float *V_out)
+{
+    const size_t n = (size_t)nrows * ncols;
+    float *up = R.planes(nrows, ncols, 2 * C);
+    DOHIP(R, hipMemcpyAsync(up, Iin, 2 * C * n * sizeof(float), hipMemcpyHostToDevice, R.s)); // 0..255: this driver does not rescale
+    // fspecial('gaussian', [5 5], 1) as fas.py states it (float64, values below eps * max zeroed, divided by the sum, single)
+    std::vector<double> g = gaussian(5, 1.0);
+    double gmax = 0.0;
+    for (double v : g) gmax = v > gmax ? v : gmax;
+    for (double &v : g)
+        if (v < 2.220446049250313e-16 * gmax) v = 0.0;
+    const double gsum = numpy_sum(g);
+    float G[25];
+    for (int i = 0; i < 25; i++) G[i] = (float)(g[i] / gsum);
+    struct Img {
+        int nr, nc;
+        float *a, *b;
+    };
+    std::vector<Img> P(1);
+    P[0] = {nrows, ncols, R.planes(nrows, ncols, C), R.planes(nrows, ncols, C)};
+    DO(R, pdeip_fas_gauss5_dev(R.s, up, nrows, ncols, C, G, P[0].a));
+    DO(R, pdeip_fas_gauss5_dev(R.s, up + C * n, nrows, ncols, C, G, P[0].b));
+    while ((int)P.size() < p.scales) {
+        const Img cur = P.back();
+        Img nx{(cur.nr + 1) / 2, (cur.nc + 1) / 2, nullptr, nullptr};
+        nx.a = R.planes(nx.nr, nx.nc, C);
+        nx.b = R.planes(nx.nr, nx.nc, C);
+        DO(R, pdeip_fas_down_dev(R.s, cur.a, cur.nr, cur.nc, C, nx.a));
+        DO(R, pdeip_fas_down_dev(R.s, cur.b, cur.nr, cur.nc, C, nx.b));
+        P.push_back(nx);
+        if (nx.nr <= 10 || nx.nc <= 10) break;
+    }
+    Fas F{R, p, C, {}};
+    for (const Img &im : P) {
+        FasScale sc{im.nr, im.nc, R.planes(im.nr, im.nc, 13 * C)};
+        DO(R, pdeip_fas_prepare_dev(R.s, im.a, im.b, im.nr, im.nc, C, (float)p.b1, (float)p.b2, sc.pl));
+        F.S.push_back(sc);
+    }
+    const int last = (int)F.S.size() - 1;
+    float *U = R.planes(F.S[last].nr, F.S[last].nc), *V = R.planes(F.S[last].nr, F.S[last].nc);
+    DOHIP(R, hipMemsetAsync(U, 0, (size_t)F.S[last].nr * F.S[last].nc * sizeof(float), R.s));
+    DOHIP(R, hipMemsetAsync(V, 0, (size_t)F.S[last].nr * F.S[last].nc * sizeof(float), R.s));
+    for (int s = last; s >= 0; s--) {
+        F.cycle(s, U, V, F.plane(s, 9), F.plane(s, 10)); // the scale's own Cu, Cv
+        if (s > 0) {
+            float *Un = R.planes(F.S[s - 1].nr, F.S[s - 1].nc), *Vn = R.planes(F.S[s - 1].nr, F.S[s - 1].nc);
+            DO(R, pdeip_fas_upscale_dev(R.s, U, F.S[s].nr, F.S[s].nc, (float)(1.0 / p.scl_factor), F.S[s - 1].nr, F.S[s - 1].nc, Un));
+            DO(R, pdeip_fas_upscale_dev(R.s, V, F.S[s].nr, F.S[s].nc, (float)(1.0 / p.scl_factor), F.S[s - 1].nr, F.S[s - 1].nc, Vn));
+            U = Un;
+            V = Vn;
+        }
+    }
+    DOHIP(R, hipMemcpyAsync(U_out, U, n * sizeof(float), hipMemcpyDeviceToHost, R.s));
+    DOHIP(R, hipMemcpyAsync(V_out, V, n * sizeof(float), hipMemcpyDeviceToHost, R.s));
+    DOHIP(R, hipStreamSynchronize(R.s));
+}
+
 // TVdenoise8.m:36-111 / TVdenoise4.m:37-114: a short pyramid (down to scl x the frame), per scale the lagged-diffusivity loop --
 // outer_iter + 1 times [diffusion weights of the current estimate, PsiData / TRACE / B, PDEsolver8 | PDEsolver4] --, the
 // estimate resized up to the next finer scale.  drivers.py `_tv` / flow_level.py TvLevel, Tv4Level are the statement the tests
@@ -826,6 +966,33 @@ extern "C" int pdeip_flow_ad_llin(const float *Iin, int nrows, int ncols, int ch
     if (ad.quantile > 1.0) return set_err(PDEIP_ERR_ARG, "%s: quantile must be in (0, 1]", who);
     ad.flow_diffusion = flow_diffusion != 0;
     return play(who, [&](Run &R) { flow_nd(R, Iin, nrows, ncols, channels, fst_term, snd_term, p, Us, Vs, U, V, ad); });
+}
+
+extern "C" int pdeip_flow_fas_fmg_elin(const float *Iin, int nrows, int ncols, int channels, const pdeip_fas_params *u, float *U, float *V)
+{
+    const char *who = "pdeip_flow_fas_fmg_elin";
+    NONNULL(who, Iin);
+    NONNULL(who, U);
+    NONNULL(who, V);
+    RC(check_dims(who, nrows, ncols, channels));
+    read_env_once();
+    FasParams p{0.035, 1.9, 0.03, 0.97, 0.5, 4, 4, PDEIP_SOLVER_ALR, 1, 0x7fffffff}; // FlowEminNDFASFMG_elin_2D_v10.m:53-69
+    if (u != nullptr) { // <= 0 or NaN: the driver's default
+        auto D = [](double v, double d) { return (v > 0.0) ? v : d; };
+        auto I = [](int v, int d) { return v > 0 ? v : d; };
+        p.alpha = D(u->alpha, p.alpha);
+        p.omega = D(u->omega, p.omega);
+        p.b1 = D(u->b1, p.b1);
+        p.b2 = D(u->b2, p.b2);
+        p.scl_factor = D(u->scl_factor, p.scl_factor);
+        p.firstLoop = I(u->firstLoop, p.firstLoop);
+        p.iter = I(u->iter, p.iter);
+        p.solver = I(u->solver, p.solver);
+        p.cycle_index = I(u->cycle_index, p.cycle_index);
+        p.scales = I(u->scales, p.scales);
+    }
+    RC(check_solver(who, p.solver));
+    return play(who, [&](Run &R) { fas_fmg(R, Iin, nrows, ncols, channels, p, U, V); });
 }
 
 extern "C" int pdeip_flow_hs_elin(const float *Iin, int nrows, int ncols, int channels, const pdeip_driver_params *prm, float *U, float *V)

@@ -418,3 +418,25 @@ def capi_FlowEminAD_llin_2D_v10(Iin, channels, fstTerm="rgb", sndTerm="none", mo
     finally:
         capi.set_mode(old)
     return U, V
+
+
+def capi_FlowEminNDFASFMG_elin_2D_v10(Iin, channels, mode=capi.MODE_EXACT_ORDER, **param):
+    """pdeip_flow_fas_fmg_elin: the C++ twin of FlowEminNDFASFMG_elin_2D_v10 above, same bits."""
+    import ctypes
+
+    class P(ctypes.Structure):
+        _fields_ = [(k, ctypes.c_double) for k in ("alpha", "omega", "b1", "b2", "scl_factor")] + \
+                   [(k, ctypes.c_int) for k in ("firstLoop", "iter", "solver", "cycle_index", "scales")]
+    prm = P()
+    for k, _ in P._fields_:
+        setattr(prm, k, type(getattr(prm, k))(param.get(k, 0) or 0))
+    I = _f_single(Iin)
+    rows, cols = I.shape[:2]
+    U, V = np.zeros((rows, cols), np.float32, order="F"), np.zeros((rows, cols), np.float32, order="F")
+    old = capi.get_mode()
+    capi.set_mode(mode)
+    try:
+        capi.call("pdeip_flow_fas_fmg_elin", I.ctypes.data, rows, cols, int(channels), ctypes.addressof(prm), U.ctypes.data, V.ctypes.data)
+    finally:
+        capi.set_mode(old)
+    return U, V

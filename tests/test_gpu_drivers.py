@@ -284,6 +284,27 @@ def test_resident_anisotropic_flow_driver_equals_the_python_driver(pdeip):
     assert pb.bit_equal(outs[0], want[0]) and pb.bit_equal(outs[1], want[1])
 
 
+def test_resident_fas_multigrid_driver_equals_the_python_driver(pdeip):
+    """pdeip_flow_fas_fmg_elin (runme.m:90 as one C-ABI call) against drivers.FlowEminNDFASFMG_elin_2D_v10 (fas.py), bit for bit:
+    Yosemite with the driver's defaults, both orderings and solvers, a W-cycle, a limited pyramid, three channels; and through the
+    MEX stub."""
+    import test_mex_stubs as tm
+    I, _, _ = _yosemite255()
+    D = drv()
+    I3 = np.concatenate([np.stack([I[:, :, k]] * 3, axis=2) * np.float32([1.0, 0.9, 0.8]) for k in range(2)], axis=2).astype(np.float32)
+    for img, ch, kw in ((I, 1, {}), (I, 1, dict(mode=pdeip.MODE_RED_BLACK, solver=1, omega=1.0)), (I, 1, dict(cycle_index=2, scales=4, firstLoop=2)),
+                        (I3, 3, dict(mode=pdeip.MODE_RED_BLACK, scales=3, iter=2))):
+        want = D.FlowEminNDFASFMG_elin_2D_v10(img, ch, **kw)
+        got = D.capi_FlowEminNDFASFMG_elin_2D_v10(img, ch, **kw)
+        for g, w in zip(got, want):
+            assert pb.bit_equal(g, w), "FAS %d channels %s: %s" % (ch, sorted(kw), pb.describe_mismatch(g, w))
+    pv = np.array([0, 0, 2, 0, 0, 0, 0, 1, 0, 4], dtype=np.float32).reshape(1, 10)   # firstLoop 2, solver 1, scales 4
+    err, outs = tm.call(tm.build_stub("FlowEminNDFASFMG_elin_2D_v10_gpu", pdeip), 2, [I, np.float32(1), pv])
+    assert err is None, err
+    want = D.FlowEminNDFASFMG_elin_2D_v10(I, 1, firstLoop=2, solver=1, scales=4)
+    assert pb.bit_equal(outs[0], want[0]) and pb.bit_equal(outs[1], want[1])
+
+
 def test_driver_stubs_through_the_mock_mex_runtime(pdeip):
     """mex/FlowEminND_llin_2D_v10_gpu.c and mex/DispEminND_llin_2D_gpu.c called as MATLAB would call them (numeric arguments:
     the .m wrappers under matlab/ translate the drivers' own argument lists): the Python driver's bits."""

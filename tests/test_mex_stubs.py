@@ -74,7 +74,7 @@ def test_all_gateways_have_a_stub():
     assert STUBS == sorted(["Oflow_sor_elin4_2d", "Oflow_sor_llin4_2d", "Oflow_sor_llin8_2d", "Oflow_lhs_elin4_2d",
                             "Oflow_lhs_llin4_2d", "Disp_sor_llin4_2d", "Disp_sor_llin_sym4_2d", "PDEsolver4", "PDEsolver8", "DdiffWeights",
                             "BilinInterp_2d", "FstDerivatives5", "SndDerivatives5",
-                            "FlowEminND_llin_2D_v10_gpu", "DispEminND_llin_2D_gpu", "TVdenoise8_gpu", "TVdenoise4_gpu", "FlowEminHS_elin_2D_v10_gpu", "DispEminND_llin_sym_2D_gpu", "FlowEminAD_llin_2D_v10_gpu"])   # the last seven: whole drivers, resident (section 2b of INTEGRATION.md)
+                            "FlowEminND_llin_2D_v10_gpu", "DispEminND_llin_2D_gpu", "TVdenoise8_gpu", "TVdenoise4_gpu", "FlowEminHS_elin_2D_v10_gpu", "DispEminND_llin_sym_2D_gpu", "FlowEminAD_llin_2D_v10_gpu", "FlowEminNDFASFMG_elin_2D_v10_gpu"])   # the last eight: whole drivers, resident (section 2b of INTEGRATION.md)
 
 
 @pytest.mark.parametrize("name", STUBS)
