@@ -479,8 +479,8 @@ int pdeip_median3_pair_dev(void *stream, const float *A0, const float *B0, const
                            float *out0, float *out1);
 
 /* ---- whole drivers, resident on the device (csrc/pdeip_drivers.hip) --------------------------------------------------------
- * What `runme.m` calls first -- FlowEminND_llin_2D_v10 (runme.m:44) and DispEminND_llin_2D (runme.m:20) -- as ONE host-pointer
- * call each: the frames go up once, the coarse-to-fine loop (pyramid, warps, derivatives, robust assembly, diffusion weights,
+ * What `runme.m` calls -- its eight drivers, FlowEminND_llin_2D_v10 (runme.m:44) and DispEminND_llin_2D (runme.m:20) first -- as ONE
+ * host-pointer call each: the frames go up once, the coarse-to-fine loop (pyramid, warps, derivatives, robust assembly, diffusion weights,
  * solver calls, medians, up-scaling) runs on device planes, the result comes down once.  A MATLAB session reaches them through
  * the stubs mex/FlowEminND_llin_2D_v10_gpu.c and mex/DispEminND_llin_2D_gpu.c.  The pyramid's IPT calls
  * (imresize, imfilter, fspecial) are OUR definitions of them (pyramid.py); everything between them is the arithmetic the

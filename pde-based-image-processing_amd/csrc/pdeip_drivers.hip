@@ -1,13 +1,18 @@
-// pdeip_drivers.hip -- libpdeip.so: the two drivers runme.m leads with, as host-pointer entry points that keep a whole
-// coarse-to-fine run resident on the device.
+// pdeip_drivers.hip -- libpdeip.so: the eight drivers runme.m calls, as host-pointer entry points that keep a whole coarse-to-fine
+// run resident on the device.
 //
-//   [U V] = FlowEminND_llin_2D_v10(Iin, channels, fstTerm, sndTerm, ...)   matlab/optical_flow/FlowEminND_llin_2D_v10.m:52-369
-//   U     = DispEminND_llin_2D(Il, Ir, fstTerm, sndTerm, ...)              matlab/disparity/DispEminND_llin_2D.m:51-316
+//   [U V] = FlowEminND_llin_2D_v10(Iin, channels, fstTerm, sndTerm, ...)   matlab/optical_flow/FlowEminND_llin_2D_v10.m:52-369       pdeip_flow_nd_llin
+//   [U V] = FlowEminAD_llin_2D_v10(...)                                     matlab/optical_flow/FlowEminAD_llin_2D_v10.m:52-383       pdeip_flow_ad_llin
+//   [U V] = FlowEminHS_elin_2D_v10(Iin, channels, ...)                      matlab/optical_flow/FlowEminHS_elin_2D_v10.m:52-200       pdeip_flow_hs_elin
+//   [U V] = FlowEminNDFASFMG_elin_2D_v10(Iin, channels, ...)                matlab/optical_flow/FlowEminNDFASFMG_elin_2D_v10.m:53-273 pdeip_flow_fas_fmg_elin
+//   U     = DispEminND_llin_2D(Il, Ir, fstTerm, sndTerm, ...)              matlab/disparity/DispEminND_llin_2D.m:51-316              pdeip_disp_nd_llin
+//   U     = DispEminND_llin_sym_2D(Il, Ir, ...)                            matlab/disparity/DispEminND_llin_sym_2D.m:51-275          pdeip_disp_nd_llin_sym
+//   Iout  = TVdenoise8(I_in, ...) / TVdenoise4(I_in, ...)                  matlab/denoising/TVdenoise{8,4}.m                         pdeip_tvdenoise8 / 4
 //
 // A MATLAB session that only swaps the MEX gateways pays 13-17 planes of PCIe traffic per solver call (7.8 ms per 4K call,
-// INTEGRATION.md); calling these instead moves the frames up once and the flow down once.  The level loop below is host
+// INTEGRATION.md); calling these instead moves the frames up once and the result down once.  The level loops below are host
 // control flow around the library's own device entry points -- the same `_dev` stage kernels, in the same order and with
-// the same arguments, as the Python drivers (drivers.py / flow_level.py / pyramid.py), which the tests compare with bit
+// the same arguments, as the Python drivers (drivers.py / flow_level.py / fas.py / pyramid.py), which the tests compare with bit
 // for bit.  The pyramid's imresize / imfilter / fspecial are the definitions of pyramid.py (csrc/pdeip_pyr.hpp), there
 // being no Image Processing Toolbox to compare with.  Ordering and solver as everywhere: pdeip_set_mode / PDEIP_MODE,
 // param.solver.

@@ -15,8 +15,9 @@ capi.MODE_RED_BLACK the parallel one).
 
 `Us=`, `Vs=` (param.Us / param.Vs: spatial a-priori fields, double, NaN = no constraint) and `scales=` (param.scales) are taken
 by the late-linearisation flow drivers and the disparity driver as the reference's drivers take them.
-The same two drivers also exist behind the C-ABI (pdeip_flow_nd_llin / pdeip_disp_nd_llin, csrc/pdeip_drivers.hip) for callers
-that are not Python -- the MATLAB session the toolbox runs in: `capi_drivers` below calls those.
+All eight also exist behind the C-ABI (pdeip_flow_nd_llin, pdeip_flow_ad_llin, pdeip_flow_hs_elin, pdeip_flow_fas_fmg_elin,
+pdeip_disp_nd_llin, pdeip_disp_nd_llin_sym, pdeip_tvdenoise8 / 4: csrc/pdeip_drivers.hip) for callers that are not Python -- the
+MATLAB session the toolbox runs in; the `capi_*` functions at the end of this file call those.
 `graph=True` (the llin flow drivers and the FAS driver, parallel orderings): the run's launches are captured into a HIP graph
 on the first call for a frame size and replayed afterwards (graphs.py) -- same kernels and bits, no per-launch host work.
 """
