@@ -558,6 +558,15 @@ def main():
                 torch.cuda.synchronize()
                 dr[name + "_graph"] = round((time.perf_counter() - t0) / nrep * 1e3, 1)
                 dr[name + "_graph_same_bits"] = bool(all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got)))
+            # the same driver as ONE C-ABI call (pdeip_flow_nd_llin, the level loop in C++: what the MEX stub of a MATLAB session calls)
+            kw = dict(mode=capi.MODE_RED_BLACK, solver=1, omega=1.5)
+            ref = drivers.FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", **kw)
+            got = drivers.capi_FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", **kw)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                drivers.capi_FlowEminND_llin_2D_v10(Iseq, 3, "grad", "gradmag", **kw)
+            dr["red_black_sor_cxx"] = round((time.perf_counter() - t0) / 20 * 1e3, 1)
+            dr["red_black_sor_cxx_same_bits"] = bool(all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got)))
             out["driver_nd_1080p"] = dr
             del Iseq
             # ---- the lagged-diffusivity loop of the TV denoiser resident in HBM (BASELINE config C3: 2160x3840 gray) ----
@@ -610,6 +619,15 @@ def main():
                     torch.cuda.synchronize()
                     fmg[name + "_graph"] = round((time.perf_counter() - t0) / reps * 1e3, 2)
                     fmg[name + "_graph_same_bits"] = bool(all(torch.equal(a, b) for a, b in zip(ref, got)))
+            # the same driver as ONE C-ABI call from host frames (pdeip_flow_fas_fmg_elin: 66 MB up, 66 MB down included)
+            Ifmg = np.asfortranarray(np.concatenate([F0, F1], axis=2))   # MATLAB's layout: no host-side copy inside the timed call
+            kwf = dict(mode=capi.MODE_RED_BLACK, solver=1, omega=1.0)
+            drivers.capi_FlowEminNDFASFMG_elin_2D_v10(Ifmg, 1, **kwf)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                drivers.capi_FlowEminNDFASFMG_elin_2D_v10(Ifmg, 1, **kwf)
+            fmg["red_black_sor_cxx_host_frames"] = round((time.perf_counter() - t0) / 10 * 1e3, 2)
+            del Ifmg
             s0, s1 = np.asfortranarray(F0[::4, ::4]), np.asfortranarray(F1[::4, ::4])
             sp = dict(fas.DEFAULTS, solver=1, omega=1.0, order=0)
             t0 = time.perf_counter()
