@@ -44,8 +44,7 @@ extern "C" {
 #define PDEIP_OK 0
 #define PDEIP_ERR_ARG 1         /* null pointer, nrows/ncols < 3, nframes < 1 */
 #define PDEIP_ERR_SOLVER 2      /* "no such solver" (gateway default: branch) */
-#define PDEIP_ERR_UNSUPPORTED 3 /* valid request outside what the device path covers (e.g. an exact-order ALR line
-                                    longer than 10000 pixels) */
+#define PDEIP_ERR_UNSUPPORTED 3 /* valid request outside what the device path covers */
 #define PDEIP_ERR_DEVICE 4      /* HIP runtime error / no gfx950 device */
 #define PDEIP_ERR_NOMEM 5
 
@@ -276,7 +275,7 @@ int pdeip_pde_sor8_dev(void *stream, float *X, const float *TRACE, const float *
 /* Alternating line relaxation, solver = 2 of the gateways (GS_ALR_SOR_*: opticalflowSolvers.c:196,690,1677;
  * disparitySolvers.c:154; pdeSolvers.c:277,344).  Iterate planes in place.
  *   mode PDEIP_MODE_EXACT_ORDER: the reference's line order, bit-identical, inherently serial (one
- *        workgroup per frame; a line must fit in LDS: at most 10000 pixels per line).
+ *        workgroup per frame; a line of more than 10240 pixels is held in global memory instead of LDS: slow).
  *   mode PDEIP_MODE_RED_BLACK:   zebra order (even lines, then odd lines), lines solved concurrently.
  * pdeip_pde_alr8_dev runs ONE iteration whatever `iter` is, like the reference (pdeSolvers.c:362). */
 int pdeip_oflow_alr_elin4_dev(void *stream, float *U, float *V, const float *M, const float *Cu,

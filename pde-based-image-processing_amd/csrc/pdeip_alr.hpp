@@ -1500,12 +1500,16 @@ __device__ __forceinline__ void alr_serial_wave(float4 *L, int n, int lane, bool
     }
 }
 
-template <class Mdl, int NCH, bool VERT>
+// GL: the line buffers live in global memory (`gline`: [frames][NCH][n] float4) instead of LDS -- lines of more than 10 240 pixels,
+// which the reference does not forbid; one workgroup works on a frame, so its barriers order those accesses as they order LDS.
+// Slow (every step of the serial recurrence is a global round trip) and only taken then.
+template <class Mdl, int NCH, bool VERT, bool GL = false>
 __global__ void __launch_bounds__(ALR_LEX_THREADS) k_alr_lex(AlrChains<Mdl, NCH> ch, int nrows, int ncols, size_t frame_stride,
-                                                             int lo, int hi, float omega)
+                                                             int lo, int hi, float omega, float4 *gline = nullptr)
 {
     constexpr bool vertical = VERT;
-    extern __shared__ float4 alr_lds[]; // NCH lines of n elements
+    extern __shared__ float4 alr_lds_raw[]; // NCH lines of n elements
+    float4 *const alr_lds = GL ? gline + (size_t)blockIdx.x * NCH * (vertical ? nrows : ncols) : alr_lds_raw;
     const size_t fo = (size_t)blockIdx.x * frame_stride;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {

@@ -20,7 +20,7 @@
 
 namespace pdeip {
 
-enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_CTL, WS_ORDER, WS_ALR, WS_ALR_T, WS_TV, WS_SMALL, WS_MAIL, WS_PACK, WS_DRIVER, WS_NSLOT };
+enum { WS_AUX0 = 0, WS_AUX1, WS_PING, WS_ARENA, WS_CTL, WS_ORDER, WS_ALR, WS_ALR_T, WS_TV, WS_SMALL, WS_MAIL, WS_PACK, WS_DRIVER, WS_LEX, WS_NSLOT };
 
 constexpr int MAX_DEVICES = 16;
 

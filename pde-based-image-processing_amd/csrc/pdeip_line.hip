@@ -11,16 +11,9 @@ using namespace pdeip;
 // ------------------------------------------------------------------------------------------------
 // alternating line relaxation (solver 2): pdeip_alr.hpp
 // ------------------------------------------------------------------------------------------------
-constexpr int ALR_LEX_MAX_LINE = 10000; // one float4 per line element in LDS (160 KB per workgroup)
-
-static int check_alr_line(const char *who, int mode, int nrows, int ncols)
-{
-    const int n = nrows > ncols ? nrows : ncols;
-    if (mode == PDEIP_MODE_EXACT_ORDER && n > ALR_LEX_MAX_LINE)
-        return set_err(PDEIP_ERR_UNSUPPORTED, "%s: exact-order line relaxation holds one line in LDS: at most %d pixels per line (got %d)",
-                       who, ALR_LEX_MAX_LINE, n);
-    return PDEIP_OK;
-}
+// exact-order line relaxation holds a line as one float4 per element: in LDS up to 10 240 elements (160 KB), in a global scratch
+// buffer beyond (k_alr_lex<.., GL = true>: correct, slow)
+static int check_alr_line(const char *, int, int, int) { return PDEIP_OK; }
 
 // Workspace of one call: per (chain, direction) the cp and divisor planes (k_alr_zebra3<ZB_FACTOR>).
 struct AlrFactors {
@@ -91,6 +84,19 @@ static int alr_lex_pass(hipStream_t s, const typename Mdl::Ctx *q, float *const 
     const size_t fs = (size_t)nrows * ncols;
     const int d = vertical ? 0 : 1;
     const size_t line_bytes = (size_t)n * sizeof(float4);
+    if (line_bytes > 160 * 1024) { // a line longer than LDS holds: the line buffer in global memory, one chain per launch
+        float *g = nullptr;
+        RC(ws_get(WS_LEX, line_bytes * nframes, &g));
+        for (int c = 0; c < nch; c++) {
+            AlrChains<Mdl, 1> ch;
+            ch.c[0] = AlrChain<Mdl>{q[order[c]], x[order[c]], f.cp[order[c]][d], f.dv[order[c]][d]};
+            if (vertical) hipLaunchKernelGGL((k_alr_lex<Mdl, 1, true, true>), dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), 0, s, ch, nrows, ncols, fs, lo, hi, omega, reinterpret_cast<float4 *>(g));
+            else hipLaunchKernelGGL((k_alr_lex<Mdl, 1, false, true>), dim3((unsigned)nframes), dim3(ALR_LEX_THREADS), 0, s, ch, nrows, ncols, fs, lo, hi, omega, reinterpret_cast<float4 *>(g));
+            tls.last_launches++;
+        }
+        HIPCHK(hipGetLastError());
+        return PDEIP_OK;
+    }
     if (nch == 2 && 2 * line_bytes <= 160 * 1024) {
         AlrChains<Mdl, 2> ch;
         for (int c = 0; c < 2; c++) ch.c[c] = AlrChain<Mdl>{q[order[c]], x[order[c]], f.cp[order[c]][d], f.dv[order[c]][d]};

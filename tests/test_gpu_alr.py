@@ -97,3 +97,17 @@ def test_alr_long_lines(pdeip, oracle, mode, order):
         got = pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(2), np.float32(1.5), TWO)
         check(got, oracle.Oflow_sor_elin4_2d(*p.values(), 2, 1.5, solver=2, order=order), "alr long lines %s mode=%d" % (shape, mode))
     pdeip.mex_api.set_mode(0)
+
+
+def test_alr_lines_beyond_lds(pdeip, oracle):
+    """Exact-order lines of more than 10 240 pixels do not fit the 160 KB of LDS: the line buffer then lives in global memory
+    (k_alr_lex<..., GL>).  The reference has no such limit; same bits as the oracle's line order, both directions, a coupled and
+    a scalar model."""
+    pdeip.mex_api.set_mode(0)
+    for shape in ((10300, 5), (6, 10290)):
+        p = pb.elin4(561, *shape, nan_frac=0.01)
+        got = pdeip.mex_api.Oflow_sor_elin4_2d(*p.values(), np.float32(1), np.float32(1.5), TWO)
+        check(got, oracle.Oflow_sor_elin4_2d(*p.values(), 1, 1.5, solver=2, order=0), "alr elin4 beyond LDS %s" % (shape,))
+        q = pb.pde4(562, *shape, nframes=2, nan_frac=0.01)
+        got = pdeip.mex_api.PDEsolver4(*q.values(), np.float32(1), np.float32(1.3), TWO)
+        check(got, oracle.PDEsolver4(*q.values(), 1, 1.3, solver=2, order=0), "alr pde4 beyond LDS %s" % (shape,))
