@@ -1373,6 +1373,23 @@ __global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3(typename Mdl::Ctx q, 
     alr_zebra3_body<Mdl, VERT, MODE>(q, x, cp, dv, dp, nrows, ncols, frame_stride, first, lastc, lstep, omega);
 }
 
+// One colour of BOTH fields of a coupled solver in one launch: field A's lines, then field B's same lines, by the same workgroup.
+// The passes run [A even, A odd, B even, B odd]; [A odd] and [B even] touch disjoint data (A odd writes A on odd lines and reads A on
+// even lines + B on odd lines; B even writes B on even lines and reads B on odd lines + A on even lines), so [A even, B even,
+// A odd, B odd] gives the same bits -- and B's lines need A only at their own pixels (the coupling term), which this workgroup has
+// just written.  Half the launches of a zebra iteration: at the drivers' scales a pass is 20-40 us of dependent steps and a launch
+// boundary ~5 us.
+template <class Mdl, bool VERT, int MODE>
+__global__ void __launch_bounds__(ZB_THREADS) k_alr_zebra3_pair(typename Mdl::Ctx qa, float *xa, float *__restrict__ cpa, float *__restrict__ dva,
+                                                                typename Mdl::Ctx qb, float *xb, float *__restrict__ cpb, float *__restrict__ dvb,
+                                                                float *__restrict__ dp, int nrows, int ncols, size_t frame_stride, int first,
+                                                                int lastc, int lstep, float omega)
+{
+    alr_zebra3_body<Mdl, VERT, MODE>(qa, xa, cpa, dva, dp, nrows, ncols, frame_stride, first, lastc, lstep, omega);
+    __syncthreads(); // field A's stores have left this workgroup's waves; field B's coefficients read them back
+    alr_zebra3_body<Mdl, VERT, MODE>(qb, xb, cpb, dvb, dp, nrows, ncols, frame_stride, first, lastc, lstep, omega);
+}
+
 // The factor passes of the two fields of a coupled solver in one launch (blockIdx.z = field): they are independent and each
 // is bound by its recurrence, so side by side they take the time of one.
 template <class Mdl, bool VERT>

@@ -153,6 +153,37 @@ static int alr_zebra_pass(hipStream_t s, const typename Mdl::Ctx &q, float *x, c
     return PDEIP_OK;
 }
 
+// Both fields of a coupled solver, one colour per launch (k_alr_zebra3_pair): field a first, then field b, as the per-field passes
+// would run them.  PDEIP_ALR_PAIR=0: one launch per field and colour.
+template <class Mdl>
+static int alr_zebra_pass_pair(hipStream_t s, const typename Mdl::Ctx &qa, float *xa, const float *cpa, const float *dva, const typename Mdl::Ctx &qb,
+                               float *xb, const float *cpb, const float *dvb, int nrows, int ncols, int nframes, bool vertical, float omega)
+{
+    const int lo = Mdl::INTERIOR_LINES ? 1 : 0;
+    const int hi = (vertical ? ncols : nrows) - 1 - lo;
+    const size_t fs = (size_t)nrows * ncols;
+    float *dp;
+    RC(ws_get(WS_AUX1, fs * nframes * sizeof(float), &dp));
+    if (vertical) RC(ensure_lds(reinterpret_cast<const void *>(&k_alr_zebra3_pair<Mdl, true, ZB_APPLY>), Z3_LDS_BYTES));
+    else RC(ensure_lds(reinterpret_cast<const void *>(&k_alr_zebra3_pair<Mdl, false, ZB_APPLY>), Z3_LDS_BYTES));
+    for (int colour = 0; colour < 2; colour++) {
+        const int first = lo + (((lo & 1) != colour) ? 1 : 0);
+        if (first > hi) continue;
+        const int lastc = hi - (((hi & 1) != colour) ? 1 : 0);
+        const int count = (lastc - first) / 2 + 1;
+        const dim3 grid((unsigned)((count + ZB_LW - 1) / ZB_LW), (unsigned)nframes);
+        if (vertical)
+            hipLaunchKernelGGL((k_alr_zebra3_pair<Mdl, true, ZB_APPLY>), grid, dim3(ZB_THREADS), Z3_LDS_BYTES, s, qa, xa, const_cast<float *>(cpa), const_cast<float *>(dva), qb, xb,
+                               const_cast<float *>(cpb), const_cast<float *>(dvb), dp, nrows, ncols, fs, first, lastc, 2, omega);
+        else
+            hipLaunchKernelGGL((k_alr_zebra3_pair<Mdl, false, ZB_APPLY>), grid, dim3(ZB_THREADS), Z3_LDS_BYTES, s, qa, xa, const_cast<float *>(cpa), const_cast<float *>(dva), qb, xb,
+                               const_cast<float *>(cpb), const_cast<float *>(dvb), dp, nrows, ncols, fs, first, lastc, 2, omega);
+        tls.last_launches++;
+    }
+    HIPCHK(hipGetLastError());
+    return PDEIP_OK;
+}
+
 // The row passes run on transposed copies of every plane (pdeip_alr.hpp).  A model's Ctx is a plain
 // struct of plane pointers; each distinct plane gets one transposed twin in the WS_ALR_T workspace.  The
 // coefficient planes are transposed once per call, the iterate planes around every row pass.
@@ -306,15 +337,21 @@ static int run_alr(const char *who, hipStream_t s, const typename Mdl::Ctx *q, f
     AlrFactors f{};
     static const bool zebra1 = env_int("PDEIP_ALR_ZEBRA1", 0) != 0; // the one-lane-per-line kernel for every model (A/B timing)
     if (mode == PDEIP_MODE_EXACT_ORDER || !zebra1) RC(alr_factor<Mdl>(s, q, qt, nch, nrows, ncols, nframes, &f));
+    // zebra order, two coupled fields, factor planes present: one launch per colour for both fields (k_alr_zebra3_pair)
+    const bool pair = mode != PDEIP_MODE_EXACT_ORDER && nch == 2 && f.cp[0][0] != nullptr && f.cp[1][0] != nullptr && env_int("PDEIP_ALR_PAIR", 1) != 0;
     SweepTimer timer(s);
     for (int it = 0; it < iter; it++) {
         if (mode == PDEIP_MODE_EXACT_ORDER)
             RC(alr_lex_pass<Mdl>(s, q, x, f, fwd, nch, nrows, ncols, nframes, true, omega));
+        else if (pair)
+            RC(alr_zebra_pass_pair<Mdl>(s, q[0], x[0], f.cp[0][0], f.dv[0][0], q[1], x[1], f.cp[1][0], f.dv[1][0], nrows, ncols, nframes, true, omega));
         else
             for (int c = 0; c < nch; c++) RC(alr_zebra_pass<Mdl>(s, q[c], x[c], f.cp[c][0], f.dv[c][0], nrows, ncols, nframes, true, omega));
         RC(alr_transpose_many(s, xt, x, nch, nrows, ncols, nframes));
         if (mode == PDEIP_MODE_EXACT_ORDER)
             RC(alr_lex_pass<Mdl>(s, qt, xt, f, nch == 2 ? rev : fwd, nch, nrows, ncols, nframes, false, omega));
+        else if (pair)
+            RC(alr_zebra_pass_pair<Mdl>(s, qt[1], xt[1], f.cp[1][1], f.dv[1][1], qt[0], xt[0], f.cp[0][1], f.dv[0][1], nrows, ncols, nframes, false, omega));
         else
             for (int c = nch - 1; c >= 0; c--) RC(alr_zebra_pass<Mdl>(s, qt[c], xt[c], f.cp[c][1], f.dv[c][1], nrows, ncols, nframes, false, omega));
         RC(alr_transpose_many(s, x, xt, nch, ncols, nrows, nframes));
